@@ -1,0 +1,490 @@
+#!/usr/bin/env python
+"""tools/gen_golden.py -- DEV-CONTAINER ONLY.  Generates tests/golden/*.npz.
+
+The reference (/root/reference, pure Python on detectron2==0.5) cannot run as-is here:
+detectron2 / fvcore / torchvision are absent and uninstallable.  This script
+  1. mounts oracle/d2_modules.py + oracle/d2.py under the ``detectron2.* / fvcore.* /
+     torchvision.*`` module names (everything else in those namespaces resolves to a
+     permissive dummy),
+  2. imports the REAL reference modules from /root/reference/pt,
+  3. drives the reference's own functions/classes with small seeded inputs,
+  4. writes inputs + outputs as small .npz fixtures (numbers only).
+No reference source text is copied; only numeric vectors are committed.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+"""
+import importlib.abc
+import importlib.machinery
+import os
+import random
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import d2, d2_modules as dm, pt as opt  # noqa: E402
+
+# ------------------------------------------------------------------ permissive stubs
+STUB_ROOTS = ("detectron2", "fvcore", "torchvision", "pycocotools", "cv2", "augment")
+
+
+class _DummyMeta(type):
+    def __getattr__(cls, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _make_dummy(name)
+
+    def __call__(cls, *a, **k):
+        if cls.__dict__.get("_is_dummy_leaf", False) and not cls.__dict__.get("_subclassed", False):
+            return _make_dummy("inst")
+        return super().__call__(*a, **k)
+
+
+def _make_dummy(name):
+    return _DummyMeta("Dummy_" + name, (object,), {"_is_dummy_leaf": True})
+
+
+class _StubModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        d = _make_dummy(name)
+        setattr(self, name, d)
+        return d
+
+
+class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, fullname, path, target=None):
+        if fullname.split(".")[0] in STUB_ROOTS:
+            return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _StubModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+def install_stubs():
+    sys.meta_path.insert(0, _Finder())
+    import importlib
+
+    def mod(name):
+        return importlib.import_module(name)
+
+    real = {
+        "detectron2.config": dict(configurable=dm.configurable, CfgNode=dm.CfgNode, get_cfg=dm.get_cfg),
+        "detectron2.layers": dict(ShapeSpec=dm.ShapeSpec, batched_nms=d2.batched_nms, cat=d2.cat,
+                                  cross_entropy=d2.cross_entropy, nonzero_tuple=d2.nonzero_tuple,
+                                  CNNBlockBase=dm.CNNBlockBase, Conv2d=dm.Conv2d, get_norm=dm.get_norm),
+        "detectron2.modeling.anchor_generator": dict(
+            build_anchor_generator=dm.build_anchor_generator, ANCHOR_GENERATOR_REGISTRY=dm.ANCHOR_GENERATOR_REGISTRY,
+            _broadcast_params=d2.broadcast_params, _create_grid_offsets=d2.create_grid_offsets,
+            DefaultAnchorGenerator=dm.DefaultAnchorGenerator),
+        "detectron2.modeling.matcher": dict(Matcher=d2.Matcher),
+        "detectron2.modeling.proposal_generator": dict(RPN=dm.RPN, StandardRPNHead=dm.StandardRPNHead),
+        "detectron2.modeling.proposal_generator.build": dict(PROPOSAL_GENERATOR_REGISTRY=dm.PROPOSAL_GENERATOR_REGISTRY),
+        "detectron2.modeling.proposal_generator.rpn": dict(RPN_HEAD_REGISTRY=dm.RPN_HEAD_REGISTRY,
+                                                           build_rpn_head=dm.build_rpn_head),
+        "detectron2.modeling.proposal_generator.proposal_utils": dict(_is_tracing=lambda: False),
+        "detectron2.structures": dict(Boxes=d2.Boxes, ImageList=d2.ImageList, pairwise_iou=d2.pairwise_iou,
+                                      Instances=d2.Instances),
+        "detectron2.structures.boxes": dict(Boxes=d2.Boxes),
+        "detectron2.utils.events": dict(get_event_storage=dm.get_event_storage),
+        "detectron2.utils.memory": dict(retry_if_cuda_oom=dm.retry_if_cuda_oom),
+        "detectron2.utils.registry": dict(Registry=dm.Registry),
+        "detectron2.modeling.roi_heads": dict(ROI_HEADS_REGISTRY=dm.ROI_HEADS_REGISTRY,
+                                              StandardROIHeads=dm.StandardROIHeads),
+        "detectron2.modeling.roi_heads.box_head": dict(build_box_head=dm.build_box_head),
+        "detectron2.modeling.roi_heads.fast_rcnn": dict(FastRCNNOutputLayers=dm.FastRCNNOutputLayers),
+        "detectron2.modeling.poolers": dict(ROIPooler=dm.ROIPooler),
+        "detectron2.modeling.meta_arch.build": dict(META_ARCH_REGISTRY=dm.META_ARCH_REGISTRY),
+        "detectron2.modeling.meta_arch.rcnn": dict(GeneralizedRCNN=dm.GeneralizedRCNN),
+        "detectron2.modeling.backbone.backbone": dict(Backbone=dm.Backbone),
+        "detectron2.modeling.backbone.build": dict(BACKBONE_REGISTRY=dm.BACKBONE_REGISTRY),
+        "detectron2.utils.comm": dict(get_world_size=lambda: 1, gather=lambda x, dst=0: [x],
+                                      is_main_process=lambda: True, get_local_rank=lambda: 0),
+        "fvcore.nn.weight_init": dict(c2_msra_fill=d2.c2_msra_fill, c2_xavier_fill=d2.c2_xavier_fill),
+    }
+    for name, attrs in real.items():
+        m = mod(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+    # `import detectron2.utils.comm as comm` / `import fvcore.nn.weight_init as weight_init`
+    import fvcore.nn
+    fvcore.nn.weight_init = mod("fvcore.nn.weight_init")
+    import detectron2.utils
+    detectron2.utils.comm = mod("detectron2.utils.comm")
+    sys.path.insert(0, REF)
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy().copy()
+    return np.asarray(t)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.1f} kB)")
+
+
+# ------------------------------------------------------------------ synthetic inputs
+def rand_boxes(g, n, h, w, min_size=16.0):
+    cx = torch.rand(n, generator=g) * w
+    cy = torch.rand(n, generator=g) * h
+    bw = torch.exp(torch.rand(n, generator=g) * (math_log(w * 0.6) - math_log(min_size)) + math_log(min_size))
+    bh = torch.exp(torch.rand(n, generator=g) * (math_log(h * 0.6) - math_log(min_size)) + math_log(min_size))
+    b = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)
+    b[:, 0::2].clamp_(0, w)
+    b[:, 1::2].clamp_(0, h)
+    return b
+
+
+def math_log(x):
+    import math
+    return math.log(x)
+
+
+def synth_image(seed, h, w):
+    """uint8 CHW image from numpy's frozen legacy RandomState (identical on every box), so the
+    fixtures store three ints per image instead of the pixels."""
+    return torch.from_numpy(np.random.RandomState(seed).randint(0, 256, (3, h, w)).astype(np.uint8))
+
+
+def make_records(g, n, h, w, K, m=5, labelled=True):
+    recs = []
+    for _ in range(n):
+        img_seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=g))
+        r = {"image": synth_image(img_seed, h, w), "height": h, "width": w, "_img_seed": (img_seed, h, w)}
+        if labelled:
+            from pt.structures.instances import FreeInstances
+            inst = FreeInstances((h, w))
+            inst.gt_boxes = d2.Boxes(rand_boxes(g, m, h, w))
+            inst.gt_classes = torch.randint(0, K, (m,), generator=g)
+            r["instances"] = inst
+        recs.append(r)
+    return recs
+
+
+def records_to_arrays(prefix, recs):
+    out = {}
+    for i, r in enumerate(recs):
+        if "_img_seed" in r:
+            out[f"{prefix}{i}_imgseed"] = np.asarray(r["_img_seed"] + tuple(r["image"].shape[-2:]))
+        else:
+            out[f"{prefix}{i}_image"] = r["image"]
+        if "instances" in r:
+            out[f"{prefix}{i}_gt_boxes"] = r["instances"].gt_boxes.tensor
+            out[f"{prefix}{i}_gt_classes"] = r["instances"].gt_classes
+    return out
+
+
+# ------------------------------------------------------------------ generators
+def gen_box_codec():
+    from pt.modeling.box_regression import Box2BoxTransform, gaussian_dist_pdf
+    g = torch.Generator().manual_seed(11)
+    src = rand_boxes(g, 64, 300, 400)
+    tgt = rand_boxes(g, 64, 300, 400)
+    out = {"src": src, "tgt": tgt}
+    for tag, w in (("rpn", (1.0, 1.0, 1.0, 1.0)), ("roi", (10.0, 10.0, 5.0, 5.0))):
+        t = Box2BoxTransform(weights=w)
+        d = t.get_deltas(src, tgt)
+        out[f"deltas_{tag}"] = d
+        big = torch.randn(64, 16, generator=g) * 2.0
+        big[0, 2] = 50.0  # exercises the scale clamp
+        out[f"apply_in_{tag}"] = big
+        out[f"apply_out_{tag}"] = t.apply_deltas(big, src)
+        out[f"roundtrip_{tag}"] = t.apply_deltas(d, src)
+    # the known answers recorded in SURVEY.md 8c
+    t = Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0))
+    ka_src = torch.tensor([[10., 20., 110., 220.], [0., 0., 50., 40.]])
+    ka_tgt = torch.tensor([[12., 25., 100., 200.], [5., 5., 45., 50.]])
+    out["ka_src"], out["ka_tgt"], out["ka_deltas"] = ka_src, ka_tgt, t.get_deltas(ka_src, ka_tgt)
+    val = torch.randn(32, 4, generator=g)
+    mean = torch.randn(32, 4, generator=g)
+    var = torch.rand(32, 4, generator=g)
+    out.update(pdf_val=val, pdf_mean=mean, pdf_var=var, pdf=gaussian_dist_pdf(val, mean, var))
+    out["pdf_ka"] = gaussian_dist_pdf(torch.tensor([0.1, 0.5]), torch.tensor([0.0, 0.0]), torch.tensor([0.5, 0.2]))
+    save("box_codec", **out)
+
+
+def build_cfg(K=8, anchor="DefaultAnchorGenerator", tau=(0.25, 0.25), vgg_path=None, burn=1):
+    from pt.config import add_config
+    cfg = dm.get_cfg()
+    add_config(cfg)
+    cfg.merge_from_dict(dict(
+        MODEL=dict(META_ARCHITECTURE="GuassianGeneralizedRCNN", BACKBONE=dict(NAME="build_vgg_backbone"),
+                   VGG=dict(DEPTH=16, PRETRAIN=vgg_path),
+                   ANCHOR_GENERATOR=dict(NAME=anchor, SIZES=[[128, 256, 512]], ASPECT_RATIOS=[[0.5, 1.0, 2.0]]),
+                   PROPOSAL_GENERATOR=dict(NAME="GuassianRPN"),
+                   RPN=dict(POSITIVE_FRACTION=0.25, PRE_NMS_TOPK_TEST=6000, POST_NMS_TOPK_TEST=1000,
+                            IN_FEATURES=["vgg_block5"], HEAD_NAME="GuassianRPNHead"),
+                   ROI_HEADS=dict(NAME="GuassianROIHead", IN_FEATURES=["vgg_block5"], NUM_CLASSES=K),
+                   ROI_BOX_HEAD=dict(NAME="FastRCNNConvFCHead", NUM_FC=2, FC_DIM=1024, POOLER_RESOLUTION=7)),
+        SOLVER=dict(BASE_LR=0.016, WARMUP_ITERS=400, STEPS=(30000,)),
+        UNSUPNET=dict(BURN_UP_STEP=burn, EMA_KEEP_RATE=0.9996, TAU=list(tau), EFL=True, EFL_LAMBDA=[0.5, 0.5]),
+    ))
+    return cfg
+
+
+def oracle_cfg(K, anchor, tau, burn=1):
+    return opt.Cfg(num_classes=K, anchor_generator=anchor, tau=tuple(tau), burn_up_step=burn)
+
+
+def write_fake_vgg(params, path):
+    idx = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+    names = [f"backbone.vgg_block{b}.0.conv{k}" for b, ch in enumerate(opt.VGG16_BLOCKS, 1) for k in range(1, len(ch) + 1)]
+    sd = {}
+    for i, n in zip(idx, names):
+        sd[f"features.{i}.weight"] = params[n + ".weight"].clone()
+        sd[f"features.{i}.bias"] = params[n + ".bias"].clone()
+    torch.save(sd, path)
+
+
+def build_reference_model(K, anchor, tau, seed=0, burn=1):
+    """Construct the real reference meta-arch and load the seeded parameter set."""
+    import pt.modeling.meta_arch.rcnn  # noqa: F401 (registers)
+    import pt.modeling.backbone.vgg  # noqa: F401
+    import pt.modeling.proposal_generator.rpn  # noqa: F401
+    import pt.modeling.roi_heads.roi_heads  # noqa: F401
+    import pt.modeling.anchor_generator  # noqa: F401
+    ocfg = oracle_cfg(K, anchor, tau, burn)
+    params = opt.golden_params(ocfg, seed)
+    tmp = tempfile.mkdtemp()
+    vp = os.path.join(tmp, "vgg16_caffe.pth")
+    write_fake_vgg(params, vp)
+    cfg = build_cfg(K, anchor, tau, vp, burn)
+    model = dm.build_model(cfg)
+    missing = model.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+    model.train()
+    return cfg, ocfg, params, model
+
+
+def inst_arrays(prefix, insts, fields):
+    out = {}
+    for i, r in enumerate(insts):
+        for f in fields:
+            if r.has(f):
+                v = r.get(f)
+                out[f"{prefix}{i}_{f}"] = v.tensor if hasattr(v, "tensor") else v
+    return out
+
+
+def gen_model_branches(anchor, tag):
+    """Full reference model, 3 branches, small images; weights = oracle.pt.init_params(seed) tweaked
+    exactly as build_reference_model does (the test re-creates them from the seed)."""
+    K, tau, seed = 8, (0.25, 0.25), 3
+    cfg, ocfg, params, model = build_reference_model(K, anchor, tau, seed)
+    g = torch.Generator().manual_seed(100)
+    H, W = 160, 224
+    recs = make_records(g, 2, H, W, K, m=4)
+    recs[1]["image"] = recs[1]["image"][:, :144, :208].contiguous()      # ragged batch -> padding path
+    recs[1]["height"], recs[1]["width"] = 144, 208
+    recs[1]["instances"]._image_size = (144, 208)
+    recs[1]["instances"].gt_boxes.clip((144, 208))
+    out = dict(seed=seed, K=K, tau=np.asarray(tau), perm_seed=77)
+    out.update(records_to_arrays("sup", recs))
+
+    # ---- supervised branch: losses + gradients
+    dm.PERM_FN = opt.SeededPerm(77)
+    model.zero_grad()
+    losses, _, _, _ = model(recs, branch="supervised")
+    total = sum(losses.values())
+    total.backward()
+    for k, v in losses.items():
+        out["sup_" + k] = v
+    sd = dict(model.named_parameters())
+    for k in ("backbone.vgg_block3.0.conv1.weight", "backbone.vgg_block5.0.conv3.bias",
+              "proposal_generator.rpn_head.conv.weight", "proposal_generator.rpn_head.anchor_deltas.weight",
+              "roi_heads.box_head.fc2.weight", "roi_heads.box_predictor.bbox_pred.weight",
+              "roi_heads.box_predictor.cls_score.bias"):
+        gk = sd[k].grad
+        out["supgrad_sum_" + k] = gk.double().sum()
+        out["supgrad_norm_" + k] = gk.double().norm()
+        out["supgrad_head_" + k] = gk.flatten()[:32].clone()
+    out["sup_perm_log"] = np.asarray(dm.PERM_FN.log)
+
+    # ---- teacher branch
+    weak = make_records(g, 2, H, W, K, labelled=False)
+    out.update(records_to_arrays("weak", weak))
+    dm.PERM_FN = opt.SeededPerm(78)
+    with torch.no_grad():
+        _, prop_rpn, prop_roih, pred = model(weak, branch="unsup_data_weak")
+    out.update(inst_arrays("t_rpn", prop_rpn, ["proposal_boxes", "objectness_logits"]))
+    out.update(inst_arrays("t_roih", prop_roih, ["pred_boxes", "scores", "pred_classes", "scores_logists", "boxes_sigma"]))
+    out["t_pred_scores"], out["t_pred_deltas"] = pred
+
+    # ---- unsupervised branch on the strong views with the teacher's pseudo labels
+    from pt.engine.trainer import PTrainer
+    tr = PTrainer.__new__(PTrainer)
+    pseudo, _ = tr.process_pseudo_label(prop_roih, "roih", "all")
+    strong = make_records(g, 2, H, W, K, labelled=False)
+    out.update(records_to_arrays("strong", strong))
+    for r, p in zip(strong, pseudo):
+        r["instances"] = p
+    model.zero_grad()
+    dm.PERM_FN = opt.SeededPerm(79)
+    losses_u, _, _, _ = model(strong, branch="unsupervised", danchor=True)
+    sum(losses_u.values()).backward()
+    for k, v in losses_u.items():
+        out["unsup_" + k] = v
+    for k in ("backbone.vgg_block3.0.conv1.weight", "proposal_generator.rpn_head.anchor_deltas.weight",
+              "roi_heads.box_head.fc2.weight", "roi_heads.box_predictor.bbox_pred.weight",
+              "proposal_generator.anchor_generator.anchor_0"):
+        if k in sd and sd[k].grad is not None:
+            gk = sd[k].grad
+            out["unsupgrad_sum_" + k] = gk.double().sum()
+            out["unsupgrad_norm_" + k] = gk.double().norm()
+            out["unsupgrad_head_" + k] = gk.flatten()[:32].clone()
+    save("model_" + tag, **out)
+
+
+def gen_trainer_pieces():
+    from pt.engine.trainer import PTrainer
+    from pt.structures.instances import FreeInstances
+    g = torch.Generator().manual_seed(5)
+    tr = PTrainer.__new__(PTrainer)
+    out = {}
+    # --- resize (shrink & paste) with a pinned ratio
+    class _M:
+        pixel_mean = torch.tensor([103.530, 116.280, 123.675]).view(3, 1, 1)
+    tr.model = _M()
+    recs = make_records(g, 2, 90, 120, 8, m=3)
+    recs[1]["instances"].pseudo_boxes = d2.Boxes(rand_boxes(g, 3, 90, 120))
+    ratios = [0.731, 0.5]
+    res = []
+    for r, q in zip(recs, ratios):
+        orig = random.uniform
+        random.uniform = lambda a, b, q=q: q
+        try:
+            res.append(tr.resize([r])[0])
+        finally:
+            random.uniform = orig
+    out.update(records_to_arrays("rz_in", recs))
+    out["rz_in1_pseudo_boxes"] = recs[1]["instances"].pseudo_boxes.tensor
+    out["rz_ratios"] = np.asarray(ratios)
+    for i, r in enumerate(res):
+        out[f"rz_out{i}_image"] = r["image"]
+        out[f"rz_out{i}_gt_boxes"] = r["instances"].gt_boxes.tensor
+    out["rz_out1_pseudo_boxes"] = res[1]["instances"].pseudo_boxes.tensor
+
+    # --- EMA + clip on a small module
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(7, 5)
+            self.b = torch.nn.Conv2d(3, 4, 3)
+    torch.manual_seed(9)
+    s, t = Net(), Net()
+    out["ema_s"] = torch.cat([p.flatten() for p in s.state_dict().values()])
+    out["ema_t"] = torch.cat([p.flatten() for p in t.state_dict().values()])
+    tr.model, tr.model_teacher = s, t
+    tr._update_teacher_model(keep_rate=0.9996)
+    out["ema_out"] = torch.cat([p.flatten() for p in t.state_dict().values()])
+    for p in s.parameters():
+        p.grad = torch.randn(p.shape, generator=g) * 3.0
+    out["clip_in"] = torch.cat([p.grad.flatten() for p in s.parameters()])
+    tr.clip_gradient(s, 10.0)
+    out["clip_out"] = torch.cat([p.grad.flatten() for p in s.parameters()])
+    save("trainer_pieces", **out)
+
+
+def gen_run_step():
+    """Three consecutive real PTrainer.run_step calls (burn-in, EMA-copy + mutual, EMA + mutual)."""
+    from pt.engine.trainer import PTrainer
+    K, tau, seed, anchor = 8, (0.5, 0.5), 4, "DifferentiableAnchorGenerator"
+    cfg, ocfg, params, student = build_reference_model(K, anchor, tau, seed, burn=1)
+    _, _, tparams, teacher = build_reference_model(K, anchor, tau, seed + 10, burn=1)
+    g = torch.Generator().manual_seed(200)
+    H, W, B = 128, 160, 1
+    out = dict(seed=seed, teacher_seed=seed + 10, K=K, tau=np.asarray(tau), B=B)
+
+    tr = PTrainer.__new__(PTrainer)
+    tr.cfg, tr.model, tr.model_teacher = cfg, student, teacher
+    lr_holder = {}
+    trainable = [p for p in student.parameters() if p.requires_grad]
+    tr.optimizer = torch.optim.SGD([{"params": [p]} for p in trainable], lr=0.0, momentum=0.9, weight_decay=1e-4)
+
+    class _T:
+        pass
+    tr._trainer = _T()
+    metrics_log = []
+    tr._write_metrics = lambda m: metrics_log.append({k: float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
+                                                      for k, v in m.items()})
+    probes = ["backbone.vgg_block3.0.conv1.weight", "backbone.vgg_block5.0.conv3.bias",
+              "proposal_generator.rpn_head.conv.weight", "proposal_generator.anchor_generator.anchor_0",
+              "roi_heads.box_head.fc1.weight", "roi_heads.box_predictor.bbox_pred.weight"]
+    for it in range(3):
+        data = tuple(make_records(g, B, H, W, K, m=3) for _ in range(4))
+        for j, nm in enumerate(("lq", "lk", "uq", "uk")):
+            out.update(records_to_arrays(f"it{it}_{nm}", data[j]))
+        n_rz = 2 * B
+        ratios = [0.5 + 0.5 * float(torch.rand(1, generator=g)) for _ in range(n_rz)]
+        out[f"it{it}_ratios"] = np.asarray(ratios)
+        rq = list(ratios)
+        orig = random.uniform
+        random.uniform = lambda a, b: rq.pop(0)
+        dm.PERM_FN = opt.SeededPerm(500 + it)
+        lr = d2.warmup_multistep_lr(it, 0.016, (30000,), 0.1, 1e-3, 400)
+        for gp in tr.optimizer.param_groups:
+            gp["lr"] = lr
+        tr.iter = it
+        tr._trainer._data_loader_iter = iter([data])
+        captured = []
+        orig_ppl = PTrainer.process_pseudo_label
+
+        def spy_ppl(self, *a, **k):
+            r = orig_ppl(self, *a, **k)
+            captured.append(r[0])
+            return r
+        PTrainer.process_pseudo_label = spy_ppl
+        try:
+            tr.run_step()
+        finally:
+            random.uniform = orig
+            PTrainer.process_pseudo_label = orig_ppl
+        if captured:   # the teacher's pseudo labels as the reference's student consumed them
+            out.update(inst_arrays(f"it{it}_pseudo", captured[0], ["pseudo_boxes", "scores_logists", "boxes_sigma"]))
+        for k, v in metrics_log[-1].items():
+            if k != "data_time":
+                out[f"it{it}_m_{k}"] = v
+        ssd, tsd = student.state_dict(), teacher.state_dict()
+        for k in probes:
+            out[f"it{it}_s_sum_{k}"] = ssd[k].double().sum()
+            out[f"it{it}_s_head_{k}"] = ssd[k].flatten()[:16].clone()
+            out[f"it{it}_t_sum_{k}"] = tsd[k].double().sum()
+            out[f"it{it}_t_head_{k}"] = tsd[k].flatten()[:16].clone()
+    save("run_step", **out)
+
+
+def main():
+    install_stubs()
+    torch.Tensor.cuda = lambda self, *a, **k: self   # anchor_generator.py:69 hard-codes .cuda()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["codec", "pieces", "model", "step"]
+    if "codec" in which:
+        gen_box_codec()
+    if "pieces" in which:
+        gen_trainer_pieces()
+    if "model" in which:
+        gen_model_branches("DefaultAnchorGenerator", "default_anchor")
+        gen_model_branches("DifferentiableAnchorGenerator", "diff_anchor")
+    if "step" in which:
+        gen_run_step()
+
+
+if __name__ == "__main__":
+    main()
