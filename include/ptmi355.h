@@ -1,0 +1,220 @@
+/*
+ * ptmi355.h -- C ABI of libptmi355.so: the MI355X (gfx950 / CDNA4) operators behind the
+ * ProbabilisticTeacher teacher+student train step (PTrainer.run_step, reference
+ * /root/reference/pt/engine/trainer.py:263-392).
+ *
+ * The reference has NO native boundary of its own: it is pure Python and reaches native code
+ * only through torch/ATen, cuDNN, torchvision C++/CUDA ops and NCCL.  Each entry point below
+ * replaces one of those implicitly-invoked native operators; the comment on each names the
+ * reference call site (file:line relative to /root/reference) whose operator it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch types.  All pointers are DEVICE pointers
+ *     unless the name ends in _host.  fp32 tensors are dense row-major NCHW / (R,C) unless noted.
+ *   - The caller allocates every output and workspace; the library never allocates, frees or
+ *     synchronises; every kernel is enqueued on the passed hipStream_t (void* here).
+ *   - Return 0 on success, negative on error; ptmi_last_error() gives a thread-local message.
+ *   - int64 indices, uint8 masks, fp32 floats, matching the reference's observable dtypes.
+ */
+#ifndef PTMI355_H
+#define PTMI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ptmi_stream_t; /* hipStream_t */
+
+const char* ptmi_last_error(void);
+int ptmi_abi_version(void);
+
+/* ------------------------------------------------------------------ conv stack (N1, N3)
+ * replaces cuDNN conv2d 3x3 s1 p1 (+bias) + F.relu_ at pt/modeling/backbone/vgg.py:45-53,66-69
+ * and the D2 StandardRPNHead 3x3 conv at pt/modeling/proposal_generator/rpn.py:96.
+ * fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.
+ *
+ * Packed weight layout (built by ptmi_conv3x3_pack_weights): for BM = ptmi_conv3x3_bm(Cout),
+ * CK = ptmi_conv3x3_ck(Cin):  [ceil(Cout/BM)][ceil(Cin/CK)][9 taps][CK][BM] fp32, zero padded.
+ * mode 0 = forward weights  Wp[co][ci][ky][kx]            = W[co][ci][ky][kx]
+ * mode 1 = dgrad weights    (roles of co/ci swapped)      = W[ci][co][2-ky][2-kx]
+ *          i.e. dX = conv3x3(dY, pack(W, mode 1)) with "Cin" := Cout(W), "Cout" := Cin(W).
+ */
+int ptmi_conv3x3_bm(int cout);
+int ptmi_conv3x3_ck(int cin);
+int64_t ptmi_conv3x3_packed_floats(int cin, int cout);
+int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode,
+                              ptmi_stream_t s);
+/* epilogue: 0 = y = acc + bias;  1 = y = relu(acc + bias);  2 = y = acc (bias may be NULL);
+ *           3 = y = (mask_ref[idx] > 0) ? acc : 0   (dgrad through the producer's ReLU;
+ *               mask_ref has the shape of y). */
+int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                     float* y, int n, int cin, int cout, int h, int w, int epilogue,
+                     ptmi_stream_t s);
+/* wgrad: dw[co][ci][3][3] (+)= sum_{n,y,x} dy[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1].
+ * workspace: ptmi_conv3x3_wgrad_ws_floats(...) fp32; split-K partials reduced in a fixed order
+ * (deterministic).  accumulate != 0 adds into dw.  db (may be NULL) = sum dy over n,y,x. */
+int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
+int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws,
+                       int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
+/* dz = dy * (y > 0), elementwise (ReLU backward; F.relu_ at vgg.py:67). In-place allowed. */
+int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ max pool (N2)
+ * replaces ATen MaxPool2d(2,2) fwd/bwd at vgg.py:59,71 (floor mode).  bwd routes the gradient to
+ * the first maximum of each window in (0,0),(0,1),(1,0),(1,1) order (ATen CPU semantics). */
+int ptmi_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, ptmi_stream_t s);
+int ptmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,
+                        ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ GEMM (N3 1x1 convs, N13 FC)
+ * replaces cuBLAS Linear (D2 FastRCNNConvFCHead; fast_rcnn.py:164) and the 1x1 RPN convs.
+ * C[b] (M,N) = op(A[b]) (M,K) * op(B[b]) (K,N)  [+ bias] [relu] [+ C if accumulate]
+ * ta: 0 -> A stored (M,K) row-major with leading dim lda; 1 -> stored (K,M).
+ * tb: 0 -> B stored (K,N) row-major with leading dim ldb; 1 -> stored (N,K).
+ * bias_mode: 0 none, 1 per-row (M), 2 per-column (N).  batch strides in elements.
+ * fp32 on v_mfma_f32_32x32x2_f32; k-ordered accumulation (deterministic). */
+int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, int m, int n,
+                  int k, int lda, int ldb, int ldc, int ta, int tb, int bias_mode, int relu,
+                  int accumulate, int batch, int64_t stride_a, int64_t stride_b,
+                  int64_t stride_c, ptmi_stream_t s);
+/* column sums: out[j] (+)= sum_i a[i][j]  (bias gradients), a is (rows, cols) row-major. */
+int ptmi_colsum(const float* a, float* out, int rows, int cols, int accumulate, ptmi_stream_t s);
+/* row sums over the inner dim: out[i] (+)= sum_j a[i][j] for each of `batch` slabs summed. */
+int ptmi_rowsum_batched(const float* a, float* out, int batch, int rows, int cols, int accumulate,
+                        ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ ROIAlign (N12)
+ * replaces torchvision roi_align(aligned=True, sampling_ratio=0) built at
+ * pt/modeling/roi_heads/roi_heads.py:68-73 and called at :126.  rois (R,5)=[img,x1,y1,x2,y2]. */
+int ptmi_roi_align_fwd(const float* feat, const float* rois, float* out, int n, int c, int h,
+                       int w, int r, int pooled, float scale, ptmi_stream_t s);
+/* dfeat must be zeroed by the caller (atomic scatter-add). */
+int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n, int c, int h,
+                       int w, int r, int pooled, float scale, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ boxes (N4, N5, N9)
+ * anchors: D2 DefaultAnchorGenerator / pt/modeling/anchor_generator.py:108-122: out (h*w*A,4),
+ * anchor n=(y*w+x)*A+a = [x*stride,y*stride,x*stride,y*stride] + cell[a] (offset 0 folded in). */
+int ptmi_grid_anchors(const float* cell, float* out, int h, int w, int a, float stride,
+                      float offset, ptmi_stream_t s);
+/* Box2BoxTransform.apply_deltas, pt/modeling/box_regression.py:101-139.
+ * deltas (rows, 4*k) with row stride `dstride` floats, boxes (nb,4) with row i using box
+ * i % nb (nb = rows, or the anchor count when the same anchors repeat per image). */
+int ptmi_apply_deltas(const float* deltas, const float* boxes, float* out, int64_t rows, int k,
+                      int dstride, int64_t nb, float wx, float wy, float ww, float wh,
+                      float scale_clamp, ptmi_stream_t s);
+/* Box2BoxTransform.get_deltas, box_regression.py:66-99 (with the +1e-9 inside the logs). */
+int ptmi_get_deltas(const float* src, const float* tgt, float* out, int64_t rows, float wx,
+                    float wy, float ww, float wh, ptmi_stream_t s);
+/* pairwise_iou + Matcher fused (rpn.py:414-415; roi_heads.py:207-214).
+ * gt (m,4), boxes (nb,4); thresholds_host / labels_host are HOST arrays.  Outputs per box: matched gt index (int64, argmax over gt, lowest
+ * index on ties), label (int8).  thresholds: n_thr in {1,2}; labels[n_thr+1].
+ * allow_low_quality: every box whose IoU with gt i equals gt i's best IoU gets label 1.
+ * ws: m floats of workspace (per-gt best IoU).  m == 0 -> idx 0, label labels[0]. */
+int ptmi_iou_match(const float* gt, const float* boxes, int m, int64_t nb, const float* thresholds_host,
+                   const int* labels_host, int n_thr, int allow_low_quality, int64_t* matched_idx,
+                   int8_t* matched_label, float* matched_iou, float* ws, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ sort + proposals (N10)
+ * replaces torch.sort(descending) at pt/modeling/proposal_generator/proposal_utils.py:87 and the
+ * sort inside torchvision nms.  Stable: ties keep ascending original index.
+ * seg_offsets (nseg+1) int32 device array.  ws sized by ptmi_segsort_ws_bytes. */
+int64_t ptmi_segsort_ws_bytes(int64_t total, int nseg);
+int ptmi_segsort_desc(const float* keys_in, float* keys_out, int32_t* idx_out, int64_t total,
+                      int nseg, const int32_t* seg_offsets, void* ws, int64_t ws_bytes,
+                      ptmi_stream_t s);
+/* proposal_utils.py:92-138 for one batch: for image i and rank j < k:
+ *   box = clip(decoded[i][sorted_idx[i][j]], image_size[i]); valid = finite & w>min & h>min;
+ *   score = sorted_logit[i][j] * (1 - mean4(sigmoid(sigma_logits[i][j])))   <- row j, NOT idx (:94)
+ * Outputs dense (n,k,*) plus valid (uint8) and nonfinite flag per image. */
+int ptmi_rpn_prepare(const float* decoded, const float* sorted_logits, const int32_t* sorted_idx,
+                     const float* sigma_logits, const float* image_sizes_hw, float* boxes_out,
+                     float* scores_out, uint8_t* valid_out, int32_t* nonfinite_out, int n,
+                     int64_t r, int k, float min_size, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ NMS (N11)
+ * replaces torchvision nms (detectron2 batched_nms) at proposal_utils.py:140, fast_rcnn.py:104.
+ * Batched over `nimg` images: boxes (sum counts,4) ALREADY sorted by descending score per image,
+ * seg_offsets (nimg+1) int32.  keep_out (nimg, max_keep) int32 = positions within the image's
+ * sorted list, keep_count (nimg) int32.  Suppress iff IoU > thr (strict), IoU evaluated as
+ * inter/(area_i+area_j-inter) in fp32 without FMA contraction => bit-exact vs the CPU oracle.
+ * ws: ptmi_nms_ws_bytes(max_count, nimg). */
+int64_t ptmi_nms_ws_bytes(int64_t max_count, int nimg);
+int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, int nimg, int64_t max_count,
+                     float thr, int max_keep, int32_t* keep_out, int32_t* keep_count, void* ws,
+                     ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ losses (N7, N8, N14)
+ * Every loss kernel writes the scalar loss (already normalised) to loss_out[0] and the gradient
+ * w.r.t. its differentiable inputs (already multiplied by 1/normaliser) in the same launch;
+ * reductions are block-tree + fixed-order final sum (deterministic).  ws: 4096 floats. */
+/* rpn.py:242-246: sum BCE-with-logits over label>=0, / norm.  labels int8 (-1,0,1). */
+int ptmi_bce_logits_sum(const float* logits, const int8_t* labels, int64_t n, float inv_norm,
+                        float* loss_out, float* dlogits, float* ws, ptmi_stream_t s);
+/* box_regression.py:165-176 / fast_rcnn.py:286-296: sum over rows of -log(pdf(mu;t,var)+1e-9),
+ * var = sigmoid(slog); d (rows,8) = [mu(4), slog(4)] gathered rows; t (rows,4) targets.
+ * Gradients: dd (rows,8); dt (rows,4) optional (NULL to skip; needed for d(loss)/d(anchors)). */
+int ptmi_gaussian_nll_sum(const float* d, const float* t, int64_t rows, float inv_norm,
+                          float* loss_out, float* dd, float* dt, float* ws, ptmi_stream_t s);
+/* fast_rcnn.py:408 + D2 FastRCNNOutputLayers.losses: mean cross entropy; dlogits (r,c). */
+int ptmi_softmax_ce_mean(const float* logits, const int64_t* target, int64_t r, int c,
+                         float* loss_out, float* dlogits, float* ws, ptmi_stream_t s);
+/* softmax over the last dim (fast_rcnn.py:408 predict_probs). */
+int ptmi_softmax_rows(const float* logits, float* probs, int64_t r, int c, ptmi_stream_t s);
+/* fast_rcnn.py:179-213 cls_loss_unsupervised: teacher logits T (r,c), student logits S (r,c):
+ * sum_r w_r * softmax(T/tau)·(-log_softmax(S)) * inv_norm, w_r=(1-H(softmax T)/log c)^lambda
+ * (w_r = 1 if !efl).  dS (r,c). */
+int ptmi_soft_ce_efl(const float* t, const float* s_logits, int64_t r, int c, float tau,
+                     float lambda, int efl, float inv_norm, float* loss_out, float* ds, float* ws,
+                     ptmi_stream_t s);
+/* rpn.py:285-304 RPN soft objectness loss (incl. the sigmoid(1-x) quirk at :299).
+ * T (k,c) teacher logits of the matched pseudo box per positive anchor, x (k) student objectness.
+ * Also emits fg[k] (uint8) = argmax T != c-1 (rpn.py:292-293). */
+int ptmi_rpn_soft_obj_loss(const float* t, const float* x, int64_t k, int c, float tau, float lambda,
+                           int efl, float inv_norm, float* loss_out, float* dx, uint8_t* fg,
+                           float* ws, ptmi_stream_t s);
+/* rpn.py:321-355 / fast_rcnn.py:215-263: KL(N(mu_p,var_p*tau) || N(mu_q,var_q)) with the
+ * per-coordinate entropy-focal weight; rows selected by fg (NULL = all rows).
+ * q (rows,8)=[mu_q, slog_q]; mu_p (rows,4); slog_p (rows,4) teacher sigma logits.
+ * reduction: 0 = sum*inv_norm (RPN), 1 = mean over selected rows*4 (ROI, inv_norm ignored).
+ * Gradients dq (rows,8), dmu_p (rows,4; NULL when mu_p is detached as in fast_rcnn.py:235). */
+int ptmi_kl_efl_loss(const float* q, const float* mu_p, const float* slog_p, const uint8_t* fg,
+                     int64_t rows, float tau, float lambda, int efl, int reduction, float inv_norm,
+                     float* loss_out, float* dq, float* dmu_p, float* ws, ptmi_stream_t s);
+/* backward of get_deltas w.r.t. the SOURCE boxes (anchors), accumulated into danchors (na,4):
+ * rows index anchors via anchor_index[i] (int64).  Used only for the differentiable anchors
+ * (rpn.py:311 with danchor=True, anchor_generator.py:147). */
+int ptmi_get_deltas_bwd_src(const float* src, const float* tgt, const float* ddeltas,
+                            const int64_t* src_index, int64_t rows, float wx, float wy, float ww,
+                            float wh, float* dsrc, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ optimiser / EMA (N15-N17)
+ * flat fp32 buffers.  EMA: trainer.py:431-449  t = s*(1-k) + t*k  (that evaluation order). */
+int ptmi_ema_update(const float* student, float* teacher, int64_t n, float keep_rate,
+                    ptmi_stream_t s);
+/* trainer.py:592-603 clip_gradient: sumsq_out[0] = sum g^2 (two-stage, deterministic). */
+int ptmi_sumsq(const float* g, int64_t n, float* sumsq_out, float* ws, ptmi_stream_t s);
+/* fused clip + SGD(momentum, weight decay) step (trainer.py:385-386; torch.optim.SGD semantics):
+ * s = clip/max(sqrt(sumsq[0]),clip); g' = g*s + wd*p; buf = first ? g' : mu*buf+g'; p -= lr*buf. */
+int ptmi_clip_sgd_step(float* p, const float* g, float* buf, int64_t n, const float* sumsq,
+                       float clip_norm, float lr, float momentum, float weight_decay, int first,
+                       ptmi_stream_t s);
+int ptmi_scale_by_clip(float* g, int64_t n, const float* sumsq, float clip_norm, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ image prep (N18)
+ * rcnn.py:40 -> D2 preprocess_image: out[i] (3,hmax,wmax) = (u8 - mean)/std, zero padded.
+ * One launch per image (images have individual sizes). */
+int ptmi_preprocess_image(const uint8_t* img, float* out, int h, int w, int hmax, int wmax,
+                          float m0, float m1, float m2, float s0, float s1, float s2,
+                          ptmi_stream_t s);
+/* trainer.py:557-590 resize: bilinear (align_corners=False) shrink to (dh,dw), truncated to u8,
+ * pasted at (y1,x1) on a canvas filled with int(pixel_mean). */
+int ptmi_shrink_paste(const uint8_t* img, uint8_t* out, int h, int w, int dh, int dw, int y1,
+                      int x1, int m0, int m1, int m2, ptmi_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI355_H */

@@ -1,0 +1,361 @@
+// boxes.hip -- anchor grid, box codec, IoU matcher and RPN proposal preparation for gfx950.
+// Compiled with -ffp-contract=off: the integer outputs (match indices, labels, valid masks) must be
+// bit-exact against the CPU oracle, so the fp32 expression trees below mirror the reference's
+// (pt/modeling/box_regression.py, D2 pairwise_iou / Matcher -- SURVEY.md A.2/A.3) op for op.
+#include "common.h"
+
+namespace {
+
+__global__ void grid_anchors_kernel(const float* __restrict__ cell, float* __restrict__ out, int h, int w, int A,
+                                    float stride, float offset)
+{
+    const int64_t total = (int64_t)h * w * A;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int a = i % A;
+        const int64_t p = i / A;
+        const int x = p % w, y = p / w;
+        // torch.arange(offset*stride, W*stride, step=stride): start + k*step
+        const float sx = offset * stride + (float)x * stride;
+        const float sy = offset * stride + (float)y * stride;
+        const float4 c = reinterpret_cast<const float4*>(cell)[a];
+        reinterpret_cast<float4*>(out)[i] = make_float4(sx + c.x, sy + c.y, sx + c.z, sy + c.w);
+    }
+}
+
+// box_regression.py:101-139.  One thread per (row, k) decoded box.
+__global__ void apply_deltas_kernel(const float* __restrict__ deltas, const float* __restrict__ boxes,
+                                    float* __restrict__ out, int64_t rows, int k, int dstride, int64_t nb,
+                                    float wx, float wy, float ww, float wh, float clampv)
+{
+    const int64_t total = rows * k;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / k;
+        const int j = i % k;
+        const float4 b = reinterpret_cast<const float4*>(boxes)[row % nb];
+        const float* d = deltas + row * dstride + 4 * j;
+        const float widths = b.z - b.x, heights = b.w - b.y;
+        const float cx = b.x + 0.5f * widths, cy = b.y + 0.5f * heights;
+        const float dx = d[0] / wx, dy = d[1] / wy;
+        float dw = d[2] / ww, dh = d[3] / wh;
+        dw = fminf(dw, clampv);
+        dh = fminf(dh, clampv);
+        const float pcx = dx * widths + cx, pcy = dy * heights + cy;
+        const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+        float* o = out + row * (int64_t)(4 * k) + 4 * j;
+        o[0] = pcx - 0.5f * pw;
+        o[1] = pcy - 0.5f * ph;
+        o[2] = pcx + 0.5f * pw;
+        o[3] = pcy + 0.5f * ph;
+    }
+}
+
+// box_regression.py:66-99
+__device__ __forceinline__ void get_deltas_row(const float4 s, const float4 t, float wx, float wy, float ww,
+                                               float wh, float* o)
+{
+    const float sw = s.z - s.x, sh = s.w - s.y;
+    const float sx = s.x + 0.5f * sw, sy = s.y + 0.5f * sh;
+    const float tw = t.z - t.x, th = t.w - t.y;
+    const float tx = t.x + 0.5f * tw, ty = t.y + 0.5f * th;
+    o[0] = wx * (tx - sx) / sw;
+    o[1] = wy * (ty - sy) / sh;
+    o[2] = ww * logf(tw / sw + 1e-9f);
+    o[3] = wh * logf(th / sh + 1e-9f);
+}
+
+__global__ void get_deltas_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                  float* __restrict__ out, int64_t rows, float wx, float wy, float ww, float wh)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float o[4];
+        get_deltas_row(reinterpret_cast<const float4*>(src)[i], reinterpret_cast<const float4*>(tgt)[i], wx, wy,
+                       ww, wh, o);
+        reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// d(loss)/d(src box) of get_deltas, scattered (atomic) into dsrc[src_index[i]].
+__global__ void get_deltas_bwd_src_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                          const float* __restrict__ dd, const int64_t* __restrict__ sidx,
+                                          int64_t rows, float wx, float wy, float ww, float wh,
+                                          float* __restrict__ dsrc)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 s = reinterpret_cast<const float4*>(src)[i];
+        const float4 t = reinterpret_cast<const float4*>(tgt)[i];
+        const float4 g = reinterpret_cast<const float4*>(dd)[i];
+        const float sw = s.z - s.x, sh = s.w - s.y;
+        const float sx = s.x + 0.5f * sw, sy = s.y + 0.5f * sh;
+        const float tw = t.z - t.x, th = t.w - t.y;
+        const float tx = t.x + 0.5f * tw, ty = t.y + 0.5f * th;
+        // dx = wx*(tx-sx)/sw ; dw = ww*log(tw/sw + 1e-9)
+        const float ddx_dsx = -wx / sw, ddx_dsw = -wx * (tx - sx) / (sw * sw);
+        const float ddw_dsw = ww * (-tw / (sw * sw)) / (tw / sw + 1e-9f);
+        const float ddy_dsy = -wy / sh, ddy_dsh = -wy * (ty - sy) / (sh * sh);
+        const float ddh_dsh = wh * (-th / (sh * sh)) / (th / sh + 1e-9f);
+        const float g_sx = g.x * ddx_dsx, g_sw = g.x * ddx_dsw + g.z * ddw_dsw;
+        const float g_sy = g.y * ddy_dsy, g_sh = g.y * ddy_dsh + g.w * ddh_dsh;
+        // sx = x1 + 0.5*(x2-x1), sw = x2 - x1
+        float* o = dsrc + 4 * sidx[i];
+        atomicAdd(o + 0, 0.5f * g_sx - g_sw);
+        atomicAdd(o + 2, 0.5f * g_sx + g_sw);
+        atomicAdd(o + 1, 0.5f * g_sy - g_sh);
+        atomicAdd(o + 3, 0.5f * g_sy + g_sh);
+    }
+}
+
+// ---------------------------------------------------------------------------------- IoU + Matcher
+__device__ __forceinline__ float iou_pair(const float4 g, float garea, const float4 b, float barea)
+{
+    // D2 pairwise_iou: wh = min(rb) - max(lt), clamp(min=0), inter = w*h,
+    // iou = inter > 0 ? inter / (area1 + area2 - inter) : 0
+    float w = fminf(g.z, b.z) - fmaxf(g.x, b.x);
+    float h = fminf(g.w, b.w) - fmaxf(g.y, b.y);
+    w = w < 0.f ? 0.f : w;
+    h = h < 0.f ? 0.f : h;
+    const float inter = w * h;
+    return inter > 0.f ? inter / (garea + barea - inter) : 0.f;
+}
+
+constexpr int MAX_GT_LDS = 2048;
+
+__global__ __launch_bounds__(256) void iou_match_pass1(const float* __restrict__ gt, const float* __restrict__ boxes,
+                                                       int m, int64_t nb, int64_t* __restrict__ midx,
+                                                       float* __restrict__ miou, int* __restrict__ best_bits)
+{
+    __shared__ float4 sg[MAX_GT_LDS / 8];
+    __shared__ float sa[MAX_GT_LDS / 8];
+    const int64_t j = blockIdx.x * 256ll + threadIdx.x;
+    float4 b = make_float4(0, 0, 0, 0);
+    float barea = 0.f;
+    if (j < nb) {
+        b = reinterpret_cast<const float4*>(boxes)[j];
+        barea = (b.z - b.x) * (b.w - b.y);
+    }
+    float best = -1.f;
+    int64_t bi = 0;
+    for (int g0 = 0; g0 < m; g0 += 256) {
+        __syncthreads();
+        const int gi = g0 + threadIdx.x;
+        if (gi < m) {
+            const float4 g = reinterpret_cast<const float4*>(gt)[gi];
+            sg[threadIdx.x] = g;
+            sa[threadIdx.x] = (g.z - g.x) * (g.w - g.y);
+        }
+        __syncthreads();
+        const int cnt = min(256, m - g0);
+        for (int i = 0; i < cnt; ++i) {
+            const float v = iou_pair(sg[i], sa[i], b, barea);
+            if (v > best) { best = v; bi = g0 + i; }      // first maximum (torch.max dim=0)
+            // per-gt best over all boxes: IoU >= 0 so the int bit pattern is order preserving; lanes past
+            // nb hold a zero box (IoU 0), so the unconditional wave reduction is safe.  One atomic per
+            // wave per gt.
+            float wmax = v;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+            if ((threadIdx.x & 63) == 0) atomicMax(best_bits + g0 + i, __float_as_int(wmax));
+        }
+    }
+    if (j < nb) {
+        midx[j] = bi;
+        miou[j] = best;
+    }
+}
+
+__global__ __launch_bounds__(256) void iou_match_pass2(const float* __restrict__ gt, const float* __restrict__ boxes,
+                                                       int m, int64_t nb, const float* __restrict__ miou,
+                                                       const int* __restrict__ best_bits, float t0, float t1, int l0,
+                                                       int l1, int l2, int n_thr, int lowq,
+                                                       int8_t* __restrict__ mlabel)
+{
+    __shared__ float4 sg[256];
+    __shared__ float sa[256];
+    __shared__ float sb[256];
+    const int64_t j = blockIdx.x * 256ll + threadIdx.x;
+    float4 b = make_float4(0, 0, 0, 0);
+    float barea = 0.f, val = 0.f;
+    if (j < nb) {
+        b = reinterpret_cast<const float4*>(boxes)[j];
+        barea = (b.z - b.x) * (b.w - b.y);
+        val = miou[j];
+    }
+    // Matcher: labels over [-inf,t0), [t0,t1), [t1,inf)   (n_thr == 1: [-inf,t0), [t0,inf))
+    int lab;
+    if (n_thr == 2) lab = val < t0 ? l0 : (val < t1 ? l1 : l2);
+    else lab = val < t0 ? l0 : l1;
+    if (lowq) {
+        bool hit = false;
+        for (int g0 = 0; g0 < m; g0 += 256) {
+            __syncthreads();
+            const int gi = g0 + threadIdx.x;
+            if (gi < m) {
+                const float4 g = reinterpret_cast<const float4*>(gt)[gi];
+                sg[threadIdx.x] = g;
+                sa[threadIdx.x] = (g.z - g.x) * (g.w - g.y);
+                sb[threadIdx.x] = __int_as_float(best_bits[gi]);
+            }
+            __syncthreads();
+            const int cnt = min(256, m - g0);
+            for (int i = 0; i < cnt; ++i) hit |= (iou_pair(sg[i], sa[i], b, barea) == sb[i]);
+        }
+        if (hit) lab = 1;
+    }
+    if (j < nb) mlabel[j] = (int8_t)lab;
+}
+
+__global__ void fill_nomatch_kernel(int64_t* __restrict__ midx, int8_t* __restrict__ mlabel, float* __restrict__ miou,
+                                    int64_t nb, int lab)
+{
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nb; i += (int64_t)gridDim.x * blockDim.x) {
+        midx[i] = 0;
+        mlabel[i] = (int8_t)lab;
+        if (miou) miou[i] = 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------- RPN prepare
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void rpn_prepare_kernel(const float* __restrict__ decoded, const float* __restrict__ slog,
+                                   const int32_t* __restrict__ sidx, const float* __restrict__ sigma,
+                                   const float* __restrict__ sizes, float* __restrict__ boxes_out,
+                                   float* __restrict__ scores_out, uint8_t* __restrict__ valid_out,
+                                   int32_t* __restrict__ nonfinite, int n, int64_t R, int k, float min_size)
+{
+    const int64_t total = (int64_t)n * k;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int img = i / k;
+        const int j = i % k;
+        const int32_t a = sidx[(int64_t)img * R + j];
+        const float4 b = reinterpret_cast<const float4*>(decoded)[(int64_t)img * R + a];
+        const float sc = slog[(int64_t)img * R + j];
+        const bool fin = isfinite(b.x) && isfinite(b.y) && isfinite(b.z) && isfinite(b.w) && isfinite(sc);
+        if (!fin) atomicOr(nonfinite + img, 1);
+        const float H = sizes[2 * img], W = sizes[2 * img + 1];
+        float4 c;
+        c.x = fminf(fmaxf(b.x, 0.f), W);
+        c.y = fminf(fmaxf(b.y, 0.f), H);
+        c.z = fminf(fmaxf(b.z, 0.f), W);
+        c.w = fminf(fmaxf(b.w, 0.f), H);
+        const bool ne = ((c.z - c.x) > min_size) && ((c.w - c.y) > min_size);
+        // proposal_utils.py:94: sigma rows are the first-k anchors in raster order (row j), not idx
+        const float4 s4 = reinterpret_cast<const float4*>(sigma)[(int64_t)img * R + j];
+        const float ssum = ((sigmoidf_(s4.x) + sigmoidf_(s4.y)) + sigmoidf_(s4.z)) + sigmoidf_(s4.w);
+        const float rescore = sc * (1.f - ssum / 4.0f);
+        reinterpret_cast<float4*>(boxes_out)[i] = c;
+        scores_out[i] = rescore;
+        valid_out[i] = (uint8_t)(fin && ne);
+    }
+}
+
+inline unsigned grid_for(int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_grid_anchors(const float* cell, float* out, int h, int w, int a, float stride, float offset,
+                      ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(cell && out && h > 0 && w > 0 && a > 0, "grid_anchors: bad args");
+    hipLaunchKernelGGL(grid_anchors_kernel, dim3(grid_for((int64_t)h * w * a)), dim3(256), 0, (hipStream_t)s, cell,
+                       out, h, w, a, stride, offset);
+    PTMI_LAUNCH_CHECK("grid_anchors");
+    return 0;
+}
+
+int ptmi_apply_deltas(const float* deltas, const float* boxes, float* out, int64_t rows, int k, int dstride,
+                      int64_t nb, float wx, float wy, float ww, float wh, float scale_clamp, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(deltas && boxes && out && rows >= 0 && k > 0 && nb > 0 && dstride >= 4 * k, "apply_deltas: bad args");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(apply_deltas_kernel, dim3(grid_for(rows * k)), dim3(256), 0, (hipStream_t)s, deltas, boxes, out,
+                       rows, k, dstride, nb, wx, wy, ww, wh, scale_clamp);
+    PTMI_LAUNCH_CHECK("apply_deltas");
+    return 0;
+}
+
+int ptmi_get_deltas(const float* src, const float* tgt, float* out, int64_t rows, float wx, float wy, float ww,
+                    float wh, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(src && tgt && out && rows >= 0, "get_deltas: bad args");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(get_deltas_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)s, src, tgt, out, rows, wx,
+                       wy, ww, wh);
+    PTMI_LAUNCH_CHECK("get_deltas");
+    return 0;
+}
+
+int ptmi_get_deltas_bwd_src(const float* src, const float* tgt, const float* ddeltas, const int64_t* src_index,
+                            int64_t rows, float wx, float wy, float ww, float wh, float* dsrc, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(src && tgt && ddeltas && src_index && dsrc && rows >= 0, "get_deltas_bwd_src: bad args");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(get_deltas_bwd_src_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)s, src, tgt,
+                       ddeltas, src_index, rows, wx, wy, ww, wh, dsrc);
+    PTMI_LAUNCH_CHECK("get_deltas_bwd_src");
+    return 0;
+}
+
+int ptmi_iou_match(const float* gt, const float* boxes, int m, int64_t nb, const float* thresholds_host,
+                   const int* labels_host, int n_thr, int allow_low_quality, int64_t* matched_idx,
+                   int8_t* matched_label, float* matched_iou, float* ws, ptmi_stream_t s)
+{
+    const float* thresholds = thresholds_host;
+    const int* labels = labels_host;
+    PTMI_CHECK_ARG(boxes && thresholds && labels && matched_idx && matched_label && matched_iou && nb >= 0 && m >= 0,
+                   "iou_match: bad args");
+    PTMI_CHECK_ARG(n_thr == 1 || n_thr == 2, "iou_match: n_thr must be 1 or 2");
+    if (nb == 0) return 0;
+    hipStream_t st = (hipStream_t)s;
+    if (m == 0) {   // Matcher on an empty (0,N) matrix: matches 0, labels = labels[0] (A.3)
+        hipLaunchKernelGGL(fill_nomatch_kernel, dim3(grid_for(nb)), dim3(256), 0, st, matched_idx, matched_label,
+                           matched_iou, nb, labels[0]);
+        PTMI_LAUNCH_CHECK("iou_match_fill");
+        return 0;
+    }
+    PTMI_CHECK_ARG(gt && ws, "iou_match: gt/ws missing");
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * (size_t)m, st);   // bits of +0.0f
+    if (e != hipSuccess) { ptmi_set_error("iou_match: memset failed"); return -2; }
+    const unsigned blocks = (unsigned)((nb + 255) / 256);
+    hipLaunchKernelGGL(iou_match_pass1, dim3(blocks), dim3(256), 0, st, gt, boxes, m, nb, matched_idx, matched_iou,
+                       reinterpret_cast<int*>(ws));
+    PTMI_LAUNCH_CHECK("iou_match_pass1");
+    const float t0 = thresholds[0], t1 = n_thr == 2 ? thresholds[1] : 0.f;
+    hipLaunchKernelGGL(iou_match_pass2, dim3(blocks), dim3(256), 0, st, gt, boxes, m, nb, matched_iou,
+                       reinterpret_cast<const int*>(ws), t0, t1, labels[0], labels[1], n_thr == 2 ? labels[2] : 0,
+                       n_thr, allow_low_quality, matched_label);
+    PTMI_LAUNCH_CHECK("iou_match_pass2");
+    return 0;
+}
+
+int ptmi_rpn_prepare(const float* decoded, const float* sorted_logits, const int32_t* sorted_idx,
+                     const float* sigma_logits, const float* image_sizes_hw, float* boxes_out, float* scores_out,
+                     uint8_t* valid_out, int32_t* nonfinite_out, int n, int64_t r, int k, float min_size,
+                     ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(decoded && sorted_logits && sorted_idx && sigma_logits && image_sizes_hw && boxes_out &&
+                       scores_out && valid_out && nonfinite_out && n > 0 && r > 0 && k > 0 && k <= r,
+                   "rpn_prepare: bad args");
+    hipStream_t st = (hipStream_t)s;
+    hipError_t e = hipMemsetAsync(nonfinite_out, 0, sizeof(int32_t) * (size_t)n, st);
+    if (e != hipSuccess) { ptmi_set_error("rpn_prepare: memset failed"); return -2; }
+    hipLaunchKernelGGL(rpn_prepare_kernel, dim3(grid_for((int64_t)n * k)), dim3(256), 0, st, decoded, sorted_logits,
+                       sorted_idx, sigma_logits, image_sizes_hw, boxes_out, scores_out, valid_out, nonfinite_out, n, r,
+                       k, min_size);
+    PTMI_LAUNCH_CHECK("rpn_prepare");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,484 @@
+// conv.hip -- 3x3 s1 p1 convolution stack for gfx950 (CDNA4), fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Replaces the cuDNN conv2d (+bias, +ReLU) the reference reaches at
+// pt/modeling/backbone/vgg.py:45-53,66-69 (13 VGG16 layers) and the 3x3 conv of D2's
+// StandardRPNHead (pt/modeling/proposal_generator/rpn.py:96), forward, dgrad and wgrad.
+//
+// Design (MI355X-first, not a cuDNN translation):
+//   * implicit GEMM  M = Cout, N = output pixels, K = 9*Cin, NCHW fp32 end to end;
+//   * one 256-thread workgroup = 4 wave64s, each wave owns a 64(co) x 64(px = 2 rows x 32 cols)
+//     accumulator block = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs);
+//   * K is walked in chunks of CK input channels: the (TH+2)x34 input halo patch of CK channels and
+//     the [9][CK][BM] weight slab go through LDS; fragment reads are plain ds_read_b32 with
+//     compile-time offsets -- lanes 0-31 walk 32 consecutive pixels (or 32 consecutive output
+//     channels) and lanes 32-63 the next input channel, which is exactly the f32 MFMA operand
+//     layout (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) => bank-conflict free, no swizzle needed;
+//   * global->register prefetch of chunk c+1 is issued before the 144 MFMAs of chunk c; with
+//     ~43 KB LDS and <=128 VGPRs three workgroups share a CU so one wave per SIMD is always
+//     inside its MFMA block (the f32 MFMA pipe is saturated by a single wave: 64-cycle issue).
+//   * dgrad reuses the same kernel with flipped/transposed packed weights; the producer's ReLU
+//     mask can be applied in the epilogue (epilogue 3).
+//   * wgrad: M = Cout, N = Cin (x 9 taps as 9 accumulator tiles), K = pixels; split-K over pixel
+//     tiles with a fixed-order second-stage reduction (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 32;   // output pixels per MFMA column block
+constexpr int PW = 34;   // staged patch width (TW + 2 halo)
+
+template <int BM>
+struct FwdCfg {
+    static constexpr int TH = (BM == 128) ? 4 : 8;   // output rows per workgroup
+    static constexpr int PR = TH + 2;
+    static constexpr int PLANE = PR * PW;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int BM, int CK>
+__global__ __launch_bounds__(256, 3) void conv3x3_mfma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
+    int tilesX, int tilesY, int coTiles, int nChunks, int epi)
+{
+    using C = FwdCfg<BM>;
+    constexpr int TH = C::TH, PLANE = C::PLANE;
+    constexpr int WS = 9 * CK * BM;          // weight slab floats
+    constexpr int PS = CK * PLANE;           // patch floats
+    constexpr int WS4 = WS / 4;
+    constexpr int NW4 = (WS4 + 255) / 256;
+    constexpr int NP = (PS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds[WS + PS];
+    float* Ws = lds;
+    float* Ps = lds + WS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int cot = bid % coTiles;
+    int pt = bid / coTiles;
+    const int tx = pt % tilesX;
+    pt /= tilesX;
+    const int ty = pt % tilesY;
+    const int n = pt / tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int HW = H * W;
+
+    // per-thread patch element offsets (relative to the chunk's first channel plane)
+    int poff[NP];
+    unsigned pvalid = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + i * 256;
+        poff[i] = 0;
+        if (idx < PS) {
+            const int ci = idx / PLANE, rem = idx - ci * PLANE;
+            const int r = rem / PW, c = rem - r * PW;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                poff[i] = ci * HW + gy * W + gx;
+                pvalid |= 1u << i;
+            }
+        }
+    }
+    const float* xn = x + (size_t)n * Cin * HW;
+    const float4* wbase = reinterpret_cast<const float4*>(wp) + (size_t)cot * nChunks * WS4;
+
+    float4 wreg[NW4];
+    float preg[NP];
+    auto gload = [&](int chunk) {
+        const float4* wsrc = wbase + (size_t)chunk * WS4;
+#pragma unroll
+        for (int i = 0; i < NW4; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < WS4) wreg[i] = wsrc[idx];
+        }
+        const int c0 = chunk * CK;
+        const float* xc = xn + (size_t)c0 * HW;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            float v = 0.f;
+            if (idx < PS && ((pvalid >> i) & 1u) && (c0 + idx / PLANE) < Cin) v = xc[poff[i]];
+            preg[i] = v;
+        }
+    };
+    auto lstore = [&]() {
+        float4* wd = reinterpret_cast<float4*>(Ws);
+#pragma unroll
+        for (int i = 0; i < NW4; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < WS4) wd[idx] = wreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < PS) Ps[idx] = preg[i];
+        }
+    };
+
+    const int wm = (BM == 128) ? (wave >> 1) : 0;
+    const int wn = (BM == 128) ? (wave & 1) : wave;
+    const float* wsl = Ws + wm * 64 + (lane & 31) + (lane >> 5) * BM;
+    const float* psl = Ps + (lane >> 5) * PLANE + (wn * 2) * PW + (lane & 31);
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // acc[s co-subtile][q pixel row]
+
+    gload(0);
+    for (int chunk = 0; chunk < nChunks; ++chunk) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (chunk + 1 < nChunks) gload(chunk + 1);
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* wk = wsl + ky * 3 * CK * BM;
+            const float* pk = psl + ky * PW;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int j = 0; j < CK / 2; ++j) {
+                    const float a0 = wk[(kx * CK + 2 * j) * BM];
+                    const float a1 = wk[(kx * CK + 2 * j) * BM + 32];
+                    const float b0 = pk[2 * j * PLANE + kx];
+                    const float b1 = pk[2 * j * PLANE + PW + kx];
+                    acc00 = mfma32(a0, b0, acc00);
+                    acc01 = mfma32(a0, b1, acc01);
+                    acc10 = mfma32(a1, b0, acc10);
+                    acc11 = mfma32(a1, b1, acc11);
+                }
+            }
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
+    const int px = x0 + (lane & 31);
+    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
+    const int yrow = y0 + wn * 2;
+    float* yn = y + (size_t)n * Cout * HW;
+    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
+            if (co >= Cout) continue;
+            const float b = (epi <= 1) ? bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int yy = yrow + q;
+                if (yy >= H || px >= W) continue;
+                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
+                const size_t o = (size_t)co * HW + (size_t)yy * W + px;
+                if (epi <= 1) {
+                    v += b;
+                    if (epi == 1) v = fmaxf(v, 0.f);
+                } else if (epi == 3) {
+                    v = (mn[o] > 0.f) ? v : 0.f;
+                }
+                yn[o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ weight pack
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int wCout,
+                                    int wCin, int mode, int BM, int CK, int coTiles, int nChunks)
+{
+    const int64_t total = (int64_t)coTiles * nChunks * 9 * CK * BM;
+    const int convCout = mode ? wCin : wCout, convCin = mode ? wCout : wCin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int col = t % BM; t /= BM;
+        const int cil = t % CK; t /= CK;
+        const int tap = t % 9; t /= 9;
+        const int chunk = t % nChunks;
+        const int cot = t / nChunks;
+        const int co = cot * BM + col, ci = chunk * CK + cil;
+        float v = 0.f;
+        if (co < convCout && ci < convCin) {
+            const int ky = tap / 3, kx = tap % 3;
+            if (mode == 0) v = w[((size_t)co * wCin + ci) * 9 + tap];
+            else v = w[((size_t)ci * wCin + co) * 9 + (2 - ky) * 3 + (2 - kx)];
+        }
+        wp[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------ wgrad
+// workgroup: 128 co x 32 ci x 9 taps; wave w owns co sub-tile w (32 co); K = pixels, 32 px / stage.
+constexpr int WG_PIX = 32;           // 1 row x 32 cols per stage
+constexpr int DY_PITCH = 33;
+constexpr int XP_PLANE = 3 * PW;     // 3 rows x 34 = 102
+constexpr int XP_PITCH = XP_PLANE + 1;   // 103 (odd)
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N,
+    int Cin, int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S)
+{
+    constexpr int DYS = 128 * DY_PITCH;
+    constexpr int XS = 32 * XP_PITCH;
+    constexpr int NDY = 128 * WG_PIX / 256;            // 16
+    constexpr int NX = (32 * XP_PLANE + 255) / 256;    // 13
+    __shared__ float lds[DYS + XS];
+    float* dYs = lds;
+    float* Xs = lds + DYS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int s = bid % S; bid /= S;
+    const int cit = bid % ciTiles;
+    const int cot = bid / ciTiles;
+    const int HW = H * W;
+    const int co0 = cot * 128, ci0 = cit * 32;
+    const int nTiles = N * tilesY * tilesX;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+
+    float dreg[NDY];
+    float xreg[NX];
+    auto gload = [&](int tile) {
+        const int tx = tile % tilesX;
+        int t2 = tile / tilesX;
+        const int ty = t2 % tilesY;
+        const int n = t2 / tilesY;
+        const int x0 = tx * TW, y0 = ty;
+        const float* dyn = dy + (size_t)n * Cout * HW;
+        const float* xn = x + (size_t)n * Cin * HW;
+        const int col = tid & 31;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) {
+            const int co = co0 + (tid >> 5) + 8 * i;
+            const int gx = x0 + col;
+            float v = 0.f;
+            if (co < Cout && gx < W) v = dyn[(size_t)co * HW + y0 * W + gx];
+            dreg[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            float v = 0.f;
+            if (idx < 32 * XP_PLANE) {
+                const int ci = idx / XP_PLANE, rem = idx - ci * XP_PLANE;
+                const int r = rem / PW, c = rem - r * PW;
+                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+                if (ci0 + ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
+                    v = xn[(size_t)(ci0 + ci) * HW + gy * W + gx];
+            }
+            xreg[i] = v;
+        }
+    };
+    auto lstore = [&]() {
+        const int col = tid & 31;
+#pragma unroll
+        for (int i = 0; i < NDY; ++i) dYs[((tid >> 5) + 8 * i) * DY_PITCH + col] = dreg[i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < 32 * XP_PLANE) {
+                const int ci = idx / XP_PLANE, rem = idx - ci * XP_PLANE;
+                Xs[ci * XP_PITCH + rem] = xreg[i];
+            }
+        }
+    };
+
+    const float* al = dYs + (wave * 32 + (lane & 31)) * DY_PITCH + (lane >> 5);
+    const float* bl = Xs + (lane & 31) * XP_PITCH + (lane >> 5);
+
+    int tile = s;
+    if (tile < nTiles) gload(tile);
+    for (; tile < nTiles; tile += S) {
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (tile + S < nTiles) gload(tile + S);
+#pragma unroll 2
+        for (int kk = 0; kk < 16; ++kk) {
+            const float a = al[2 * kk];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const float b = bl[ky * PW + 2 * kk + kx];
+                acc[tap] = mfma32(a, b, acc[tap]);
+            }
+        }
+    }
+    // partial[s][tap][co][ci]
+    const int ci = ci0 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* dst = partial + ((size_t)s * 9 + tap) * Cout * Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[tap][r];
+        }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
+                                    int Cin, int S, int accumulate)
+{
+    const int64_t total = (int64_t)Cout * Cin * 9;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes partial layout [tap][co][ci] for coalesced reads
+        const int64_t cc = (int64_t)Cout * Cin;
+        const int tap = i / cc;
+        const int64_t rem = i - tap * cc;
+        float sum = 0.f;
+        for (int s = 0; s < S; ++s) sum += partial[((size_t)s * 9 + tap) * cc + rem];
+        const size_t o = (size_t)rem * 9 + tap;
+        dw[o] = accumulate ? dw[o] + sum : sum;
+    }
+}
+
+// db[co] = sum_{n,p} dy[n][co][p]   (one workgroup per channel, fixed order)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+                                                        int N, int C, int HW, int accumulate)
+{
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = dy + ((size_t)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+    }
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + t : t;
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                float* __restrict__ dz, int64_t n)
+{
+    const int64_t n4 = n >> 2;
+    const float4* dy4 = reinterpret_cast<const float4*>(dy);
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    float4* dz4 = reinterpret_cast<float4*>(dz);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 g = dy4[i];
+        const float4 v = y4[i];
+        g.x = v.x > 0.f ? g.x : 0.f;
+        g.y = v.y > 0.f ? g.y : 0.f;
+        g.z = v.z > 0.f ? g.z : 0.f;
+        g.w = v.w > 0.f ? g.w : 0.f;
+        dz4[i] = g;
+    }
+    for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dz[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+int wgrad_splits(int n, int cin, int cout, int h, int w)
+{
+    const int tilesX = cdiv(w, TW), tilesY = h;
+    const int64_t nTiles = (int64_t)n * tilesX * tilesY;
+    const int base = cdiv(cout, 128) * cdiv(cin, 32);
+    int S = cdiv(1024, base);
+    if (S > nTiles) S = (int)nTiles;
+    if (S < 1) S = 1;
+    if (S > 256) S = 256;
+    return S;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_conv3x3_bm(int cout) { return cout <= 64 ? 64 : 128; }
+int ptmi_conv3x3_ck(int cin) { return cin <= 4 ? 4 : 8; }
+
+int64_t ptmi_conv3x3_packed_floats(int cin, int cout)
+{
+    const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
+    return (int64_t)cdiv(cout, BM) * cdiv(cin, CK) * 9 * CK * BM;
+}
+
+int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode,
+                              ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(w && wp && w_cout > 0 && w_cin > 0, "conv3x3_pack_weights: bad args");
+    const int convCout = mode ? w_cin : w_cout, convCin = mode ? w_cout : w_cin;
+    const int BM = ptmi_conv3x3_bm(convCout), CK = ptmi_conv3x3_ck(convCin);
+    const int coTiles = cdiv(convCout, BM), nChunks = cdiv(convCin, CK);
+    const int64_t total = (int64_t)coTiles * nChunks * 9 * CK * BM;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, wp, w_cout,
+                       w_cin, mode, BM, CK, coTiles, nChunks);
+    PTMI_LAUNCH_CHECK("conv3x3_pack_weights");
+    return 0;
+}
+
+int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                     float* y, int n, int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
+    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "conv3x3_fwd: bad epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
+    const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
+    const int TH = BM == 128 ? 4 : 8;
+    const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
+    const int64_t blocks = (int64_t)n * tilesX * tilesY * coTiles;
+    PTMI_CHECK_ARG(blocks < (1ll << 31), "conv3x3_fwd: grid too large");
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = (hipStream_t)s;
+#define LAUNCH(BM_, CK_)                                                                              \
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<BM_, CK_>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, \
+                       cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
+    if (BM == 128 && CK == 8) LAUNCH(128, 8);
+    else if (BM == 64 && CK == 8) LAUNCH(64, 8);
+    else if (BM == 128 && CK == 4) LAUNCH(128, 4);
+    else LAUNCH(64, 4);
+#undef LAUNCH
+    PTMI_LAUNCH_CHECK("conv3x3_fwd");
+    return 0;
+}
+
+int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
+{
+    return (int64_t)wgrad_splits(n, cin, cout, h, w) * 9 * cout * cin;
+}
+
+int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
+                       int cout, int h, int w, int accumulate, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0, "conv3x3_wgrad: bad args");
+    const int tilesX = cdiv(w, TW), tilesY = h;
+    const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
+    const int S = wgrad_splits(n, cin, cout, h, w);
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
+                       cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);
+    PTMI_LAUNCH_CHECK("conv3x3_wgrad");
+    const int64_t total = (int64_t)cout * cin * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw,
+                       cout, cin, S, accumulate);
+    PTMI_LAUNCH_CHECK("conv3x3_wgrad_reduce");
+    if (db) {
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(cout), dim3(256), 0, st, dy, db, n, cout, h * w, accumulate);
+        PTMI_LAUNCH_CHECK("conv3x3_bias_grad");
+    }
+    return 0;
+}
+
+int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(dy && y && dz && numel >= 0, "relu_bwd: bad args");
+    if (numel == 0) return 0;
+    int64_t blocks = (numel / 4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, dy, y, dz, numel);
+    PTMI_LAUNCH_CHECK("relu_bwd");
+    return 0;
+}
+
+}  // extern "C"

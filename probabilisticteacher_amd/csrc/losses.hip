@@ -1,0 +1,414 @@
+// losses.hip -- fused loss + gradient kernels of the Probabilistic-Teacher step (gfx950).
+//
+// Each kernel evaluates one loss term of the reference AND its gradient w.r.t. the network outputs in a
+// single pass (the autograd wrapper only scales by the upstream scalar).  Per-workgroup partial sums
+// use wave64 shuffles + LDS, and a single-workgroup finaliser adds the partials in a fixed order, so
+// the scalar losses are bitwise reproducible run to run.
+//
+//   bce_logits_sum      pt/modeling/proposal_generator/rpn.py:242-246
+//   gaussian_nll_sum    pt/modeling/box_regression.py:33-35,165-176; pt/modeling/roi_heads/fast_rcnn.py:286-296
+//   softmax_ce_mean     D2 FastRCNNOutputLayers.losses, fast_rcnn.py:408 (softmax)
+//   soft_ce_efl         fast_rcnn.py:179-213
+//   rpn_soft_obj_loss   rpn.py:285-304  (keeps the sigmoid(1-x) quirk of :299)
+//   kl_efl_loss         rpn.py:321-355, fast_rcnn.py:215-263
+#include "common.h"
+
+namespace {
+
+constexpr int MAXB = 1024;        // partial slots
+constexpr int WS_SUM = 0, WS_CNT = 1024, WS_SCALE = 2048;
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float E_F = 2.71828182845904523536f;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+inline int blocks_for(int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    if (b > MAXB) b = MAXB;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(const float* __restrict__ ws, int nb, float scale, int mean_mode,
+                                                       float* __restrict__ loss_out, float* __restrict__ ws_scale)
+{
+    __shared__ float sm[4];
+    float a = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        a += ws[WS_SUM + i];
+        if (mean_mode) c += ws[WS_CNT + i];
+    }
+    const float ta = block_sum_256(a, sm);
+    const float tc = block_sum_256(c, sm);
+    if (threadIdx.x == 0) {
+        if (mean_mode) {
+            // mean over (selected rows x 4); 0/0 -> NaN exactly like torch's mean of an empty tensor
+            const float denom = tc * 4.0f;
+            loss_out[0] = ta / denom;
+            ws_scale[0] = 1.0f / denom;
+        } else {
+            loss_out[0] = ta * scale;
+        }
+    }
+}
+
+__global__ void scale_rows_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ sc)
+{
+    const float s = sc[0];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        g[i] *= s;
+}
+
+// ------------------------------------------------------------------------------------------ BCE
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ x, const int8_t* __restrict__ lab,
+                                                  int64_t n, float inv_norm, float* __restrict__ dx,
+                                                  float* __restrict__ ws)
+{
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int l = lab[i];
+        float g = 0.f;
+        if (l >= 0) {
+            const float v = x[i], t = (float)l;
+            // ATen binary_cross_entropy_with_logits: (1-t)*x + max(-x,0) + log(exp(-max) + exp(-x-max))
+            const float mx = fmaxf(-v, 0.f);
+            acc += (1.f - t) * v + mx + logf(expf(-mx) + expf(-v - mx));
+            g = (sigmoidf_(v) - t) * inv_norm;
+        }
+        dx[i] = g;
+    }
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) ws[WS_SUM + blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------ Gaussian NLL
+__global__ __launch_bounds__(256) void gnll_kernel(const float* __restrict__ d, const float* __restrict__ tg,
+                                                   int64_t rows, float inv_norm, float* __restrict__ dd,
+                                                   float* __restrict__ dt, float* __restrict__ ws)
+{
+    __shared__ float sm[4];
+    float acc = 0.f;
+    const int64_t total = rows * 4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i >> 2;
+        const int c = (int)(i & 3);
+        const float mu = d[r * 8 + c], sl = d[r * 8 + 4 + c], t = tg[i];
+        const float var = sigmoidf_(sl);
+        const float diff = mu - t;
+        const float e = diff * diff;
+        const float A = expf(-e / (var + 1e-9f) / 2.0f);
+        const float B = sqrtf(2.0f * PI_F * (var + 0.3f));
+        const float pdf = A / B;
+        acc += -logf(pdf + 1e-9f);
+        const float dL_dpdf = -1.f / (pdf + 1e-9f);
+        const float dpdf_dmu = pdf * (-diff / (var + 1e-9f));
+        const float dpdf_dvar = pdf * (e / (2.f * (var + 1e-9f) * (var + 1e-9f)) - 1.f / (2.f * (var + 0.3f)));
+        const float gmu = dL_dpdf * dpdf_dmu * inv_norm;
+        dd[r * 8 + c] = gmu;
+        dd[r * 8 + 4 + c] = dL_dpdf * dpdf_dvar * var * (1.f - var) * inv_norm;
+        if (dt) dt[i] = -gmu;
+    }
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) ws[WS_SUM + blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------ softmax CE (mean)
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                                         int64_t R, int C, float inv_r, float* __restrict__ dx,
+                                                         float* __restrict__ ws)
+{
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t r = blockIdx.x * 256ll + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+        const float* p = x + r * C;
+        float m = p[0];
+        for (int j = 1; j < C; ++j) m = fmaxf(m, p[j]);
+        float s = 0.f;
+        for (int j = 0; j < C; ++j) s += expf(p[j] - m);
+        const float ls = logf(s);
+        const int t = (int)tgt[r];
+        acc += -(p[t] - m - ls);
+        for (int j = 0; j < C; ++j) {
+            const float sj = expf(p[j] - m - ls);
+            dx[r * C + j] = (sj - (j == t ? 1.f : 0.f)) * inv_r;
+        }
+    }
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) ws[WS_SUM + blockIdx.x] = t;
+}
+
+__global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t R, int C)
+{
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const float* p = x + r * C;
+        float m = p[0];
+        for (int j = 1; j < C; ++j) m = fmaxf(m, p[j]);
+        float s = 0.f;
+        for (int j = 0; j < C; ++j) s += expf(p[j] - m);
+        for (int j = 0; j < C; ++j) y[r * C + j] = expf(p[j] - m) / s;
+    }
+}
+
+// entropy-focal weight of one teacher row: (1 - H(softmax T)/log C)^lambda   (0*log0 -> NaN kept)
+__device__ __forceinline__ float efl_weight(const float* __restrict__ T, int C, float lambda)
+{
+    float m = T[0];
+    for (int j = 1; j < C; ++j) m = fmaxf(m, T[j]);
+    float s = 0.f;
+    for (int j = 0; j < C; ++j) s += expf(T[j] - m);
+    float H = 0.f;
+    for (int j = 0; j < C; ++j) {
+        const float p = expf(T[j] - m) / s;
+        H += p * logf(p);
+    }
+    H = -H;
+    return powf(1.f - H / logf((float)C), lambda);
+}
+
+// ------------------------------------------------------------------------------------------ soft CE + EFL (ROI)
+__global__ __launch_bounds__(256) void soft_ce_efl_kernel(const float* __restrict__ T, const float* __restrict__ S,
+                                                          int64_t R, int C, float tau, float lambda, int efl,
+                                                          float inv_norm, float* __restrict__ dS,
+                                                          float* __restrict__ ws)
+{
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t r = blockIdx.x * 256ll + threadIdx.x; r < R; r += (int64_t)gridDim.x * 256) {
+        const float* t = T + r * C;
+        const float* s = S + r * C;
+        const float w = efl ? efl_weight(t, C, lambda) : 1.f;
+        // q = softmax(t / tau)
+        float mq = t[0] / tau;
+        for (int j = 1; j < C; ++j) mq = fmaxf(mq, t[j] / tau);
+        float sq = 0.f;
+        for (int j = 0; j < C; ++j) sq += expf(t[j] / tau - mq);
+        // log_softmax(s)
+        float ms = s[0];
+        for (int j = 1; j < C; ++j) ms = fmaxf(ms, s[j]);
+        float ss = 0.f;
+        for (int j = 0; j < C; ++j) ss += expf(s[j] - ms);
+        const float ls = logf(ss);
+        float l = 0.f;
+        for (int j = 0; j < C; ++j) {
+            const float q = expf(t[j] / tau - mq) / sq * w;     // soft_label * weight (fast_rcnn.py:204-206)
+            const float lsm = s[j] - ms - ls;
+            l += q * (-lsm);
+        }
+        acc += l;
+        // d/ds_j of sum_i qw_i * (-log_softmax(s)_i) = softmax(s)_j * sum_i qw_i - qw_j ; sum_i q_i = 1
+        for (int j = 0; j < C; ++j) {
+            const float q = expf(t[j] / tau - mq) / sq;
+            const float pj = expf(s[j] - ms - ls);
+            dS[r * C + j] = w * (pj - q) * inv_norm;
+        }
+    }
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) ws[WS_SUM + blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------ RPN soft objectness
+__global__ __launch_bounds__(256) void rpn_soft_obj_kernel(const float* __restrict__ T, const float* __restrict__ x,
+                                                           int64_t K, int C, float tau, float lambda, int efl,
+                                                           float inv_norm, float* __restrict__ dx,
+                                                           uint8_t* __restrict__ fg, float* __restrict__ ws)
+{
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t r = blockIdx.x * 256ll + threadIdx.x; r < K; r += (int64_t)gridDim.x * 256) {
+        const float* t = T + r * C;
+        const float w = efl ? efl_weight(t, C, lambda) : 1.f;
+        int am = 0;
+        float mv = t[0];
+        for (int j = 1; j < C; ++j)
+            if (t[j] > mv) { mv = t[j]; am = j; }
+        fg[r] = (uint8_t)(am != C - 1);
+        float mq = t[0] / tau;
+        for (int j = 1; j < C; ++j) mq = fmaxf(mq, t[j] / tau);
+        float sq = 0.f;
+        for (int j = 0; j < C; ++j) sq += expf(t[j] / tau - mq);
+        float qfg = 0.f;
+        for (int j = 0; j < C - 1; ++j) qfg += expf(t[j] / tau - mq) / sq;
+        const float qbg = expf(t[C - 1] / tau - mq) / sq;
+        const float v = x[r];
+        const float sb = sigmoidf_(1.f - v), sf = sigmoidf_(v);      // rpn.py:299 (sic)
+        const float nlb = -logf(sb + 1e-9f), nlf = -logf(sf + 1e-9f);
+        acc += (qbg * w) * nlb + (qfg * w) * nlf;
+        const float dnlb = sb * (1.f - sb) / (sb + 1e-9f);            // d(-log(sig(1-x)+eps))/dx
+        const float dnlf = -sf * (1.f - sf) / (sf + 1e-9f);
+        dx[r] = w * (qbg * dnlb + qfg * dnlf) * inv_norm;
+    }
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) ws[WS_SUM + blockIdx.x] = t;
+}
+
+// ------------------------------------------------------------------------------------------ KL + EFL
+__global__ __launch_bounds__(256) void kl_efl_kernel(const float* __restrict__ q, const float* __restrict__ mup,
+                                                     const float* __restrict__ slp, const uint8_t* __restrict__ fg,
+                                                     int64_t rows, float tau, float lambda, int efl, float gscale,
+                                                     float* __restrict__ dq, float* __restrict__ dmup,
+                                                     float* __restrict__ ws)
+{
+    __shared__ float sm[4];
+    float acc = 0.f, cnt = 0.f;
+    const int64_t total = rows * 4;
+    const float max_ent = 0.5f * logf(2.f * PI_F * E_F);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i >> 2;
+        const int c = (int)(i & 3);
+        float gmu = 0.f, gsl = 0.f;
+        if (!fg || fg[r]) {
+            const float var_p0 = sigmoidf_(slp[i]);
+            float w = 1.f;
+            if (efl) {
+                const float ent = 0.5f * logf(2.f * PI_F * E_F * var_p0);
+                w = powf(1.f - ent / max_ent, lambda);
+            }
+            const float var_p = var_p0 * tau;
+            const float var_q = sigmoidf_(q[r * 8 + 4 + c]);
+            const float diff = q[r * 8 + c] - mup[i];
+            const float kl = 0.5f * logf(var_q / var_p) - 0.5f + (var_p + diff * diff) / (2.f * var_q);
+            acc += kl * w;
+            if (c == 0) cnt += 1.f;
+            gmu = w * diff / var_q * gscale;
+            const float dvq = w * (0.5f / var_q - (var_p + diff * diff) / (2.f * var_q * var_q));
+            gsl = dvq * var_q * (1.f - var_q) * gscale;
+        }
+        dq[r * 8 + c] = gmu;
+        dq[r * 8 + 4 + c] = gsl;
+        if (dmup) dmup[i] = -gmu;
+    }
+    const float t = block_sum_256(acc, sm);
+    const float tc = block_sum_256(cnt, sm);
+    if (threadIdx.x == 0) {
+        ws[WS_SUM + blockIdx.x] = t;
+        ws[WS_CNT + blockIdx.x] = tc;
+    }
+}
+
+int finalize(float* ws, int nb, float scale, int mean_mode, float* loss_out, hipStream_t st, const char* name)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, st, ws, nb, scale, mean_mode, loss_out, ws + WS_SCALE);
+    PTMI_LAUNCH_CHECK(name);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_bce_logits_sum(const float* logits, const int8_t* labels, int64_t n, float inv_norm, float* loss_out,
+                        float* dlogits, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(loss_out && ws && n >= 0, "bce_logits_sum: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const int nb = blocks_for(n);
+    if (n > 0) {
+        PTMI_CHECK_ARG(logits && labels && dlogits, "bce_logits_sum: null buffer");
+        hipLaunchKernelGGL(bce_kernel, dim3(nb), dim3(256), 0, st, logits, labels, n, inv_norm, dlogits, ws);
+        PTMI_LAUNCH_CHECK("bce_logits_sum");
+    }
+    return finalize(ws, n > 0 ? nb : 0, inv_norm, 0, loss_out, st, "bce_finalize");
+}
+
+int ptmi_gaussian_nll_sum(const float* d, const float* t, int64_t rows, float inv_norm, float* loss_out, float* dd,
+                          float* dt, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(loss_out && ws && rows >= 0, "gaussian_nll_sum: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const int nb = blocks_for(rows * 4);
+    if (rows > 0) {
+        PTMI_CHECK_ARG(d && t && dd, "gaussian_nll_sum: null buffer");
+        hipLaunchKernelGGL(gnll_kernel, dim3(nb), dim3(256), 0, st, d, t, rows, inv_norm, dd, dt, ws);
+        PTMI_LAUNCH_CHECK("gaussian_nll_sum");
+    }
+    return finalize(ws, rows > 0 ? nb : 0, inv_norm, 0, loss_out, st, "gnll_finalize");
+}
+
+int ptmi_softmax_ce_mean(const float* logits, const int64_t* target, int64_t r, int c, float* loss_out,
+                         float* dlogits, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(loss_out && ws && r >= 0 && c > 0, "softmax_ce_mean: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const int nb = blocks_for(r);
+    const float inv_r = r > 0 ? 1.0f / (float)r : 0.f;
+    if (r > 0) {
+        PTMI_CHECK_ARG(logits && target && dlogits, "softmax_ce_mean: null buffer");
+        hipLaunchKernelGGL(softmax_ce_kernel, dim3(nb), dim3(256), 0, st, logits, target, r, c, inv_r, dlogits, ws);
+        PTMI_LAUNCH_CHECK("softmax_ce_mean");
+    }
+    return finalize(ws, r > 0 ? nb : 0, inv_r, 0, loss_out, st, "ce_finalize");   // r == 0 -> 0 (D2 cross_entropy)
+}
+
+int ptmi_softmax_rows(const float* logits, float* probs, int64_t r, int c, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(r >= 0 && c > 0, "softmax_rows: bad args");
+    if (r == 0) return 0;
+    PTMI_CHECK_ARG(logits && probs, "softmax_rows: null buffer");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(blocks_for(r)), dim3(256), 0, (hipStream_t)s, logits, probs, r, c);
+    PTMI_LAUNCH_CHECK("softmax_rows");
+    return 0;
+}
+
+int ptmi_soft_ce_efl(const float* t, const float* s_logits, int64_t r, int c, float tau, float lambda, int efl,
+                     float inv_norm, float* loss_out, float* ds, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(loss_out && ws && r >= 0 && c > 0, "soft_ce_efl: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const int nb = blocks_for(r);
+    if (r > 0) {
+        PTMI_CHECK_ARG(t && s_logits && ds, "soft_ce_efl: null buffer");
+        hipLaunchKernelGGL(soft_ce_efl_kernel, dim3(nb), dim3(256), 0, st, t, s_logits, r, c, tau, lambda, efl, inv_norm,
+                           ds, ws);
+        PTMI_LAUNCH_CHECK("soft_ce_efl");
+    }
+    return finalize(ws, r > 0 ? nb : 0, inv_norm, 0, loss_out, st, "soft_ce_finalize");
+}
+
+int ptmi_rpn_soft_obj_loss(const float* t, const float* x, int64_t k, int c, float tau, float lambda, int efl,
+                           float inv_norm, float* loss_out, float* dx, uint8_t* fg, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(loss_out && ws && k >= 0 && c > 1, "rpn_soft_obj_loss: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const int nb = blocks_for(k);
+    if (k > 0) {
+        PTMI_CHECK_ARG(t && x && dx && fg, "rpn_soft_obj_loss: null buffer");
+        hipLaunchKernelGGL(rpn_soft_obj_kernel, dim3(nb), dim3(256), 0, st, t, x, k, c, tau, lambda, efl, inv_norm, dx,
+                           fg, ws);
+        PTMI_LAUNCH_CHECK("rpn_soft_obj_loss");
+    }
+    return finalize(ws, k > 0 ? nb : 0, inv_norm, 0, loss_out, st, "rpn_soft_obj_finalize");
+}
+
+int ptmi_kl_efl_loss(const float* q, const float* mu_p, const float* slog_p, const uint8_t* fg, int64_t rows,
+                     float tau, float lambda, int efl, int reduction, float inv_norm, float* loss_out, float* dq,
+                     float* dmu_p, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(loss_out && ws && rows >= 0 && (reduction == 0 || reduction == 1), "kl_efl_loss: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const int nb = blocks_for(rows * 4);
+    if (rows > 0) {
+        PTMI_CHECK_ARG(q && mu_p && slog_p && dq, "kl_efl_loss: null buffer");
+        hipLaunchKernelGGL(kl_efl_kernel, dim3(nb), dim3(256), 0, st, q, mu_p, slog_p, fg, rows, tau, lambda, efl,
+                           reduction == 0 ? inv_norm : 1.0f, dq, dmu_p, ws);
+        PTMI_LAUNCH_CHECK("kl_efl_loss");
+    } else {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * 2049, st);
+        if (e != hipSuccess) { ptmi_set_error("kl_efl_loss: memset failed"); return -2; }
+    }
+    const int rc = finalize(ws, rows > 0 ? nb : 0, inv_norm, reduction, loss_out, st, "kl_finalize");
+    if (rc) return rc;
+    if (reduction == 1 && rows > 0) {
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for(rows * 8)), dim3(256), 0, st, dq, rows * 8, ws + WS_SCALE);
+        PTMI_LAUNCH_CHECK("kl_scale");
+        if (dmu_p) {
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks_for(rows * 4)), dim3(256), 0, st, dmu_p, rows * 4,
+                               ws + WS_SCALE);
+            PTMI_LAUNCH_CHECK("kl_scale_mu");
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

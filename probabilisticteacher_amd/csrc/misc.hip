@@ -1,0 +1,285 @@
+// misc.hip -- HBM-bound elementwise / reduction operators of the train step (gfx950).
+//   * 2x2 max pool fwd/bwd      (ATen MaxPool2d at pt/modeling/backbone/vgg.py:59,71)
+//   * image normalise + pad     (D2 preprocess_image reached at pt/modeling/meta_arch/rcnn.py:40)
+//   * shrink-and-paste resize   (pt/engine/trainer.py:557-590)
+//   * EMA / grad-norm / clip+SGD on flat parameter buffers (pt/engine/trainer.py:431-449,592-603,386)
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- max pool
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int nc, int h, int w,
+                                   int oh, int ow)
+{
+    const int64_t total = (int64_t)nc * oh * ow;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = i % ow;
+        const int64_t t = i / ow;
+        const int oy = t % oh;
+        const int64_t c = t / oh;
+        const float* p = x + (c * h + 2 * oy) * (int64_t)w + 2 * ox;
+        const float a = p[0], b = p[1], cc = p[w], d = p[w + 1];
+        // ATen semantics: running max with (val > max) || isnan(val)
+        float m = a;
+        if (b > m || b != b) m = b;
+        if (cc > m || cc != cc) m = cc;
+        if (d > m || d != d) m = d;
+        y[i] = m;
+    }
+}
+
+// dx[pos] = dy[window] iff pos is the FIRST maximum of its window (scan order (0,0),(0,1),(1,0),(1,1)).
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                   float* __restrict__ dx, int nc, int h, int w, int oh, int ow)
+{
+    const int64_t total = (int64_t)nc * h * w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = i % w;
+        const int64_t t = i / w;
+        const int yy = t % h;
+        const int64_t c = t / h;
+        const int ox = xx >> 1, oy = yy >> 1;
+        float g = 0.f;
+        if (ox < ow && oy < oh) {
+            const float* p = x + (c * h + 2 * oy) * (int64_t)w + 2 * ox;
+            const float v[4] = {p[0], p[1], p[w], p[w + 1]};
+            int am = 0;
+            float m = v[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (v[k] > m || v[k] != v[k]) { m = v[k]; am = k; }
+            const int me = (yy & 1) * 2 + (xx & 1);
+            if (me == am) g = dy[(c * oh + oy) * (int64_t)ow + ox];
+        }
+        dx[i] = g;
+    }
+}
+
+// ---------------------------------------------------------------------------------- image prep
+__global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int h, int w,
+                                  int hmax, int wmax, float m0, float m1, float m2, float s0, float s1, float s2)
+{
+    const int64_t total = 3ll * hmax * wmax;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = i % wmax;
+        const int64_t t = i / wmax;
+        const int y = t % hmax;
+        const int c = t / hmax;
+        float v = 0.f;
+        if (y < h && x < w) {
+            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+            const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+            v = ((float)img[((int64_t)c * h + y) * w + x] - mean) / sd;
+        }
+        out[i] = v;
+    }
+}
+
+// F.interpolate(bilinear, align_corners=False) from (h,w) to (dh,dw), truncated to uint8, pasted at
+// (y1,x1) on a canvas of int(pixel_mean)   (trainer.py:563-575).
+__global__ void shrink_paste_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, int h, int w,
+                                    int dh, int dw, int y1, int x1, int m0, int m1, int m2)
+{
+    const int64_t total = 3ll * h * w;
+    const float sy = (float)h / (float)dh, sx = (float)w / (float)dw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = i % w;
+        const int64_t t = i / w;
+        const int y = t % h;
+        const int c = t / h;
+        int v = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        const int oy = y - y1, ox = x - x1;
+        if (oy >= 0 && oy < dh && ox >= 0 && ox < dw) {
+            // ATen area_pixel_compute_source_index(align_corners=False): max(scale*(dst+0.5)-0.5, 0)
+            float fy = sy * ((float)oy + 0.5f) - 0.5f;
+            float fx = sx * ((float)ox + 0.5f) - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            fx = fx < 0.f ? 0.f : fx;
+            const int iy = (int)fy, ix = (int)fx;
+            const int iy1 = iy + (iy < h - 1 ? 1 : 0), ix1 = ix + (ix < w - 1 ? 1 : 0);
+            const float ly = fy - (float)iy, lx = fx - (float)ix;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const uint8_t* p = img + (int64_t)c * h * w;
+            const float r = hy * (hx * (float)p[(int64_t)iy * w + ix] + lx * (float)p[(int64_t)iy * w + ix1]) +
+                            ly * (hx * (float)p[(int64_t)iy1 * w + ix] + lx * (float)p[(int64_t)iy1 * w + ix1]);
+            v = (int)r;   // float -> uint8 truncation on assignment into the uint8 canvas
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        out[i] = (uint8_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------- optimiser
+__global__ void ema_kernel(const float* __restrict__ s, float* __restrict__ t, int64_t n, float k, float omk)
+{
+    const int64_t n4 = n >> 2;
+    const float4* s4 = reinterpret_cast<const float4*>(s);
+    float4* t4 = reinterpret_cast<float4*>(t);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = s4[i];
+        float4 b = t4[i];
+        b.x = a.x * omk + b.x * k;
+        b.y = a.y * omk + b.y * k;
+        b.z = a.z * omk + b.z * k;
+        b.w = a.w * omk + b.w * k;
+        t4[i] = b;
+    }
+    for (int64_t i = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        t[i] = s[i] * omk + t[i] * k;
+}
+
+constexpr int SUMSQ_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n,
+                                                            float* __restrict__ partial)
+{
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = g[i];
+        acc += v * v;
+    }
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict__ partial, int np,
+                                                        float* __restrict__ out)
+{
+    __shared__ float sm[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+    const float t = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+__global__ void clip_sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                int64_t n, const float* __restrict__ sumsq, float clip, float lr, float mu,
+                                float wd, int first)
+{
+    const float total = sqrtf(sumsq[0]);
+    const float sc = clip / fmaxf(total, clip);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float gv = g[i] * sc + wd * pv;
+        const float b = first ? gv : mu * buf[i] + gv;
+        buf[i] = b;
+        p[i] = pv - lr * b;
+    }
+}
+
+__global__ void scale_by_clip_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ sumsq, float clip)
+{
+    const float total = sqrtf(sumsq[0]);
+    const float sc = clip / fmaxf(total, clip);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        g[i] *= sc;
+}
+
+inline unsigned grid_for(int64_t n, int per = 256, int cap = 8192)
+{
+    int64_t b = (n + per - 1) / per;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && y && nc > 0 && h >= 2 && w >= 2, "maxpool2x2_fwd: bad args");
+    const int oh = h / 2, ow = w / 2;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)nc * oh * ow)), dim3(256), 0, (hipStream_t)s, x,
+                       y, nc, h, w, oh, ow);
+    PTMI_LAUNCH_CHECK("maxpool2x2_fwd");
+    return 0;
+}
+
+int ptmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && dy && dx && nc > 0 && h >= 2 && w >= 2, "maxpool2x2_bwd: bad args");
+    const int oh = h / 2, ow = w / 2;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)nc * h * w)), dim3(256), 0, (hipStream_t)s, x, dy,
+                       dx, nc, h, w, oh, ow);
+    PTMI_LAUNCH_CHECK("maxpool2x2_bwd");
+    return 0;
+}
+
+int ptmi_preprocess_image(const uint8_t* img, float* out, int h, int w, int hmax, int wmax, float m0, float m1,
+                          float m2, float s0, float s1, float s2, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(img && out && h > 0 && w > 0 && hmax >= h && wmax >= w, "preprocess_image: bad args");
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(3ll * hmax * wmax)), dim3(256), 0, (hipStream_t)s, img, out,
+                       h, w, hmax, wmax, m0, m1, m2, s0, s1, s2);
+    PTMI_LAUNCH_CHECK("preprocess_image");
+    return 0;
+}
+
+int ptmi_shrink_paste(const uint8_t* img, uint8_t* out, int h, int w, int dh, int dw, int y1, int x1, int m0,
+                      int m1, int m2, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(img && out && h > 0 && w > 0 && dh > 0 && dw > 0 && dh <= h && dw <= w && y1 >= 0 && x1 >= 0,
+                   "shrink_paste: bad args");
+    hipLaunchKernelGGL(shrink_paste_kernel, dim3(grid_for(3ll * h * w)), dim3(256), 0, (hipStream_t)s, img, out, h,
+                       w, dh, dw, y1, x1, m0, m1, m2);
+    PTMI_LAUNCH_CHECK("shrink_paste");
+    return 0;
+}
+
+int ptmi_ema_update(const float* student, float* teacher, int64_t n, float keep_rate, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(student && teacher && n >= 0, "ema_update: bad args");
+    if (n == 0) return 0;
+    // (1 - k) is formed in double then rounded, exactly as python `1 - keep_rate` feeds torch (trainer.py:443)
+    const float omk = (float)(1.0 - (double)keep_rate);
+    hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, student, teacher, n,
+                       keep_rate, omk);
+    PTMI_LAUNCH_CHECK("ema_update");
+    return 0;
+}
+
+int ptmi_sumsq(const float* g, int64_t n, float* sumsq_out, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(g && sumsq_out && ws && n >= 0, "sumsq: bad args");
+    int np = (int)((n + 255) / 256);
+    if (np > SUMSQ_BLOCKS) np = SUMSQ_BLOCKS;
+    if (np < 1) np = 1;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(np), dim3(256), 0, (hipStream_t)s, g, n, ws);
+    PTMI_LAUNCH_CHECK("sumsq_partial");
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, ws, np, sumsq_out);
+    PTMI_LAUNCH_CHECK("sumsq_final");
+    return 0;
+}
+
+int ptmi_clip_sgd_step(float* p, const float* g, float* buf, int64_t n, const float* sumsq, float clip_norm,
+                       float lr, float momentum, float weight_decay, int first, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(p && g && buf && sumsq && n >= 0, "clip_sgd_step: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(clip_sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, p, g, buf, n, sumsq,
+                       clip_norm, lr, momentum, weight_decay, first);
+    PTMI_LAUNCH_CHECK("clip_sgd_step");
+    return 0;
+}
+
+int ptmi_scale_by_clip(float* g, int64_t n, const float* sumsq, float clip_norm, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(g && sumsq && n >= 0, "scale_by_clip: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_by_clip_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, g, n, sumsq, clip_norm);
+    PTMI_LAUNCH_CHECK("scale_by_clip");
+    return 0;
+}
+
+}  // extern "C"

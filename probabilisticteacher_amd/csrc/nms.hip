@@ -1,0 +1,143 @@
+// nms.hip -- batched greedy NMS for gfx950: 64-bit suppression bitmask (one wave64 ballot word per
+// 64-box column block) + a chunked in-order scan, all images of a batch in one launch each.
+//
+// Replaces torchvision.ops.nms (via detectron2 batched_nms) at
+// pt/modeling/proposal_generator/proposal_utils.py:140 and pt/modeling/roi_heads/fast_rcnn.py:104.
+// Bit-exact against the CPU oracle: IoU = inter / (area_i + area_j - inter), fp32, no FMA contraction
+// (-ffp-contract=off), suppression iff IoU > thr (strict), candidates visited in the given
+// (descending-score, stable) order.
+#include "common.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+// mask[img][i][w] bit b set  <=>  box j = 64*w + b (j > i) is suppressed by box i.
+// grid = (colBlocks, rowBlocks, nimg), block = 64 threads (one wave): thread t owns row box 64*rb + t.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes,
+                                                      const int32_t* __restrict__ seg, float thr, int words,
+                                                      int64_t max_count, u64* __restrict__ mask)
+{
+    const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
+    if (cb < rb) return;
+    const int beg = seg[img], n = seg[img + 1] - beg;
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ float4 cbox[64];
+    __shared__ float carea[64];
+    const int t = threadIdx.x;
+    const int cj = cb * 64 + t;
+    if (cj < n) {
+        const float4 b = reinterpret_cast<const float4*>(boxes)[beg + cj];
+        cbox[t] = b;
+        carea[t] = (b.z - b.x) * (b.w - b.y);
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= n) return;
+    const float4 a = reinterpret_cast<const float4*>(boxes)[beg + i];
+    const float aarea = (a.z - a.x) * (a.w - a.y);
+    const int lim = min(64, n - cb * 64);
+    u64 bits = 0;
+    const int start = (cb == rb) ? t + 1 : 0;
+    for (int k = start; k < lim; ++k) {
+        const float4 b = cbox[k];
+        const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+        const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+        float w = xx2 - xx1, h = yy2 - yy1;
+        w = w < 0.f ? 0.f : w;
+        h = h < 0.f ? 0.f : h;
+        const float inter = w * h;
+        const float iou = inter / (aarea + carea[k] - inter);
+        if (iou > thr) bits |= 1ull << k;
+    }
+    mask[((size_t)img * max_count + i) * words + cb] = bits;
+}
+
+// One wave per image walks the boxes in order, 64 at a time.
+__global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ seg,
+                                                      int words, int64_t max_count, int max_keep,
+                                                      int32_t* __restrict__ keep, int32_t* __restrict__ keep_count)
+{
+    extern __shared__ u64 removed[];   // words entries
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int n = seg[img + 1] - seg[img];
+    const u64* M = mask + (size_t)img * max_count * words;
+    for (int w = lane; w < words; w += 64) removed[w] = 0;
+    __syncthreads();
+    int count = 0;
+    const int chunks = (n + 63) / 64;
+    for (int c = 0; c < chunks && count < max_keep; ++c) {
+        const int row = c * 64 + lane;
+        u64 diag = 0;
+        if (row < n) diag = M[(size_t)row * words + c];
+        u64 cur = removed[c];
+        if (c == chunks - 1 && (n & 63)) cur |= ~0ull << (n & 63);   // rows past n do not exist
+        // resolve the 64x64 diagonal block in order (wave-uniform)
+        u64 kept = 0;
+        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+        for (int i = 0; i < 64; ++i) {
+            if (!((cur >> i) & 1ull)) {
+                kept |= 1ull << i;
+                const u64 di = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                               (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+                cur |= di;
+            }
+        }
+        // emit kept indices in order, capped at max_keep
+        const int nk = __popcll(kept);
+        if ((kept >> lane) & 1ull) {
+            const int pos = count + __popcll(kept & ((1ull << lane) - 1ull));
+            if (pos < max_keep) keep[(size_t)img * max_keep + pos] = row;
+        }
+        count += nk;
+        if (count >= max_keep) break;
+        // fold the kept rows into the remaining words (lanes stride over words; loads coalesced)
+        for (int w = c + 1 + lane; w < chunks; w += 64) {
+            u64 acc = removed[w];
+            u64 kb = kept;
+            while (kb) {
+                const int i = __ffsll((long long)kb) - 1;
+                kb &= kb - 1;
+                acc |= M[(size_t)(c * 64 + i) * words + w];
+            }
+            removed[w] = acc;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) keep_count[img] = count < max_keep ? count : max_keep;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ptmi_nms_ws_bytes(int64_t max_count, int nimg)
+{
+    const int64_t words = (max_count + 63) / 64;
+    return (int64_t)nimg * max_count * words * 8;
+}
+
+int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, int nimg, int64_t max_count, float thr,
+                     int max_keep, int32_t* keep_out, int32_t* keep_count, void* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(boxes && seg_offsets && keep_out && keep_count && ws && nimg > 0 && max_count >= 0 && max_keep > 0,
+                   "nms_batched: bad args");
+    hipStream_t st = (hipStream_t)s;
+    if (max_count == 0) {
+        hipError_t e = hipMemsetAsync(keep_count, 0, sizeof(int32_t) * (size_t)nimg, st);
+        if (e != hipSuccess) { ptmi_set_error("nms_batched: memset failed"); return -2; }
+        return 0;
+    }
+    const int words = (int)((max_count + 63) / 64);
+    PTMI_CHECK_ARG((size_t)words * 8 <= 64 * 1024, "nms_batched: max_count %lld too large", (long long)max_count);
+    dim3 grid(words, words, nimg);
+    hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(64), 0, st, boxes, seg_offsets, thr, words, max_count,
+                       reinterpret_cast<u64*>(ws));
+    PTMI_LAUNCH_CHECK("nms_mask");
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(nimg), dim3(64), (size_t)words * 8, st, reinterpret_cast<const u64*>(ws),
+                       seg_offsets, words, max_count, max_keep, keep_out, keep_count);
+    PTMI_LAUNCH_CHECK("nms_scan");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// roi_align.hip -- ROIAlign (aligned=True, sampling_ratio=0 adaptive grid) fwd/bwd for gfx950.
+//
+// Replaces torchvision roi_align, which the reference reaches through detectron2's ROIPooler built at
+// pt/modeling/roi_heads/roi_heads.py:68-73 and called at :126.  Gather-bound: the
+// 50x83x512 fp32 feature map of an image (8.5 MB) lives in L2/MALL, one workgroup per ROI walks all
+// channels with threads laid out along (c, ph, pw) so that the (R, C, 7, 7) output is written with
+// fully coalesced stores.  Backward scatters with hardware fp32 atomics (-munsafe-fp-atomics).
+#include "common.h"
+
+namespace {
+
+struct RoiGeom {
+    int b;
+    float sw, sh, bw, bh;
+    int gw, gh;
+    float count;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float* __restrict__ roi, float scale, int P)
+{
+    RoiGeom g;
+    g.b = (int)roi[0];
+    g.sw = roi[1] * scale - 0.5f;
+    g.sh = roi[2] * scale - 0.5f;
+    const float ew = roi[3] * scale - 0.5f, eh = roi[4] * scale - 0.5f;
+    const float rw = ew - g.sw, rh = eh - g.sh;
+    g.bw = rw / (float)P;
+    g.bh = rh / (float)P;
+    g.gw = (int)ceilf(rw / (float)P);
+    g.gh = (int)ceilf(rh / (float)P);
+    const int c = g.gh * g.gw;
+    g.count = (float)(c > 1 ? c : 1);
+    return g;
+}
+
+__device__ __forceinline__ bool bilin(float y, float x, int H, int W, int& yl, int& xl, int& yh, int& xh, float& w1,
+                                      float& w2, float& w3, float& w4)
+{
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return false;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    yl = (int)y;
+    xl = (int)x;
+    if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+    const float ly = y - (float)yl, lx = x - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+    w1 = hy * hx; w2 = hy * lx; w3 = ly * hx; w4 = ly * lx;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restrict__ feat,
+                                                            const float* __restrict__ rois, float* __restrict__ out,
+                                                            int C, int H, int W, int P, float scale)
+{
+    const int r = blockIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, P);
+    const int PP = P * P, total = C * PP;
+    const float* fb = feat + (size_t)g.b * C * H * W;
+    float* ob = out + (size_t)r * total;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int c = i / PP, rem = i - c * PP;
+        const int ph = rem / P, pw = rem - ph * P;
+        const float* f = fb + (size_t)c * H * W;
+        float acc = 0.f;
+        for (int iy = 0; iy < g.gh; ++iy) {
+            const float y = g.sh + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ++ix) {
+                const float x = g.sw + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                int yl, xl, yh, xh;
+                float w1, w2, w3, w4;
+                if (!bilin(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+                acc += w1 * f[yl * W + xl] + w2 * f[yl * W + xh] + w3 * f[yh * W + xl] + w4 * f[yh * W + xh];
+            }
+        }
+        ob[i] = acc / g.count;
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restrict__ dout,
+                                                            const float* __restrict__ rois, float* __restrict__ dfeat,
+                                                            int C, int H, int W, int P, float scale)
+{
+    const int r = blockIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, P);
+    const int PP = P * P, total = C * PP;
+    float* fb = dfeat + (size_t)g.b * C * H * W;
+    const float* ob = dout + (size_t)r * total;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int c = i / PP, rem = i - c * PP;
+        const int ph = rem / P, pw = rem - ph * P;
+        float* f = fb + (size_t)c * H * W;
+        const float go = ob[i];
+        for (int iy = 0; iy < g.gh; ++iy) {
+            const float y = g.sh + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ++ix) {
+                const float x = g.sw + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                int yl, xl, yh, xh;
+                float w1, w2, w3, w4;
+                if (!bilin(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+                atomicAdd(f + yl * W + xl, go * w1 / g.count);
+                atomicAdd(f + yl * W + xh, go * w2 / g.count);
+                atomicAdd(f + yh * W + xl, go * w3 / g.count);
+                atomicAdd(f + yh * W + xh, go * w4 / g.count);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptmi_roi_align_fwd(const float* feat, const float* rois, float* out, int n, int c, int h, int w, int r,
+                       int pooled, float scale, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(feat && out && n > 0 && c > 0 && h > 0 && w > 0 && r >= 0 && pooled > 0, "roi_align_fwd: bad args");
+    if (r == 0) return 0;
+    PTMI_CHECK_ARG(rois, "roi_align_fwd: rois missing");
+    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)s, feat, rois, out, c, h, w, pooled,
+                       scale);
+    PTMI_LAUNCH_CHECK("roi_align_fwd");
+    return 0;
+}
+
+int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n, int c, int h, int w, int r,
+                       int pooled, float scale, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(dout && dfeat && n > 0 && c > 0 && h > 0 && w > 0 && r >= 0 && pooled > 0, "roi_align_bwd: bad args");
+    if (r == 0) return 0;
+    PTMI_CHECK_ARG(rois, "roi_align_bwd: rois missing");
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)s, dout, rois, dfeat, c, h, w, pooled,
+                       scale);
+    PTMI_LAUNCH_CHECK("roi_align_bwd");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,622 @@
+"""torch-facing wrappers of the HIP operators in libptmi355.so.
+
+PyTorch is used here for device memory (caching allocator), the current HIP stream and the autograd tape
+only; every operator body is a hand-written gfx950 kernel reached through the C ABI (include/ptmi355.h).
+There is no CPU path: tensors must live on a ROCm device and the shared library must be present.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, dtype=F32, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.PtmiError(f"{name}: expected a ROCm device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.PtmiError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.PtmiError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+_WS = {}
+
+
+def _ws(name: str, nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device scratch buffers (kernels are stream-ordered, so reuse is safe)."""
+    key = (name, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _loss_ws(device) -> torch.Tensor:
+    return _ws("loss", 4096 * 4, device)
+
+
+# ============================================================================ conv 3x3
+def conv3x3_pack(w: torch.Tensor, mode: int) -> torch.Tensor:
+    _chk(w, name="conv weight")
+    co, ci = w.shape[0], w.shape[1]
+    conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
+    n = _lib.load().ptmi_conv3x3_packed_floats(conv_cin, conv_cout)
+    wp = torch.empty(n, dtype=F32, device=w.device)
+    _lib.call("ptmi_conv3x3_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
+    return wp
+
+
+def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor:
+    _chk(x, name="conv input")
+    n, cin, h, w = x.shape
+    y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
+    _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
+              epilogue, _stream())
+    return y
+
+
+def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    dz = torch.empty_like(dy)
+    _lib.call("ptmi_relu_bwd", _ptr(_chk(dy.contiguous())), _ptr(_chk(y)), _ptr(dz), dy.numel(), _stream())
+    return dz
+
+
+class _Conv3x3(torch.autograd.Function):
+    """conv3x3 s1 p1 + bias (+ ReLU).  Replaces Conv2d + F.relu_ (vgg.py:45-53,66-69)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool):
+        x = _chk(x.contiguous(), name="conv input")
+        weight = _chk(weight.contiguous(), name="conv weight")
+        bias = _chk(bias.contiguous(), name="conv bias")
+        wp = conv3x3_pack(weight, 0)
+        y = conv3x3_raw(x, wp, bias, None, weight.shape[0], 1 if relu else 0)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _chk(dy.contiguous(), name="conv grad")
+        dz = relu_bwd(dy, y) if ctx.relu else dy
+        n, cin, h, w = x.shape
+        cout = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = torch.empty_like(weight)
+            db = torch.empty(cout, dtype=F32, device=x.device)
+            nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w)
+            ws = _ws("wgrad", nws * 4, x.device)
+            _lib.call("ptmi_conv3x3_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
+                      _stream())
+        if ctx.needs_input_grad[0]:
+            wpd = conv3x3_pack(weight, 1)
+            dx = conv3x3_raw(dz, wpd, None, None, cin, 2)
+        return dx, dw, db, None
+
+
+def conv3x3(x, weight, bias, relu: bool = True):
+    return _Conv3x3.apply(x, weight, bias, relu)
+
+
+# ============================================================================ max pool
+class _MaxPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _chk(x.contiguous(), name="pool input")
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, h // 2, w // 2), dtype=F32, device=x.device)
+        _lib.call("ptmi_maxpool2x2_fwd", _ptr(x), _ptr(y), n * c, h, w, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        _lib.call("ptmi_maxpool2x2_bwd", _ptr(x), _ptr(_chk(dy.contiguous())), _ptr(dx), n * c, h, w, _stream())
+        return dx
+
+
+def maxpool2x2(x):
+    return _MaxPool2x2.apply(x)
+
+
+# ============================================================================ GEMM family
+def gemm(a, b, m, n, k, lda, ldb, ta, tb, bias=None, bias_mode=0, relu=False, out=None, accumulate=False,
+         batch=1, stride_a=0, stride_b=0, stride_c=0, ldc=None):
+    """C = op(A) op(B) (+bias)(relu); see ptmi_gemm_f32."""
+    if out is None:
+        shape = (m, n) if batch == 1 else (batch, m, n)
+        out = torch.empty(shape, dtype=F32, device=a.device)
+    ldc = n if ldc is None else ldc
+    if m == 0 or n == 0:
+        return out
+    _lib.call("ptmi_gemm_f32", _ptr(a), _ptr(b), _ptr(out), _ptr(bias), m, n, k, lda, ldb, ldc, ta, tb, bias_mode,
+              int(relu), int(accumulate), batch, stride_a, stride_b, stride_c, _stream())
+    return out
+
+
+def colsum(a: torch.Tensor) -> torch.Tensor:
+    rows, cols = a.shape
+    out = torch.empty(cols, dtype=F32, device=a.device)
+    if rows == 0:
+        return out.zero_()
+    _lib.call("ptmi_colsum", _ptr(a), _ptr(out), rows, cols, 0, _stream())
+    return out
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b (+ReLU).  Replaces nn.Linear/F.relu of FastRCNNConvFCHead + predictors."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool):
+        x = _chk(x.contiguous(), name="linear input")
+        weight = _chk(weight.contiguous())
+        bias = _chk(bias.contiguous())
+        r, k = x.shape
+        nout = weight.shape[0]
+        y = gemm(x, weight, r, nout, k, k, k, 0, 1, bias=bias, bias_mode=2, relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _chk(dy.contiguous())
+        dz = relu_bwd(dy, y) if ctx.relu else dy
+        r, k = x.shape
+        nout = weight.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(dz, weight, r, k, nout, nout, k, 0, 0)                  # (r,nout) x (nout,k)
+        if ctx.needs_input_grad[1]:
+            if r == 0:
+                dw = torch.zeros_like(weight)
+            else:
+                dw = gemm(dz, x, nout, k, r, nout, k, 1, 0)                   # dz^T (nout,r) x x (r,k)
+        if ctx.needs_input_grad[2]:
+            db = colsum(dz)
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias, relu: bool = False):
+    return _Linear.apply(x, weight, bias, relu)
+
+
+class _Conv1x1(torch.autograd.Function):
+    """1x1 conv as a batched GEMM over images (D2 StandardRPNHead objectness / anchor-delta convs)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _chk(x.contiguous())
+        n, ci, h, w = x.shape
+        co = weight.shape[0]
+        w2 = _chk(weight.reshape(co, ci).contiguous())
+        hw = h * w
+        y = torch.empty((n, co, h, w), dtype=F32, device=x.device)
+        gemm(w2, x, co, hw, ci, ci, hw, 0, 0, bias=_chk(bias.contiguous()), bias_mode=1, out=y, batch=n, stride_a=0,
+             stride_b=ci * hw, stride_c=co * hw, ldc=hw)
+        ctx.save_for_backward(x, w2)
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        dy = _chk(dy.contiguous())
+        n, ci, h, w = x.shape
+        co, hw = w2.shape[0], h * w
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            gemm(w2, dy, ci, hw, co, ci, hw, 1, 0, out=dx, batch=n, stride_a=0, stride_b=co * hw, stride_c=ci * hw,
+                 ldc=hw)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((co, ci), dtype=F32, device=x.device)
+            for i in range(n):                                               # accumulate over images, fixed order
+                gemm(dy[i], x[i], co, ci, hw, hw, hw, 0, 1, out=dw, accumulate=True)
+            dw = dw.view(ctx.wshape)
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(co, dtype=F32, device=x.device)
+            _lib.call("ptmi_rowsum_batched", _ptr(dy), _ptr(db), n, co, hw, 0, _stream())
+        return dx, dw, db
+
+
+def conv1x1(x, weight, bias):
+    return _Conv1x1.apply(x, weight, bias)
+
+
+# ============================================================================ ROIAlign
+class _ROIAlign(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, pooled: int, scale: float):
+        feat = _chk(feat.contiguous())
+        rois = _chk(rois.contiguous())
+        n, c, h, w = feat.shape
+        r = rois.shape[0]
+        out = torch.empty((r, c, pooled, pooled), dtype=F32, device=feat.device)
+        _lib.call("ptmi_roi_align_fwd", _ptr(feat), _ptr(rois), _ptr(out), n, c, h, w, r, pooled, float(scale), _stream())
+        ctx.save_for_backward(rois)
+        ctx.meta = (n, c, h, w, pooled, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (rois,) = ctx.saved_tensors
+        n, c, h, w, pooled, scale = ctx.meta
+        dfeat = torch.zeros((n, c, h, w), dtype=F32, device=dout.device)
+        _lib.call("ptmi_roi_align_bwd", _ptr(_chk(dout.contiguous())), _ptr(rois), _ptr(dfeat), n, c, h, w,
+                  rois.shape[0], pooled, scale, _stream())
+        return dfeat, None, None, None
+
+
+def roi_align(feat, rois, pooled: int, scale: float):
+    return _ROIAlign.apply(feat, rois, pooled, scale)
+
+
+# ============================================================================ boxes
+def grid_anchors(cell: torch.Tensor, h: int, w: int, stride: float, offset: float) -> torch.Tensor:
+    cell = _chk(cell.contiguous())
+    a = cell.shape[0]
+    out = torch.empty((h * w * a, 4), dtype=F32, device=cell.device)
+    _lib.call("ptmi_grid_anchors", _ptr(cell), _ptr(out), h, w, a, float(stride), float(offset), _stream())
+    return out
+
+
+def apply_deltas(deltas: torch.Tensor, boxes: torch.Tensor, weights: Sequence[float], scale_clamp: float,
+                 k: Optional[int] = None, dstride: Optional[int] = None) -> torch.Tensor:
+    """deltas (rows, >=4k) [row stride dstride], boxes (nb,4) cycled over rows -> (rows, 4k)."""
+    _chk(deltas)
+    boxes = _chk(boxes.contiguous())
+    rows = deltas.shape[0]
+    dstride = deltas.shape[1] if dstride is None else dstride
+    k = deltas.shape[1] // 4 if k is None else k
+    out = torch.empty((rows, 4 * k), dtype=F32, device=deltas.device)
+    wx, wy, ww, wh = [float(v) for v in weights]
+    if rows:
+        _lib.call("ptmi_apply_deltas", _ptr(deltas), _ptr(boxes), _ptr(out), rows, k, dstride, boxes.shape[0], wx, wy,
+                  ww, wh, float(scale_clamp), _stream())
+    return out
+
+
+class _GetDeltas(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, tgt, wx, wy, ww, wh):
+        src = _chk(src.contiguous())
+        tgt = _chk(tgt.contiguous())
+        out = torch.empty_like(src)
+        if src.shape[0]:
+            _lib.call("ptmi_get_deltas", _ptr(src), _ptr(tgt), _ptr(out), src.shape[0], wx, wy, ww, wh, _stream())
+        ctx.save_for_backward(src, tgt)
+        ctx.w = (wx, wy, ww, wh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dd):
+        src, tgt = ctx.saved_tensors
+        dsrc = None
+        if ctx.needs_input_grad[0]:
+            rows = src.shape[0]
+            dsrc = torch.zeros_like(src)
+            if rows:
+                idx = torch.arange(rows, dtype=torch.int64, device=src.device)
+                _lib.call("ptmi_get_deltas_bwd_src", _ptr(src), _ptr(tgt), _ptr(_chk(dd.contiguous())), _ptr(idx), rows,
+                          *ctx.w, _ptr(dsrc), _stream())
+        return dsrc, None, None, None, None, None
+
+
+def get_deltas(src, tgt, weights: Sequence[float]):
+    wx, wy, ww, wh = [float(v) for v in weights]
+    return _GetDeltas.apply(src, tgt, wx, wy, ww, wh)
+
+
+def iou_match(gt: torch.Tensor, boxes: torch.Tensor, thresholds: Sequence[float], labels: Sequence[int],
+              allow_low_quality: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """pairwise_iou + Matcher fused -> (matched_idx int64, matched_label int8, matched_iou f32)."""
+    boxes = _chk(boxes.contiguous())
+    gt = _chk(gt.contiguous())
+    nb, m = boxes.shape[0], gt.shape[0]
+    dev = boxes.device
+    midx = torch.empty(nb, dtype=torch.int64, device=dev)
+    mlab = torch.empty(nb, dtype=torch.int8, device=dev)
+    miou = torch.empty(nb, dtype=F32, device=dev)
+    ws = _ws("ioum", max(m, 1) * 4, dev)
+    thr = (ctypes.c_float * len(thresholds))(*[float(t) for t in thresholds])
+    lab = (ctypes.c_int * len(labels))(*[int(l) for l in labels])
+    _lib.call("ptmi_iou_match", _ptr(gt), _ptr(boxes), m, nb, thr, lab, len(thresholds), int(allow_low_quality),
+              _ptr(midx), _ptr(mlab), _ptr(miou), _ptr(ws), _stream())
+    return midx, mlab, miou
+
+
+# ============================================================================ sort / proposals / NMS
+def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable descending sort inside each segment.  Returns (sorted keys, index within segment int32)."""
+    keys = _chk(keys.contiguous())
+    seg_offsets = _chk(seg_offsets.contiguous(), torch.int32)
+    total, nseg = keys.numel(), seg_offsets.numel() - 1
+    out = torch.empty_like(keys)
+    idx = torch.empty(total, dtype=torch.int32, device=keys.device)
+    if total == 0:
+        return out, idx
+    nbytes = _lib.load().ptmi_segsort_ws_bytes(total, nseg)
+    ws = _ws("sort", nbytes, keys.device)
+    _lib.call("ptmi_segsort_desc", _ptr(keys), _ptr(out), _ptr(idx), total, nseg, _ptr(seg_offsets), _ptr(ws), nbytes,
+              _stream())
+    return out, idx
+
+
+def rpn_prepare(decoded, sorted_logits, sorted_idx, sigma_logits, image_sizes_hw, k: int, min_size: float):
+    n, r = sorted_logits.shape
+    dev = decoded.device
+    boxes = torch.empty((n, k, 4), dtype=F32, device=dev)
+    scores = torch.empty((n, k), dtype=F32, device=dev)
+    valid = torch.empty((n, k), dtype=torch.uint8, device=dev)
+    nonfinite = torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.call("ptmi_rpn_prepare", _ptr(_chk(decoded)), _ptr(_chk(sorted_logits)), _ptr(_chk(sorted_idx, torch.int32)),
+              _ptr(_chk(sigma_logits)), _ptr(_chk(image_sizes_hw)), _ptr(boxes), _ptr(scores), _ptr(valid),
+              _ptr(nonfinite), n, r, k, float(min_size), _stream())
+    return boxes, scores, valid, nonfinite
+
+
+def nms_batched(boxes_sorted: torch.Tensor, seg_offsets: torch.Tensor, max_count: int, thr: float, max_keep: int):
+    """boxes (sum,4) sorted by descending score per image; returns keep (nimg,max_keep) int32 positions, counts."""
+    boxes_sorted = _chk(boxes_sorted.contiguous())
+    seg_offsets = _chk(seg_offsets.contiguous(), torch.int32)
+    nimg = seg_offsets.numel() - 1
+    dev = boxes_sorted.device
+    keep = torch.empty((nimg, max_keep), dtype=torch.int32, device=dev)
+    cnt = torch.empty(nimg, dtype=torch.int32, device=dev)
+    nbytes = _lib.load().ptmi_nms_ws_bytes(max_count, nimg)
+    ws = _ws("nms", nbytes, dev)
+    _lib.call("ptmi_nms_batched", _ptr(boxes_sorted), _ptr(seg_offsets), nimg, max_count, float(thr), max_keep,
+              _ptr(keep), _ptr(cnt), _ptr(ws), _stream())
+    return keep, cnt
+
+
+# ============================================================================ losses (loss + gradient in one launch)
+class _LossFn(torch.autograd.Function):
+    """Base: forward stores precomputed grads; backward scales them by the upstream scalar."""
+
+    @staticmethod
+    def _finish(ctx, loss, grads):
+        ctx.save_for_backward(*[g for g in grads if g is not None])
+        ctx.mask = [g is not None for g in grads]
+        return loss.reshape(())
+
+
+def _scale_saved(ctx, gout):
+    saved = list(ctx.saved_tensors)
+    out = []
+    for present in ctx.mask:
+        out.append(saved.pop(0) * gout if present else None)
+    return out
+
+
+class _BCELogitsSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, inv_norm: float):
+        logits = _chk(logits.contiguous())
+        labels = _chk(labels.contiguous(), torch.int8)
+        loss = torch.empty(1, dtype=F32, device=logits.device)
+        dl = torch.empty_like(logits)
+        _lib.call("ptmi_bce_logits_sum", _ptr(logits), _ptr(labels), logits.numel(), float(inv_norm), _ptr(loss),
+                  _ptr(dl), _ptr(_loss_ws(logits.device)), _stream())
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None
+
+
+def bce_logits_sum(logits, labels_i8, inv_norm):
+    return _BCELogitsSum.apply(logits, labels_i8, inv_norm)
+
+
+class _GaussianNLLSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d, t, inv_norm: float):
+        d = _chk(d.contiguous())
+        t = _chk(t.contiguous())
+        rows = d.shape[0]
+        loss = torch.empty(1, dtype=F32, device=d.device)
+        dd = torch.empty_like(d)
+        dt = torch.empty_like(t) if ctx.needs_input_grad[1] else None
+        _lib.call("ptmi_gaussian_nll_sum", _ptr(d), _ptr(t), rows, float(inv_norm), _ptr(loss), _ptr(dd), _ptr(dt),
+                  _ptr(_loss_ws(d.device)), _stream())
+        ctx.has_dt = dt is not None
+        ctx.save_for_backward(dd, dt) if dt is not None else ctx.save_for_backward(dd)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.has_dt:
+            dd, dt = ctx.saved_tensors
+            return dd * g, dt * g, None
+        (dd,) = ctx.saved_tensors
+        return dd * g, None, None
+
+
+def gaussian_nll_sum(d, t, inv_norm):
+    return _GaussianNLLSum.apply(d, t, inv_norm)
+
+
+class _SoftmaxCEMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = _chk(logits.contiguous())
+        target = _chk(target.contiguous(), torch.int64)
+        r, c = logits.shape
+        loss = torch.empty(1, dtype=F32, device=logits.device)
+        dl = torch.empty_like(logits)
+        _lib.call("ptmi_softmax_ce_mean", _ptr(logits), _ptr(target), r, c, _ptr(loss), _ptr(dl),
+                  _ptr(_loss_ws(logits.device)), _stream())
+        ctx.save_for_backward(dl)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def softmax_ce_mean(logits, target):
+    return _SoftmaxCEMean.apply(logits, target)
+
+
+def softmax_rows(logits: torch.Tensor) -> torch.Tensor:
+    logits = _chk(logits.contiguous())
+    out = torch.empty_like(logits)
+    _lib.call("ptmi_softmax_rows", _ptr(logits), _ptr(out), logits.shape[0], logits.shape[1], _stream())
+    return out
+
+
+class _SoftCEEFL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, teacher, student, tau, lam, efl, inv_norm):
+        teacher = _chk(teacher.contiguous())
+        student = _chk(student.contiguous())
+        r, c = student.shape
+        loss = torch.empty(1, dtype=F32, device=student.device)
+        ds = torch.empty_like(student)
+        _lib.call("ptmi_soft_ce_efl", _ptr(teacher), _ptr(student), r, c, float(tau), float(lam), int(efl),
+                  float(inv_norm), _ptr(loss), _ptr(ds), _ptr(_loss_ws(student.device)), _stream())
+        ctx.save_for_backward(ds)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return None, ds * g, None, None, None, None
+
+
+def soft_ce_efl(teacher, student, tau, lam, efl, inv_norm):
+    return _SoftCEEFL.apply(teacher, student, tau, lam, efl, inv_norm)
+
+
+class _RPNSoftObj(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, teacher, x, tau, lam, efl, inv_norm):
+        teacher = _chk(teacher.contiguous())
+        x = _chk(x.contiguous())
+        k, c = teacher.shape
+        loss = torch.empty(1, dtype=F32, device=x.device)
+        dx = torch.empty_like(x)
+        fg = torch.empty(k, dtype=torch.uint8, device=x.device)
+        _lib.call("ptmi_rpn_soft_obj_loss", _ptr(teacher), _ptr(x), k, c, float(tau), float(lam), int(efl),
+                  float(inv_norm), _ptr(loss), _ptr(dx), _ptr(fg), _ptr(_loss_ws(x.device)), _stream())
+        ctx.save_for_backward(dx)
+        ctx.mark_non_differentiable(fg)
+        return loss.reshape(()), fg
+
+    @staticmethod
+    def backward(ctx, g, _gfg):
+        (dx,) = ctx.saved_tensors
+        return None, dx * g, None, None, None, None
+
+
+def rpn_soft_obj_loss(teacher, x, tau, lam, efl, inv_norm):
+    return _RPNSoftObj.apply(teacher, x, tau, lam, efl, inv_norm)
+
+
+class _KLEFL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, mu_p, slog_p, fg, tau, lam, efl, reduction, inv_norm):
+        q = _chk(q.contiguous())
+        mu_p = _chk(mu_p.contiguous())
+        slog_p = _chk(slog_p.contiguous())
+        if fg is not None:
+            fg = _chk(fg.contiguous(), torch.uint8)
+        rows = q.shape[0]
+        loss = torch.empty(1, dtype=F32, device=q.device)
+        dq = torch.empty_like(q)
+        dmu = torch.empty_like(mu_p) if ctx.needs_input_grad[1] else None
+        _lib.call("ptmi_kl_efl_loss", _ptr(q), _ptr(mu_p), _ptr(slog_p), _ptr(fg), rows, float(tau), float(lam),
+                  int(efl), int(reduction), float(inv_norm), _ptr(loss), _ptr(dq), _ptr(dmu),
+                  _ptr(_loss_ws(q.device)), _stream())
+        ctx.has_dmu = dmu is not None
+        ctx.save_for_backward(dq, dmu) if dmu is not None else ctx.save_for_backward(dq)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.has_dmu:
+            dq, dmu = ctx.saved_tensors
+            return dq * g, dmu * g, None, None, None, None, None, None, None
+        (dq,) = ctx.saved_tensors
+        return dq * g, None, None, None, None, None, None, None, None
+
+
+def kl_efl_loss(q, mu_p, slog_p, fg, tau, lam, efl, reduction, inv_norm):
+    return _KLEFL.apply(q, mu_p, slog_p, fg, tau, lam, efl, reduction, inv_norm)
+
+
+# ============================================================================ optimiser / EMA / image prep
+def ema_update(student_flat: torch.Tensor, teacher_flat: torch.Tensor, keep_rate: float) -> None:
+    _lib.call("ptmi_ema_update", _ptr(_chk(student_flat)), _ptr(_chk(teacher_flat)), student_flat.numel(),
+              float(keep_rate), _stream())
+
+
+def sumsq(g_flat: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(1, dtype=F32, device=g_flat.device)
+    ws = _ws("sumsq", 1024 * 4, g_flat.device)
+    _lib.call("ptmi_sumsq", _ptr(_chk(g_flat)), g_flat.numel(), _ptr(out), _ptr(ws), _stream())
+    return out
+
+
+def clip_sgd_step(p, g, buf, sumsq_t, clip_norm, lr, momentum, weight_decay, first: bool) -> None:
+    _lib.call("ptmi_clip_sgd_step", _ptr(_chk(p)), _ptr(_chk(g)), _ptr(_chk(buf)), p.numel(), _ptr(sumsq_t),
+              float(clip_norm), float(lr), float(momentum), float(weight_decay), int(first), _stream())
+
+
+def scale_by_clip(g, sumsq_t, clip_norm) -> None:
+    _lib.call("ptmi_scale_by_clip", _ptr(_chk(g)), g.numel(), _ptr(sumsq_t), float(clip_norm), _stream())
+
+
+def preprocess_images(images_u8: List[torch.Tensor], mean: Sequence[float], std: Sequence[float]):
+    """D2 preprocess_image + ImageList.from_tensors: (x-mean)/std, zero pad to the batch max."""
+    hmax = max(im.shape[-2] for im in images_u8)
+    wmax = max(im.shape[-1] for im in images_u8)
+    dev = images_u8[0].device
+    out = torch.empty((len(images_u8), 3, hmax, wmax), dtype=F32, device=dev)
+    for i, im in enumerate(images_u8):
+        im = _chk(im.contiguous(), torch.uint8, "image")
+        _lib.call("ptmi_preprocess_image", _ptr(im), _ptr(out[i]), im.shape[-2], im.shape[-1], hmax, wmax,
+                  float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _stream())
+    return out
+
+
+def shrink_paste(img_u8: torch.Tensor, ratio: float, mean_int: Sequence[int]) -> Tuple[torch.Tensor, int, int]:
+    """trainer.py:557-590 image part; returns (canvas, x1, y1)."""
+    img_u8 = _chk(img_u8.contiguous(), torch.uint8, "image")
+    h, w = img_u8.shape[-2:]
+    dh, dw = int(h * ratio), int(w * ratio)
+    x1, y1 = int((w - dw) / 2), int((h - dh) / 2)
+    out = torch.empty_like(img_u8)
+    _lib.call("ptmi_shrink_paste", _ptr(img_u8), _ptr(out), h, w, dh, dw, y1, x1, int(mean_int[0]), int(mean_int[1]),
+              int(mean_int[2]), _stream())
+    return out, x1, y1
