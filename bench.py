@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- teacher+student train-step throughput (img/s) at 1333x800 on N x MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full PTrainer.run_step in the mutual-learning phase (BASELINE.json configs[2]): EMA teacher update,
+teacher forward on B unlabelled weak views, student supervised forward on 2B labelled views, student unsupervised
+forward on B strong views, ONE backward, gradient all-reduce (RCCL) for N>1, clip + SGD.  Per GPU B_label =
+B_unlabel = --per-gpu-batch (weak scaling: per-GPU work fixed).  img/s = N*(B_label+B_unlabel)/step_seconds
+(SURVEY.md 8d).  Synthetic uint8 images resident in HBM before the timed region, random-init weights, fp32.
+
+Prints ONE JSON line (rank 0) with `roofline` (MFMA conv kernel, HIP-event timed inside the timed region) and,
+at N=1, `cpu_baseline` (the CPU oracle on the host cores, bounded sample)."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synth_records(gen, n, h, w, K, dev, m=12, labelled=True):
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    recs = []
+    for _ in range(n):
+        img = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8).to(dev)
+        r = {"image": img, "height": h, "width": w}
+        if labelled:
+            bw = torch.exp(torch.rand(m, generator=gen) * (math.log(400) - math.log(32)) + math.log(32))
+            bh = torch.exp(torch.rand(m, generator=gen) * (math.log(400) - math.log(32)) + math.log(32))
+            cx, cy = torch.rand(m, generator=gen) * w, torch.rand(m, generator=gen) * h
+            b = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)
+            b[:, 0::2].clamp_(0, w)
+            b[:, 1::2].clamp_(0, h)
+            keep = ((b[:, 2] - b[:, 0]) > 4) & ((b[:, 3] - b[:, 1]) > 4)
+            inst = FreeInstances((h, w))
+            inst.gt_boxes = Boxes(b[keep].to(dev))
+            inst.gt_classes = torch.randint(0, K, (int(keep.sum()),), generator=gen).to(dev)
+            r["instances"] = inst
+        recs.append(r)
+    return recs
+
+
+def cpu_baseline(h, w, K, seed=0):
+    """The CPU oracle (oracle/pt.py, a port of the reference's algorithm on stock torch CPU fp32 ops) timed on this
+    box's host cores: ONE full mutual-learning step with 1 labelled + 1 unlabelled image (bounded sample)."""
+    from oracle import d2, pt as opt
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = opt.Cfg(num_classes=K, burn_up_step=0)
+    gen = torch.Generator().manual_seed(seed)
+    state = {"student": opt.init_params(cfg, 0), "teacher": opt.init_params(cfg, 0), "bufs": {}, "iter": 0}
+
+    def recs(labelled=True):
+        r = {"image": torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8), "height": h, "width": w}
+        inst = opt.FreeInstances((h, w))
+        b = torch.tensor([[100.0, 120.0, 400.0, 380.0], [600.0, 200.0, 900.0, 700.0], [50.0, 500.0, 300.0, 780.0]])
+        inst.gt_boxes = d2.Boxes(b)
+        inst.gt_classes = torch.tensor([0, 1, 2]) % K
+        r["instances"] = inst
+        return [r]
+    data = (recs(), recs(), recs(), recs())
+    t0 = time.perf_counter()
+    opt.run_step(cfg, state, data, {"label": [0.8], "unlabel": [0.7]}, perm_fn=opt.SeededPerm(1))
+    dt = time.perf_counter() - t0
+    return {"value": 2.0 / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full teacher+student step (EMA, teacher fwd, 3 student fwd, 3 bwd, clip+SGD) with 1 labelled + "
+                      f"1 unlabelled {w}x{h} image, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--per-gpu-batch", type=int, default=16, help="B_label = B_unlabel per GPU")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP extension is the only compute path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)          # RCCL over xGMI
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+
+    from probabilisticteacher_amd import ops
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+
+    B = args.per_gpu_batch
+    cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), [
+        "MODEL.DEVICE", f"cuda:{local_rank}", "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", 0,
+        "SOLVER.IMG_PER_BATCH_LABEL", B * world, "SOLVER.IMG_PER_BATCH_UNLABEL", B * world])
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    torch.manual_seed(0)                                                # identical init on all ranks
+    trainer = PTrainer(cfg)
+    gen = torch.Generator().manual_seed(1234 + rank * 1000)
+    H, W = args.height, args.width
+
+    def batch():
+        return (synth_records(gen, B, H, W, K, dev), synth_records(gen, B, H, W, K, dev),
+                synth_records(gen, B, H, W, K, dev), synth_records(gen, B, H, W, K, dev))
+    batches = [batch() for _ in range(2)]                               # resident in HBM before timing
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.run_step(batches[i % 2])
+    sync()
+    ops.profile_start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.run_step(batches[i % 2])
+    sync()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop()
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * 2 * B * args.steps / dt
+        conv = prof.get("conv3x3_mfma", {"ms": 0.0, "flops": 0.0, "calls": 0})
+        ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        out = {
+            "metric": "teacher-student train-step img/s at 1333x800", "value": value, "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: final_c2f.yaml (K=8) full teacher+student+EMA step, per-GPU "
+                                   f"{B} labelled + {B} unlabelled synthetic {W}x{H} images, BURN_UP_STEP=0, random init",
+                       "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "conv3x3_mfma_kernel (fwd + dgrad launches)", "calls": conv["calls"],
+                         "avg_launch_ms": conv["ms"] / max(conv["calls"], 1),
+                         "flops_per_launch_avg": conv["flops"] / max(conv["calls"], 1)},
+            "kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12)
+                            if v["ms"] > 0 and v["flops"] else None, "calls_per_step": v["calls"] / args.steps}
+                        for k, v in prof.items()},
+            "step_conv_tflops": 2.696 * 2 * B * world * args.steps / dt if (H, W) == (800, 1333) else None,
+            "losses": {k: v for k, v in trainer.last_metrics.items() if k.startswith("loss")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(H, W, K)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -193,7 +193,7 @@ int ptmi_get_deltas_bwd_src(const float* src, const float* tgt, const float* dde
 /* ------------------------------------------------------------------ optimiser / EMA (N15-N17)
  * flat fp32 buffers.  EMA: trainer.py:431-449  t = s*(1-k) + t*k  (that evaluation order). */
 int ptmi_ema_update(const float* student, float* teacher, int64_t n, float keep_rate,
-                    ptmi_stream_t s);
+                    float one_minus_keep_rate, ptmi_stream_t s);
 /* trainer.py:592-603 clip_gradient: sumsq_out[0] = sum g^2 (two-stage, deterministic). */
 int ptmi_sumsq(const float* g, int64_t n, float* sumsq_out, float* ws, ptmi_stream_t s);
 /* fused clip + SGD(momentum, weight decay) step (trainer.py:385-386; torch.optim.SGD semantics):

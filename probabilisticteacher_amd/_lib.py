@@ -47,7 +47,7 @@ SIGNATURES = {
     "ptmi_rpn_soft_obj_loss": (_i, [_vp, _vp, _i64, _i, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ptmi_kl_efl_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ptmi_get_deltas_bwd_src": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _vp]),
-    "ptmi_ema_update": (_i, [_vp, _vp, _i64, _f, _vp]),
+    "ptmi_ema_update": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
     "ptmi_sumsq": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "ptmi_clip_sgd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _i, _vp]),
     "ptmi_scale_by_clip": (_i, [_vp, _i64, _vp, _f, _vp]),

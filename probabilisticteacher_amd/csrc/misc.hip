@@ -237,12 +237,14 @@ int ptmi_shrink_paste(const uint8_t* img, uint8_t* out, int h, int w, int dh, in
     return 0;
 }
 
-int ptmi_ema_update(const float* student, float* teacher, int64_t n, float keep_rate, ptmi_stream_t s)
+int ptmi_ema_update(const float* student, float* teacher, int64_t n, float keep_rate, float one_minus_keep_rate,
+                    ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(student && teacher && n >= 0, "ema_update: bad args");
     if (n == 0) return 0;
-    // (1 - k) is formed in double then rounded, exactly as python `1 - keep_rate` feeds torch (trainer.py:443)
-    const float omk = (float)(1.0 - (double)keep_rate);
+    PTMI_CHECK_ARG(student && teacher && n > 0, "ema_update: bad args");
+    // (1 - k) is formed by the caller in double and rounded once, exactly as python's `1 - keep_rate`
+    // reaches torch at trainer.py:443; deriving it from the fp32 k here would differ in the last bits.
+    const float omk = one_minus_keep_rate;
     hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)s, student, teacher, n,
                        keep_rate, omk);
     PTMI_LAUNCH_CHECK("ema_update");

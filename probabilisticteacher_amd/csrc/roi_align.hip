@@ -113,9 +113,9 @@ extern "C" {
 int ptmi_roi_align_fwd(const float* feat, const float* rois, float* out, int n, int c, int h, int w, int r,
                        int pooled, float scale, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(feat && out && n > 0 && c > 0 && h > 0 && w > 0 && r >= 0 && pooled > 0, "roi_align_fwd: bad args");
     if (r == 0) return 0;
-    PTMI_CHECK_ARG(rois, "roi_align_fwd: rois missing");
+    PTMI_CHECK_ARG(feat && out && rois && n > 0 && c > 0 && h > 0 && w > 0 && r > 0 && pooled > 0,
+                   "roi_align_fwd: bad args");
     hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)s, feat, rois, out, c, h, w, pooled,
                        scale);
     PTMI_LAUNCH_CHECK("roi_align_fwd");
@@ -125,9 +125,9 @@ int ptmi_roi_align_fwd(const float* feat, const float* rois, float* out, int n, 
 int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n, int c, int h, int w, int r,
                        int pooled, float scale, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(dout && dfeat && n > 0 && c > 0 && h > 0 && w > 0 && r >= 0 && pooled > 0, "roi_align_bwd: bad args");
     if (r == 0) return 0;
-    PTMI_CHECK_ARG(rois, "roi_align_bwd: rois missing");
+    PTMI_CHECK_ARG(dout && dfeat && rois && n > 0 && c > 0 && h > 0 && w > 0 && r > 0 && pooled > 0,
+                   "roi_align_bwd: bad args");
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)s, dout, rois, dfeat, c, h, w, pooled,
                        scale);
     PTMI_LAUNCH_CHECK("roi_align_bwd");

@@ -1,0 +1,217 @@
+"""PTrainer: the teacher+student train step on MI355X (reference pt/engine/trainer.py).
+
+`run_step` follows trainer.py:263-392 call for call -- burn-in vs mutual learning, teacher pseudo-labelling
+without thresholding, shrink-and-paste `resize`, supervised + unsupervised student forwards, one backward,
+gradient clipping, SGD -- but every heavy piece is a HIP kernel and the per-tensor Python loops of the reference
+(EMA, clip, SGD, metrics `.item()`s) are single launches over flat buffers.  What the reference does only to burn
+time (anomaly mode, empty_cache, gc.collect, a third unused model copy) is not replicated."""
+import copy
+import random
+import time
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..modeling import EnsembleTSModel, build_model
+from ..structures import Boxes, FreeInstances
+from .flat import FlatParams, allreduce_mean_, broadcast_, lr_at
+
+
+class PTrainer:
+    def __init__(self, cfg, data_loader=None, ratio_fn: Optional[Callable[[], float]] = None):
+        self.cfg = cfg
+        self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.model = build_model(cfg)                  # student
+        self.model_teacher = build_model(cfg)          # teacher (per-rank replica, never all-reduced)
+        self.model.train()
+        self.model_teacher.train()                     # the reference never puts the teacher in eval mode (:302-303)
+        for p in self.model_teacher.parameters():
+            p.requires_grad_(False)
+        self.student = FlatParams(self.model)
+        # teacher must share the student's flat layout: order by the student's index
+        self.teacher = _flatten_like(self.model_teacher, self.student)
+        broadcast_(self.student.flat)                  # trainer.py:495 _sync_params_and_buffers
+        broadcast_(self.teacher.flat)
+        self.momentum_buf = torch.zeros_like(self.student.trainable())
+        self._first_step = True
+        self.ensem_ts_model = EnsembleTSModel(self.model_teacher, self.model)
+        self.iter = self.start_iter = 0
+        self.max_iter = cfg.SOLVER.MAX_ITER
+        self._data_iter = iter(data_loader) if data_loader is not None else None
+        self._ratio_fn = ratio_fn or (lambda: random.uniform(0.5, 1.0))
+        self.last_metrics: Dict[str, float] = {}
+        self._mean_int = [int(m) for m in cfg.MODEL.PIXEL_MEAN]     # pixel_mean.cpu().int() (trainer.py:569)
+
+    # ------------------------------------------------------------------ pseudo-labelling (trainer.py:179-257)
+    def threshold_bbox(self, inst, proposal_type="roih"):
+        new = FreeInstances(inst.image_size)
+        if proposal_type == "rpn":
+            new.gt_boxes = Boxes(inst.proposal_boxes.tensor)
+            new.objectness_logits = inst.objectness_logits
+            new.pseudo_boxes = Boxes(inst.proposal_boxes.tensor)
+        elif proposal_type == "roih":
+            new.pseudo_boxes = Boxes(inst.pred_boxes.tensor)
+            new.scores_logists = inst.scores_logists
+            if inst.has("boxes_sigma"):
+                new.boxes_sigma = inst.boxes_sigma
+        return new
+
+    def process_pseudo_label(self, proposals, proposal_type, psedo_label_method=""):
+        if psedo_label_method != "all":
+            raise ValueError("Unkown pseudo label boxes methods")
+        out = [self.threshold_bbox(p, proposal_type) for p in proposals]
+        n = sum(len(p) for p in out) / max(len(out), 1)
+        return out, n
+
+    @staticmethod
+    def remove_label(data):
+        for d in data:
+            d.pop("instances", None)
+        return data
+
+    @staticmethod
+    def add_label(data, labels):
+        for d, lab in zip(data, labels):
+            d["instances"] = lab
+        return data
+
+    # ------------------------------------------------------------------ resize (trainer.py:557-590)
+    def resize(self, data: List[dict]) -> List[dict]:
+        out = []
+        dev = self.model.device
+        for rec in data:
+            img = rec["image"].to(dev, non_blocking=True)
+            ratio = self._ratio_fn()
+            canvas, x1, y1 = ops.shrink_paste(img, ratio, self._mean_int)
+            new = dict(rec)
+            new["image"] = canvas
+            inst = rec["instances"]
+            ni = FreeInstances(inst.image_size)
+            for k, v in inst.get_fields().items():
+                if k in ("gt_boxes", "pseudo_boxes"):
+                    t = v.tensor.to(dev).clone()
+                    t *= ratio
+                    t[:, 0] += x1
+                    t[:, 2] += x1
+                    t[:, 1] += y1
+                    t[:, 3] += y1
+                    ni.set(k, Boxes(t))
+                else:
+                    ni.set(k, v)
+            new["instances"] = ni
+            out.append(new)
+        return out
+
+    # ------------------------------------------------------------------ EMA / optimiser
+    @torch.no_grad()
+    def _update_teacher_model(self, keep_rate=0.996):
+        """trainer.py:431-449 as ONE launch over the flat buffers: t = s*(1-k) + t*k."""
+        ops.ema_update(self.student.flat, self.teacher.flat, keep_rate)
+
+    @torch.no_grad()
+    def _clip_and_step(self, clip_norm: float):
+        """trainer.py:385-386: clip_gradient(model, 10.) + optimizer.step() fused: one reduction + one update."""
+        g = self.student.grad
+        ss = ops.sumsq(g)
+        ops.clip_sgd_step(self.student.trainable(), g, self.momentum_buf, ss, clip_norm, lr_at(self.cfg, self.iter),
+                          self.cfg.SOLVER.MOMENTUM, self.cfg.SOLVER.WEIGHT_DECAY, self._first_step)
+        self._first_step = False
+        return ss
+
+    # ------------------------------------------------------------------ the step (trainer.py:263-392)
+    def run_step(self, data=None) -> Dict[str, float]:
+        assert self.model.training, "[PTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        if data is None:
+            data = next(self._data_iter)
+        label_data_q, label_data_k, unlabel_data_q, unlabel_data_k = [list(d) for d in data]
+        data_time = time.perf_counter() - start
+        U = self.cfg.UNSUPNET
+        self.student.zero_grad()
+
+        if self.iter < U.BURN_UP_STEP:
+            batch = self.resize(label_data_q + label_data_k)
+            record_dict, _, _, _ = self.model(batch, branch="supervised")
+            losses = sum(v * 1.0 for k, v in record_dict.items() if k[:4] == "loss")
+        else:
+            if self.iter == U.BURN_UP_STEP:
+                self._update_teacher_model(keep_rate=0.00)
+            elif (self.iter - U.BURN_UP_STEP) % U.TEACHER_UPDATE_ITER == 0:
+                self._update_teacher_model(keep_rate=U.EMA_KEEP_RATE)
+            with torch.no_grad():
+                _, _, proposals_roih_unsup_k, _ = self.model_teacher(unlabel_data_k, branch="unsup_data_weak")
+            pseudo, _ = self.process_pseudo_label(proposals_roih_unsup_k, "roih", "all")
+            self.last_pseudo = pseudo
+            if getattr(self, "pseudo_override", None) is not None:     # test hook, see tests/test_model_gpu.py
+                pseudo = self.pseudo_override
+            unlabel_data_q = self.add_label(self.remove_label([dict(d) for d in unlabel_data_q]), pseudo)
+            unlabel_data_q = self.resize(unlabel_data_q)
+            label_data_q = self.resize(label_data_q)
+            record_dict = {}
+            rec_sup, _, _, _ = self.model(label_data_q + label_data_k, branch="supervised")
+            record_dict.update({k + "_sup": v for k, v in rec_sup.items()})
+            rec_unsup, _, _, _ = self.model(unlabel_data_q, branch="unsupervised", danchor=True)
+            record_dict.update({k + "_unsup": v for k, v in rec_unsup.items()})
+            losses = 0
+            for k, v in record_dict.items():
+                if k[:4] != "loss":
+                    continue
+                tail = k.split("_")[-1]
+                if tail == "sup":
+                    losses = losses + v * U.SOURCE_LOSS_WEIGHT
+                elif tail == "unsup":
+                    losses = losses + v * U.TARGET_UNSUP_LOSS_WEIGHT
+                else:
+                    raise NotImplementedError
+
+        losses.backward()
+        allreduce_mean_(self.student.grad, self.world_size)            # DDP gradient average
+        ss = self._clip_and_step(10.0)
+        self._write_metrics(record_dict, data_time, ss)
+        self.iter += 1
+        return self.last_metrics
+
+    def _write_metrics(self, record_dict, data_time, sumsq):
+        """trainer.py:394-429 with ONE device->host copy: all loss scalars packed into a single tensor (the
+        reference does ~10 `.cpu().item()` syncs and a pickled gloo gather)."""
+        keys = list(record_dict.keys())
+        packed = torch.stack([record_dict[k].detach().float() for k in keys] + [sumsq.reshape(())])
+        if self.world_size > 1:
+            red = packed.clone()
+            red[-1] = 0
+            dist.all_reduce(red)
+            packed[:-1] = red[:-1] / self.world_size
+        vals = packed.cpu().tolist()
+        m = dict(zip(keys, vals[:-1]))
+        m["total_loss"] = sum(v for k, v in m.items() if k[:4] == "loss")
+        m["grad_norm"] = vals[-1] ** 0.5
+        m["data_time"] = data_time
+        self.last_metrics = m
+
+    def train(self, start_iter=0, max_iter=None):
+        self.iter = self.start_iter = start_iter
+        for _ in range(start_iter, max_iter or self.max_iter):
+            self.run_step()
+
+    def state_dict(self):
+        return {"model": self.ensem_ts_model.state_dict(), "momentum": self.momentum_buf, "iteration": self.iter}
+
+
+def _flatten_like(model, ref: FlatParams) -> FlatParams:
+    """Flatten `model` with exactly the layout of `ref` (so student/teacher buffers line up element for element)."""
+    named = dict(model.named_parameters())
+    fp = FlatParams.__new__(FlatParams)
+    fp.flat = torch.empty_like(ref.flat)
+    fp.index = ref.index
+    fp.n_trainable = ref.n_trainable
+    fp.params = {}
+    fp.grad = None
+    for n, (off, k) in ref.index.items():
+        p = named[n]
+        view = fp.flat[off:off + k].view(p.shape)
+        view.copy_(p.data)
+        p.data = view
+        fp.params[n] = p
+    return fp

@@ -1,0 +1,87 @@
+"""Meta-architecture: three-branch Gaussian Faster R-CNN (reference pt/modeling/meta_arch/rcnn.py:30-92) and the
+teacher/student holder (pt/modeling/meta_arch/ts_ensemble.py:20-29)."""
+from typing import List
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..registry import META_ARCH_REGISTRY
+from ..structures import ImageList
+from .backbone import build_backbone
+from .roi_heads import build_roi_heads
+from .rpn import build_proposal_generator
+
+
+@META_ARCH_REGISTRY.register()
+class GuassianGeneralizedRCNN(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.backbone = build_backbone(cfg)
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.roi_heads = build_roi_heads(cfg, self.backbone.output_shape())
+        self.input_format = cfg.INPUT.FORMAT
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
+        self._mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self._std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs: List[dict]) -> ImageList:
+        """D2 GeneralizedRCNN.preprocess_image: normalise, then zero-pad to the batch max."""
+        imgs = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
+        sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in imgs]
+        return ImageList(ops.preprocess_images(imgs, self._mean, self._std), sizes)
+
+    def forward(self, batched_inputs, branch="supervised", danchor=False):
+        if not self.training:
+            raise NotImplementedError("eval-mode inference is outside the train-step hot path (SURVEY.md 8f-2)")
+        images = self.preprocess_image(batched_inputs)
+        gt_instances = None
+        if "instances" in batched_inputs[0]:
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        features = self.backbone(images.tensor)
+
+        if branch == "supervised":
+            proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt_instances)
+            _, detector_losses = self.roi_heads(images, features, proposals_rpn, gt_instances, branch=branch)
+            losses = {}
+            losses.update(detector_losses)
+            losses.update(proposal_losses)
+            return losses, [], [], None
+        if branch == "unsup_data_weak":
+            proposals_rpn, _ = self.proposal_generator(images, features, None, compute_loss=False)
+            proposals_roih, roi_predictions = self.roi_heads(images, features, proposals_rpn, targets=None,
+                                                             compute_loss=False, branch=branch)
+            return {}, proposals_rpn, proposals_roih, roi_predictions
+        if branch == "unsupervised":
+            proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt_instances, branch=branch,
+                                                                     danchor=danchor)
+            _, detector_losses = self.roi_heads(images, features, proposals_rpn, gt_instances, branch=branch)
+            losses = {}
+            losses.update(detector_losses)
+            losses.update(proposal_losses)
+            return losses, [], [], None
+        raise ValueError(f"unknown branch {branch!r}")
+
+
+class EnsembleTSModel(nn.Module):
+    """Holder that fixes the checkpoint prefixes `modelTeacher.` / `modelStudent.` (ts_ensemble.py:20-29)."""
+
+    def __init__(self, modelTeacher, modelStudent):
+        super().__init__()
+        if isinstance(modelTeacher, nn.parallel.DistributedDataParallel):
+            modelTeacher = modelTeacher.module
+        if isinstance(modelStudent, nn.parallel.DistributedDataParallel):
+            modelStudent = modelStudent.module
+        self.modelTeacher = modelTeacher
+        self.modelStudent = modelStudent
+
+
+def build_model(cfg):
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model

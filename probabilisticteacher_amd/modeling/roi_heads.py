@@ -1,0 +1,284 @@
+"""Gaussian ROI head on HIP kernels (reference pt/modeling/roi_heads/{roi_heads.py,fast_rcnn.py}).
+
+ROIAlign, the FC box head (fp32 MFMA GEMMs with fused bias/ReLU), IoU matching, box codec, per-class NMS and all
+losses (+gradients) are HIP kernels; torch gathers rows by index and carries the per-image containers.
+Quirks kept: bbox_pred emits 8 numbers per class always; apply_deltas decodes the sigma
+quadruples as boxes and they are dropped (fast_rcnn.py:63); teacher scores are multiplied by 1-mean(sigmoid(sigma))
+(:101); per-class NMS uses torchvision's fp32 `boxes + cls*(max+1)` offset; unsup cls loss divides by R (NaN if 0)."""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
+from ..structures import Boxes, FreeInstances
+from .box_regression import Box2BoxTransform
+from .sampling import subsample_labels
+
+GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))     # proposal_utils.py:207
+
+
+class _LinearP(nn.Module):
+    def __init__(self, nin, nout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(nout, nin))
+        self.bias = nn.Parameter(torch.zeros(nout))
+
+
+class ROIPooler(nn.Module):
+    """Single-level ROIAlignV2 pooler (D2 ROIPooler; constructed at roi_heads.py:68-73)."""
+
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type):
+        super().__init__()
+        assert pooler_type == "ROIAlignV2" and sampling_ratio == 0 and len(scales) == 1
+        self.output_size, self.scale = int(output_size), float(scales[0])
+
+    def forward(self, x: List[torch.Tensor], box_lists: List[Boxes]) -> torch.Tensor:
+        dev = x[0].device
+        rows = [torch.cat([torch.full((len(b), 1), float(i), device=dev), b.tensor], 1) for i, b in enumerate(box_lists)]
+        rois = torch.cat(rows, 0) if rows else torch.zeros((0, 5), device=dev)
+        return ops.roi_align(x[0], rois.contiguous(), self.output_size, self.scale)
+
+
+@ROI_BOX_HEAD_REGISTRY.register()
+class FastRCNNConvFCHead(nn.Module):
+    """flatten -> fc1 + ReLU -> fc2 + ReLU (D2 FastRCNNConvFCHead), c2_xavier_fill init."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        H = cfg.MODEL.ROI_BOX_HEAD
+        assert H.NUM_CONV == 0, "conv layers in the box head are not on the hot path"
+        dim = input_shape.channels * input_shape.height * input_shape.width
+        self.num_fc = H.NUM_FC
+        for k in range(H.NUM_FC):
+            fc = _LinearP(dim, H.FC_DIM)
+            nn.init.kaiming_uniform_(fc.weight, a=1)
+            setattr(self, f"fc{k + 1}", fc)
+            dim = H.FC_DIM
+        self.output_size = dim
+
+    def forward(self, x):
+        x = x.flatten(1)
+        for k in range(self.num_fc):
+            fc = getattr(self, f"fc{k + 1}")
+            x = ops.linear(x, fc.weight, fc.bias, True)
+        return x
+
+
+def build_box_head(cfg, input_shape):
+    return ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, input_shape)
+
+
+class GuassianFastRCNNOutputLayers(nn.Module):
+    """cls_score (K+1) and bbox_pred (8K) + Gaussian / entropy-focal losses + teacher inference
+    (fast_rcnn.py:145-409)."""
+
+    def __init__(self, cfg, input_size: int):
+        super().__init__()
+        self.cfg = cfg
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        assert not cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG
+        self.model_type = cfg.UNSUPNET.MODEL_TYPE
+        self.box2box_transform = Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS)
+        self.cls_score = _LinearP(input_size, self.num_classes + 1)
+        self.bbox_pred = _LinearP(input_size, self.num_classes * 8)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        self.test_score_thresh = cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST
+        self.test_nms_thresh = cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST
+        self.test_topk_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        self.loss_weight = {"loss_cls": 1.0, "loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT}
+
+    def forward(self, x):
+        return (ops.linear(x, self.cls_score.weight, self.cls_score.bias, False),
+                ops.linear(x, self.bbox_pred.weight, self.bbox_pred.bias, False))
+
+    # ---- supervised (D2 FastRCNNOutputLayers.losses + fast_rcnn.py:265-336)
+    def losses(self, predictions, proposals: List[FreeInstances]):
+        scores, deltas = predictions
+        K = self.num_classes
+        gt_classes = torch.cat([p.gt_classes for p in proposals], 0)
+        pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
+        gb = torch.cat([p.gt_boxes.tensor for p in proposals], 0)
+        loss_cls = ops.softmax_ce_mean(scores, gt_classes)
+        fg = torch.nonzero((gt_classes >= 0) & (gt_classes < K)).squeeze(1)
+        d = deltas.view(-1, K, 8)[fg, gt_classes[fg]]
+        tgt = self.box2box_transform.get_deltas(pb[fg], gb[fg])
+        loss_box = ops.gaussian_nll_sum(d, tgt, 1.0 / max(gt_classes.numel(), 1.0))
+        out = {"loss_cls": loss_cls, "loss_box_reg": loss_box}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in out.items()}
+
+    # ---- unsupervised (roi_heads.py:130-171 + fast_rcnn.py:179-263)
+    def losses_unsupervised(self, predictions, proposals: List[FreeInstances]):
+        scores, deltas = predictions
+        K, U = self.num_classes, self.cfg.UNSUPNET
+        T = torch.cat([p.soft_label for p in proposals]).detach().contiguous()
+        r = T.shape[0]
+        inv = 1.0 / r if r > 0 else float("nan")                      # fast_rcnn.py:209 divides by R
+        out = {"loss_cls": ops.soft_ce_efl(T, scores, U.TAU[0], U.EFL_LAMBDA[0], bool(U.EFL), inv)}
+        if proposals[0].has("boxes_sigma"):
+            with torch.no_grad():
+                sig_p = torch.cat([p.boxes_sigma for p in proposals])
+                pb = torch.cat([p.proposal_boxes.tensor for p in proposals])
+                psb = torch.cat([p.pseudo_boxes.tensor for p in proposals])
+                cls = T.max(-1)[1] if r > 0 else torch.zeros(0, dtype=torch.int64, device=T.device)
+                rows = torch.nonzero(cls != K).squeeze(1)
+                mu_p = self.box2box_transform.get_deltas(pb[rows], psb[rows])
+                sig_sel = sig_p[rows].contiguous()
+            q = deltas.view(-1, K, 8)[rows, cls[rows]]                 # one gather instead of the per-row loop (:159-161)
+            out["loss_box_reg"] = ops.kl_efl_loss(q, mu_p, sig_sel, None, U.TAU[1], U.EFL_LAMBDA[1], bool(U.EFL), 1, 1.0)
+        return out
+
+    # ---- teacher inference (fast_rcnn.py:338-409, :34-141)
+    @torch.no_grad()
+    def inference(self, predictions, proposals: List[FreeInstances]):
+        scores, deltas = predictions
+        K = self.num_classes
+        dev = scores.device
+        counts = [len(p) for p in proposals]
+        pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
+        dec = self.box2box_transform.apply_deltas(deltas, pb)          # (R, 8K): 2K boxes per ROI
+        probs = ops.softmax_rows(scores)
+        cand_boxes, cand_scores, cand_nms_boxes, cand_meta = [], [], [], []
+        for boxes, sc, logit, sg, prop in zip(dec.split(counts), probs.split(counts), scores.split(counts),
+                                              deltas.split(counts), proposals):
+            r = boxes.shape[0]
+            boxes = boxes.view(r, K, 8)[..., :4]
+            bsig = sg.view(r, K, 8)[..., 4:]
+            valid = torch.isfinite(boxes).all(dim=2).all(dim=1) & torch.isfinite(sc).all(dim=1)
+            if not bool(valid.all()):
+                boxes, sc, bsig = boxes[valid], sc[valid], bsig[valid]
+            h, w = prop.image_size
+            boxes = torch.stack((boxes[..., 0].clamp(min=0, max=w), boxes[..., 1].clamp(min=0, max=h),
+                                 boxes[..., 2].clamp(min=0, max=w), boxes[..., 3].clamp(min=0, max=h)), dim=-1)
+            sc = sc[:, :-1]
+            fm = sc > self.test_score_thresh
+            finds = fm.nonzero()
+            boxes, bsig, sc = boxes[fm], bsig[fm], sc[fm]
+            sc = sc * (1 - torch.sigmoid(bsig).sum(-1) / 4.0)
+            if boxes.numel():
+                offs = finds[:, 1].to(boxes) * (boxes.max() + torch.tensor(1.0, device=dev))
+                nb = boxes + offs[:, None]
+            else:
+                nb = boxes
+            cand_boxes.append(boxes)
+            cand_scores.append(sc)
+            cand_nms_boxes.append(nb)
+            cand_meta.append((finds, logit, bsig))
+        ccounts = [len(s) for s in cand_scores]
+        offs = [0]
+        for c in ccounts:
+            offs.append(offs[-1] + c)
+        seg = torch.tensor(offs, dtype=torch.int32, device=dev)
+        all_sc = torch.cat(cand_scores)
+        _, order = ops.segsort_desc(all_sc.contiguous(), seg)
+        base = torch.repeat_interleave(seg[:-1].long(), torch.tensor(ccounts, device=dev))
+        gorder = base + order.long()
+        sorted_nb = torch.cat(cand_nms_boxes)[gorder]
+        topk = self.test_topk_per_image if self.test_topk_per_image >= 0 else max(max(ccounts), 1)
+        keep, kcnt = ops.nms_batched(sorted_nb, seg, max(ccounts) if ccounts else 0, float(self.test_nms_thresh),
+                                     int(max(topk, 1)))
+        kc = kcnt.cpu().tolist()
+        results, kept_rows = [], []
+        for i, prop in enumerate(proposals):
+            finds, logit, bsig = cand_meta[i]
+            sel = gorder[keep[i, :kc[i]].long() + offs[i]] - offs[i]    # indices into this image's candidates
+            res = FreeInstances(prop.image_size)
+            res.pred_boxes = Boxes(cand_boxes[i][sel])
+            res.scores = cand_scores[i][sel]
+            res.pred_classes = finds[sel][:, 1]
+            res.scores_logists = logit[finds[sel][:, 0]]
+            res.boxes_sigma = bsig[sel]
+            results.append(res)
+            kept_rows.append(finds[sel][:, 0])
+        return results, kept_rows
+
+
+@ROI_HEADS_REGISTRY.register()
+class GuassianROIHead(nn.Module):
+    def __init__(self, cfg, input_shape: Dict):
+        super().__init__()
+        self.cfg = cfg
+        H = cfg.MODEL.ROI_HEADS
+        self.num_classes = H.NUM_CLASSES
+        self.batch_size_per_image = H.BATCH_SIZE_PER_IMAGE
+        self.positive_fraction = H.POSITIVE_FRACTION
+        self.proposal_append_gt = H.PROPOSAL_APPEND_GT
+        self.iou_thresholds, self.iou_labels = list(H.IOU_THRESHOLDS), list(H.IOU_LABELS)
+        self.box_in_features = H.IN_FEATURES
+        B = cfg.MODEL.ROI_BOX_HEAD
+        in_channels = input_shape[self.box_in_features[0]].channels
+        scales = tuple(1.0 / input_shape[k].stride for k in self.box_in_features)
+        self.box_pooler = ROIPooler(B.POOLER_RESOLUTION, scales, B.POOLER_SAMPLING_RATIO, B.POOLER_TYPE)
+        from .backbone import ShapeSpec
+        self.box_head = build_box_head(cfg, ShapeSpec(channels=in_channels, height=B.POOLER_RESOLUTION,
+                                                      width=B.POOLER_RESOLUTION))
+        self.box_predictor = GuassianFastRCNNOutputLayers(cfg, self.box_head.output_size)
+        self.train_on_pred_boxes = B.TRAIN_ON_PRED_BOXES
+
+    def forward(self, images, features, proposals, targets=None, compute_loss=True, branch=""):
+        if self.training and compute_loss:
+            assert targets
+            proposals = self.label_and_sample_proposals(proposals, targets, branch=branch)
+        feats = [features[f] for f in self.box_in_features]
+        box_features = self.box_pooler(feats, [x.proposal_boxes for x in proposals])
+        predictions = self.box_predictor(self.box_head(box_features))
+        del box_features
+        if branch == "unsupervised" and self.training:
+            return proposals, self.box_predictor.losses_unsupervised(predictions, proposals)
+        if self.training and compute_loss:
+            return proposals, self.box_predictor.losses(predictions, proposals)
+        pred_instances, _ = self.box_predictor.inference(predictions, proposals)
+        return pred_instances, predictions
+
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, targets, branch=""):
+        """roi_heads.py:192-255 (+ proposal_utils.py:157-224 GT append, D2 _sample_proposals A.12) and
+        roi_heads.py:257-291 for the unsupervised branch."""
+        K = self.num_classes
+        out = []
+        for prop, tgt in zip(proposals, targets):
+            if branch == "unsupervised":
+                pb = tgt.pseudo_boxes.tensor
+                midx, mlab, _ = ops.iou_match(pb, prop.proposal_boxes.tensor, self.iou_thresholds, self.iou_labels, False)
+                sel = torch.nonzero(mlab == 1).squeeze(1)
+                r = FreeInstances(prop.image_size)
+                r.proposal_boxes = Boxes(prop.proposal_boxes.tensor[sel])
+                if pb.shape[0] == 0:
+                    r.pseudo_boxes, r.soft_label = tgt.pseudo_boxes, tgt.scores_logists
+                    if tgt.has("boxes_sigma"):
+                        r.boxes_sigma = tgt.boxes_sigma
+                else:
+                    m = midx[sel]
+                    r.pseudo_boxes, r.soft_label = Boxes(pb[m]), tgt.scores_logists[m]
+                    if tgt.has("boxes_sigma"):
+                        r.boxes_sigma = tgt.boxes_sigma[m]
+                out.append(r)
+                continue
+            gtb = tgt.gt_boxes.tensor
+            boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
+            if self.proposal_append_gt:
+                boxes = torch.cat([boxes, gtb], 0)
+                logits = torch.cat([logits, GT_LOGIT * torch.ones(len(gtb), device=boxes.device)], 0)
+            midx, mlab, _ = ops.iou_match(gtb, boxes.contiguous(), self.iou_thresholds, self.iou_labels, False)
+            if tgt.gt_classes.numel() > 0:
+                cls = tgt.gt_classes[midx]
+                cls[mlab == 0] = K
+                cls[mlab == -1] = -1
+            else:
+                cls = torch.zeros_like(midx) + K
+            fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, K)
+            sel = torch.cat([fg, bg], 0)
+            r = FreeInstances(prop.image_size)
+            r.proposal_boxes = Boxes(boxes[sel])
+            r.objectness_logits = logits[sel]
+            r.gt_classes = cls[sel]
+            r.gt_boxes = Boxes(gtb[midx[sel]]) if len(gtb) > 0 else Boxes(gtb.new_zeros((len(sel), 4)))
+            out.append(r)
+        return out
+
+
+def build_roi_heads(cfg, input_shape):
+    return ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, input_shape)

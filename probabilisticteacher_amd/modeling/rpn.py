@@ -1,0 +1,214 @@
+"""Gaussian RPN on HIP kernels (reference pt/modeling/proposal_generator/{rpn.py,proposal_utils.py}).
+
+What runs where: the 3x3/1x1 head convs (MFMA), anchor grid, IoU + Matcher, box codec, segmented sorts,
+proposal clipping/rescoring, NMS and every loss (+ its gradient) are HIP kernels from libptmi355.so; torch
+only gathers/scatters rows by index (autograd glue) and carries per-image Python containers.
+
+Reference quirks kept on purpose: 8-dim (mu, sigma-logit) deltas always; sigma rows of the
+top-k proposals taken from the FIRST k anchors in raster order (proposal_utils.py:94); rescoring multiplies raw
+logits (:136-138); RPN soft-label loss uses sigmoid(1-x) (rpn.py:299) and only positive anchors; the box target
+mean_p is NOT detached in the RPN (rpn.py:315) so the learnable anchors receive gradient when danchor=True."""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..registry import PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
+from ..structures import Boxes, FreeInstances
+from .anchor_generator import build_anchor_generator
+from .box_regression import Box2BoxTransform
+from .sampling import subsample_labels
+
+
+class _ConvP(nn.Module):
+    def __init__(self, cout, cin, k, std=0.01):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.normal_(self.weight, std=std)
+
+
+@RPN_HEAD_REGISTRY.register()
+class GuassianRPNHead(nn.Module):
+    """StandardRPNHead with box_dim doubled (rpn.py:44-55): conv3x3+ReLU, 1x1 -> A logits, 1x1 -> A*8 deltas."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        in_channels = input_shape[0].channels
+        ag = build_anchor_generator(cfg, input_shape)
+        num_anchors, box_dim = ag.num_anchors[0], ag.box_dim * 2
+        self.conv = _ConvP(in_channels, in_channels, 3)
+        self.objectness_logits = _ConvP(num_anchors, in_channels, 1)
+        self.anchor_deltas = _ConvP(num_anchors * box_dim, in_channels, 1)
+
+    def forward(self, features: List[torch.Tensor]):
+        obj, deltas = [], []
+        for x in features:
+            t = ops.conv3x3(x, self.conv.weight, self.conv.bias, True)
+            obj.append(ops.conv1x1(t, self.objectness_logits.weight, self.objectness_logits.bias))
+            deltas.append(ops.conv1x1(t, self.anchor_deltas.weight, self.anchor_deltas.bias))
+        return obj, deltas
+
+
+def build_rpn_head(cfg, input_shape):
+    return RPN_HEAD_REGISTRY.get(cfg.MODEL.RPN.HEAD_NAME)(cfg, input_shape)
+
+
+def find_top_rpn_proposals(decoded, logits, sigma_logits, image_sizes, nms_thresh, pre_nms_topk, post_nms_topk,
+                           min_box_size, training) -> List[FreeInstances]:
+    """proposal_utils.py:27-154 for one feature level, batched over images on the device:
+    segmented sort -> clip / nonempty / sigma-rescoring kernel -> compaction -> segmented sort of the rescored
+    scores -> batched bitmask NMS.  Two small device->host reads (counts) per call."""
+    n, r = logits.shape
+    dev = logits.device
+    k = min(r, pre_nms_topk)
+    seg = torch.arange(0, (n + 1) * r, r, dtype=torch.int32, device=dev)
+    srt, idx = ops.segsort_desc(logits.reshape(-1), seg)
+    sizes = torch.tensor([[float(h), float(w)] for h, w in image_sizes], dtype=torch.float32, device=dev)
+    boxes, scores, valid, nonfinite = ops.rpn_prepare(decoded, srt.view(n, r), idx.view(n, r), sigma_logits, sizes,
+                                                      k, float(min_box_size))
+    valid_b = valid.bool()
+    counts_dev = valid_b.sum(dim=1)
+    host = torch.cat([counts_dev, nonfinite.long()]).cpu()           # one sync
+    counts, bad = host[:n].tolist(), host[n:].tolist()
+    if any(bad) and training:
+        raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
+    flat = valid_b.view(-1)
+    vb = boxes.view(-1, 4)[flat]
+    vs = scores.view(-1)[flat]
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    seg2 = torch.tensor(offs, dtype=torch.int32, device=dev)
+    s2, i2 = ops.segsort_desc(vs, seg2)
+    base = torch.repeat_interleave(seg2[:-1].long(), torch.tensor(counts, device=dev))
+    sb = vb[base + i2.long()]
+    max_count = max(counts) if counts else 0
+    keep, kcnt = ops.nms_batched(sb, seg2, max_count, float(nms_thresh), int(post_nms_topk))
+    kc = kcnt.cpu().tolist()                                          # second sync
+    results = []
+    for i, size in enumerate(image_sizes):
+        sel = keep[i, :kc[i]].long() + offs[i]
+        res = FreeInstances(size)
+        res.proposal_boxes = Boxes(sb[sel])
+        res.objectness_logits = s2[sel]
+        results.append(res)
+    return results
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class GuassianRPN(nn.Module):
+    def __init__(self, cfg, input_shape: Dict):
+        super().__init__()
+        R = cfg.MODEL.RPN
+        self.cfg = cfg
+        self.in_features = R.IN_FEATURES
+        shapes = [input_shape[f] for f in self.in_features]
+        self.anchor_generator = build_anchor_generator(cfg, shapes)
+        self.rpn_head = build_rpn_head(cfg, shapes)
+        self.box2box_transform = Box2BoxTransform(weights=R.BBOX_REG_WEIGHTS)
+        self.iou_thresholds, self.iou_labels = list(R.IOU_THRESHOLDS), list(R.IOU_LABELS)
+        self.batch_size_per_image = R.BATCH_SIZE_PER_IMAGE
+        self.positive_fraction = R.POSITIVE_FRACTION
+        self.pre_nms_topk = {True: R.PRE_NMS_TOPK_TRAIN, False: R.PRE_NMS_TOPK_TEST}
+        self.post_nms_topk = {True: R.POST_NMS_TOPK_TRAIN, False: R.POST_NMS_TOPK_TEST}
+        self.nms_thresh = R.NMS_THRESH
+        self.min_box_size = float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
+        self.anchor_boundary_thresh = R.BOUNDARY_THRESH
+        self.loss_weight = {"loss_rpn_cls": R.LOSS_WEIGHT, "loss_rpn_loc": R.BBOX_REG_LOSS_WEIGHT * R.LOSS_WEIGHT}
+
+    # ------------------------------------------------------------------ forward (rpn.py:80-154)
+    def forward(self, images, features, gt_instances: Optional[List[FreeInstances]] = None, compute_loss=True,
+                branch="", danchor=False):
+        feats = [features[f] for f in self.in_features]
+        assert len(feats) == 1, "single-level RPN (vgg_block5)"
+        anchors = self.anchor_generator(feats)[0].tensor
+        if not danchor:
+            anchors = anchors.detach()      # grad_zero (rpn.py:91-94): the anchor table gets an all-zero gradient
+        obj, deltas = self.rpn_head(feats)
+        n, a, h, w = obj[0].shape
+        # (N,A,H,W) -> (N,H*W*A);  (N,A*8,H,W) -> (N,H*W*A,8)   (rpn.py:97-113)
+        logits = obj[0].permute(0, 2, 3, 1).reshape(n, -1)
+        d8 = deltas[0].view(n, a, 8, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 8)
+
+        if branch == "unsupervised":
+            losses = self._losses_unsup(anchors, logits, d8, gt_instances)
+        elif self.training and compute_loss:
+            losses = self._losses_sup(anchors, logits, d8, gt_instances)
+            losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+        else:
+            losses = {}
+        proposals = self.predict_proposals(anchors, logits, d8, images.image_sizes)
+        return proposals, losses
+
+    @torch.no_grad()
+    def predict_proposals(self, anchors, logits, d8, image_sizes):
+        n, r = logits.shape
+        dd = d8.detach().contiguous()
+        decoded = ops.apply_deltas(dd.view(n * r, 8), anchors.detach(), self.box2box_transform.weights,
+                                   self.box2box_transform.scale_clamp, k=1, dstride=8).view(n, r, 4)
+        sigma = dd[..., 4:].contiguous()
+        return find_top_rpn_proposals(decoded, logits.detach().contiguous(), sigma, image_sizes, self.nms_thresh,
+                                      self.pre_nms_topk[self.training], self.post_nms_topk[self.training],
+                                      self.min_box_size, self.training)
+
+    # ------------------------------------------------------------------ supervised (rpn.py:191-255, 363-448)
+    def _losses_sup(self, anchors, logits, d8, gt_instances):
+        n, r = logits.shape
+        anc = anchors.detach()
+        labels, matched = [], []
+        with torch.no_grad():
+            for inst in gt_instances:
+                gt = inst.gt_boxes.tensor
+                midx, lab, _ = ops.iou_match(gt, anc, self.iou_thresholds, self.iou_labels, True)
+                pos, neg = subsample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0)
+                lab.fill_(-1)
+                lab[pos] = 1
+                lab[neg] = 0
+                labels.append(lab)
+                matched.append(torch.zeros_like(anc) if len(gt) == 0 else gt[midx])
+            lab_all = torch.stack(labels)                              # (N,R) int8
+            flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
+            gt_rows = torch.stack(matched).view(-1, 4)[flat_pos]
+        inv = 1.0 / (self.batch_size_per_image * n)
+        loss_cls = ops.bce_logits_sum(logits.contiguous(), lab_all, inv)
+        d_rows = d8.reshape(-1, 8)[flat_pos]
+        a_rows = anchors[flat_pos % r]
+        tgt = self.box2box_transform.get_deltas(a_rows, gt_rows)
+        loss_loc = ops.gaussian_nll_sum(d_rows, tgt, inv)
+        return {"loss_rpn_cls": loss_cls, "loss_rpn_loc": loss_loc}
+
+    # ------------------------------------------------------------------ unsupervised (rpn.py:257-361, 426-430)
+    def _losses_unsup(self, anchors, logits, d8, pseudo: List[FreeInstances]):
+        n, r = logits.shape
+        U = self.cfg.UNSUPNET
+        anc = anchors.detach()
+        has_box = pseudo[0].has("boxes_sigma")
+        soft, sig, rows, tgt_rows = [], [], [], []
+        with torch.no_grad():
+            for i, inst in enumerate(pseudo):
+                pb = inst.pseudo_boxes.tensor
+                midx, lab, _ = ops.iou_match(pb, anc, self.iou_thresholds, self.iou_labels, True)
+                pos = torch.nonzero(lab == 1).squeeze(1)               # positives only, no subsampling
+                sel = midx[pos]
+                soft.append(inst.scores_logists[sel])
+                sig.append((inst.boxes_sigma if has_box else inst.scores_logists)[sel])
+                rows.append(pos + i * r)
+                tgt_rows.append(pb[sel])
+            T = torch.cat(soft, 0).contiguous()
+            flat = torch.cat(rows, 0)
+        inv = 1.0 / (self.batch_size_per_image * n)
+        x = logits.reshape(-1)[flat]
+        loss_cls, fg = ops.rpn_soft_obj_loss(T, x, U.TAU[0], U.EFL_LAMBDA[0], bool(U.EFL), inv)
+        out = {"loss_rpn_cls": loss_cls}
+        if has_box:
+            q = d8.reshape(-1, 8)[flat]
+            mu_p = self.box2box_transform.get_deltas(anchors[flat % r], torch.cat(tgt_rows, 0))
+            out["loss_rpn_loc"] = ops.kl_efl_loss(q, mu_p, torch.cat(sig, 0), fg, U.TAU[1], U.EFL_LAMBDA[1],
+                                                  bool(U.EFL), 0, inv)
+        return out
+
+
+def build_proposal_generator(cfg, input_shape):
+    return PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, input_shape)

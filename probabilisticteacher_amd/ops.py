@@ -54,6 +54,48 @@ def _loss_ws(device) -> torch.Tensor:
     return _ws("loss", 4096 * 4, device)
 
 
+# ---------------------------------------------------------------------------- HIP-event profiling (bench.py)
+_PROF = None
+
+
+def profile_start() -> None:
+    """Start recording a HIP event pair around every launch group below, on the stream the kernels use."""
+    global _PROF
+    _PROF = []
+
+
+def profile_stop() -> dict:
+    """Synchronise and return {kernel: {"ms", "flops", "calls"}} accumulated since profile_start()."""
+    global _PROF
+    rec, _PROF = _PROF or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for name, flops, e0, e1 in rec:
+        d = out.setdefault(name, {"ms": 0.0, "flops": 0.0, "calls": 0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["flops"] += flops
+        d["calls"] += 1
+    return out
+
+
+class _prof:
+    def __init__(self, name, flops=0.0):
+        self.name, self.flops = name, float(flops)
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROF is not None:
+            self.e1.record()
+            _PROF.append((self.name, self.flops, self.e0, self.e1))
+        return False
+
+
 # ============================================================================ conv 3x3
 def conv3x3_pack(w: torch.Tensor, mode: int) -> torch.Tensor:
     _chk(w, name="conv weight")
@@ -69,14 +111,18 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     _chk(x, name="conv input")
     n, cin, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
-    _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
-              epilogue, _stream())
+    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n):
+        _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
+                  epilogue, _stream())
     return y
 
 
 def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     dz = torch.empty_like(dy)
-    _lib.call("ptmi_relu_bwd", _ptr(_chk(dy.contiguous())), _ptr(_chk(y)), _ptr(dz), dy.numel(), _stream())
+    if dy.numel() == 0:
+        return dz
+    with _prof("relu_bwd"):
+        _lib.call("ptmi_relu_bwd", _ptr(_chk(dy.contiguous())), _ptr(_chk(y)), _ptr(dz), dy.numel(), _stream())
     return dz
 
 
@@ -107,8 +153,9 @@ class _Conv3x3(torch.autograd.Function):
             db = torch.empty(cout, dtype=F32, device=x.device)
             nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w)
             ws = _ws("wgrad", nws * 4, x.device)
-            _lib.call("ptmi_conv3x3_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
-                      _stream())
+            with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
+                _lib.call("ptmi_conv3x3_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
+                          _stream())
         if ctx.needs_input_grad[0]:
             wpd = conv3x3_pack(weight, 1)
             dx = conv3x3_raw(dz, wpd, None, None, cin, 2)
@@ -126,7 +173,8 @@ class _MaxPool2x2(torch.autograd.Function):
         x = _chk(x.contiguous(), name="pool input")
         n, c, h, w = x.shape
         y = torch.empty((n, c, h // 2, w // 2), dtype=F32, device=x.device)
-        _lib.call("ptmi_maxpool2x2_fwd", _ptr(x), _ptr(y), n * c, h, w, _stream())
+        with _prof("maxpool_fwd"):
+            _lib.call("ptmi_maxpool2x2_fwd", _ptr(x), _ptr(y), n * c, h, w, _stream())
         ctx.save_for_backward(x)
         return y
 
@@ -153,8 +201,9 @@ def gemm(a, b, m, n, k, lda, ldb, ta, tb, bias=None, bias_mode=0, relu=False, ou
     ldc = n if ldc is None else ldc
     if m == 0 or n == 0:
         return out
-    _lib.call("ptmi_gemm_f32", _ptr(a), _ptr(b), _ptr(out), _ptr(bias), m, n, k, lda, ldb, ldc, ta, tb, bias_mode,
-              int(relu), int(accumulate), batch, stride_a, stride_b, stride_c, _stream())
+    with _prof("gemm_f32", 2.0 * m * n * k * batch):
+        _lib.call("ptmi_gemm_f32", _ptr(a), _ptr(b), _ptr(out), _ptr(bias), m, n, k, lda, ldb, ldc, ta, tb, bias_mode,
+                  int(relu), int(accumulate), batch, stride_a, stride_b, stride_c, _stream())
     return out
 
 
@@ -258,7 +307,9 @@ class _ROIAlign(torch.autograd.Function):
         n, c, h, w = feat.shape
         r = rois.shape[0]
         out = torch.empty((r, c, pooled, pooled), dtype=F32, device=feat.device)
-        _lib.call("ptmi_roi_align_fwd", _ptr(feat), _ptr(rois), _ptr(out), n, c, h, w, r, pooled, float(scale), _stream())
+        with _prof("roi_align_fwd"):
+            _lib.call("ptmi_roi_align_fwd", _ptr(feat), _ptr(rois), _ptr(out), n, c, h, w, r, pooled, float(scale),
+                      _stream())
         ctx.save_for_backward(rois)
         ctx.meta = (n, c, h, w, pooled, float(scale))
         return out
@@ -268,8 +319,9 @@ class _ROIAlign(torch.autograd.Function):
         (rois,) = ctx.saved_tensors
         n, c, h, w, pooled, scale = ctx.meta
         dfeat = torch.zeros((n, c, h, w), dtype=F32, device=dout.device)
-        _lib.call("ptmi_roi_align_bwd", _ptr(_chk(dout.contiguous())), _ptr(rois), _ptr(dfeat), n, c, h, w,
-                  rois.shape[0], pooled, scale, _stream())
+        with _prof("roi_align_bwd"):
+            _lib.call("ptmi_roi_align_bwd", _ptr(_chk(dout.contiguous())), _ptr(rois), _ptr(dfeat), n, c, h, w,
+                      rois.shape[0], pooled, scale, _stream())
         return dfeat, None, None, None
 
 
@@ -363,8 +415,9 @@ def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor) -> Tuple[torch.T
         return out, idx
     nbytes = _lib.load().ptmi_segsort_ws_bytes(total, nseg)
     ws = _ws("sort", nbytes, keys.device)
-    _lib.call("ptmi_segsort_desc", _ptr(keys), _ptr(out), _ptr(idx), total, nseg, _ptr(seg_offsets), _ptr(ws), nbytes,
-              _stream())
+    with _prof("segsort_desc"):
+        _lib.call("ptmi_segsort_desc", _ptr(keys), _ptr(out), _ptr(idx), total, nseg, _ptr(seg_offsets), _ptr(ws),
+                  nbytes, _stream())
     return out, idx
 
 
@@ -391,30 +444,13 @@ def nms_batched(boxes_sorted: torch.Tensor, seg_offsets: torch.Tensor, max_count
     cnt = torch.empty(nimg, dtype=torch.int32, device=dev)
     nbytes = _lib.load().ptmi_nms_ws_bytes(max_count, nimg)
     ws = _ws("nms", nbytes, dev)
-    _lib.call("ptmi_nms_batched", _ptr(boxes_sorted), _ptr(seg_offsets), nimg, max_count, float(thr), max_keep,
-              _ptr(keep), _ptr(cnt), _ptr(ws), _stream())
+    with _prof("nms_batched"):
+        _lib.call("ptmi_nms_batched", _ptr(boxes_sorted), _ptr(seg_offsets), nimg, max_count, float(thr), max_keep,
+                  _ptr(keep), _ptr(cnt), _ptr(ws), _stream())
     return keep, cnt
 
 
 # ============================================================================ losses (loss + gradient in one launch)
-class _LossFn(torch.autograd.Function):
-    """Base: forward stores precomputed grads; backward scales them by the upstream scalar."""
-
-    @staticmethod
-    def _finish(ctx, loss, grads):
-        ctx.save_for_backward(*[g for g in grads if g is not None])
-        ctx.mask = [g is not None for g in grads]
-        return loss.reshape(())
-
-
-def _scale_saved(ctx, gout):
-    saved = list(ctx.saved_tensors)
-    out = []
-    for present in ctx.mask:
-        out.append(saved.pop(0) * gout if present else None)
-    return out
-
-
 class _BCELogitsSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, inv_norm: float):
@@ -578,7 +614,7 @@ def kl_efl_loss(q, mu_p, slog_p, fg, tau, lam, efl, reduction, inv_norm):
 # ============================================================================ optimiser / EMA / image prep
 def ema_update(student_flat: torch.Tensor, teacher_flat: torch.Tensor, keep_rate: float) -> None:
     _lib.call("ptmi_ema_update", _ptr(_chk(student_flat)), _ptr(_chk(teacher_flat)), student_flat.numel(),
-              float(keep_rate), _stream())
+              float(keep_rate), float(1 - keep_rate), _stream())
 
 
 def sumsq(g_flat: torch.Tensor) -> torch.Tensor:

@@ -1,0 +1,165 @@
+"""GPU parity (pytest -m gpu): the HIP model / trainer against (a) golden vectors produced by the REAL reference
+(tests/golden, see tools/gen_golden.py) and (b) the CPU oracle on the same seeded inputs.
+
+Tolerances: losses rtol 1e-4 (BASELINE.json north_star: "loss parity vs CPU reference to 1e-4"); gradients
+rtol 2e-3 of the tensor norm (fp32 MFMA k-ordered accumulation vs oneDNN blocking); box coordinates 2e-3 px;
+class indices, sampler draw sizes (== label counts) exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import d2, pt as opt
+from tests.helpers import close, load, records
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(K, anchor, tau, burn=4000):
+    from probabilisticteacher_amd.config import setup_cfg
+    return setup_cfg("configs/pt/final_c2f.yaml", [
+        "MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "", "MODEL.ANCHOR_GENERATOR.NAME", anchor,
+        "MODEL.ROI_HEADS.NUM_CLASSES", K, "UNSUPNET.TAU", list(tau), "UNSUPNET.BURN_UP_STEP", burn])
+
+
+def _load_params(model, params):
+    sd = model.state_dict()
+    assert set(sd) == set(params), set(sd) ^ set(params)
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(v)
+
+
+def _gpu_records(z, prefix, n):
+    from probabilisticteacher_amd.structures import FreeInstances
+    return records(z, prefix, n, make_instances=FreeInstances)
+
+
+def _grad_check(z, prefix, named, tol=2e-3):
+    checked = 0
+    for k, p in named.items():
+        key = f"{prefix}_norm_{k}"
+        if key not in z.files:
+            continue
+        g = p.grad
+        nrm = float(z[key])
+        close(g.double().norm().cpu(), z[key], tol, 1e-7, key)
+        close(g.flatten()[:32].cpu(), z[f"{prefix}_head_{k}"], 5e-3, 2e-4 * nrm + 1e-8, f"{prefix}_head_{k}")
+        checked += 1
+    assert checked >= 4
+
+
+@pytest.mark.parametrize("anchor,tag", [("DefaultAnchorGenerator", "default_anchor"),
+                                        ("DifferentiableAnchorGenerator", "diff_anchor")])
+def test_model_branches_match_reference_goldens(anchor, tag):
+    from probabilisticteacher_amd import modeling
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.engine.flat import FlatParams
+    z = load("model_" + tag)
+    K, tau = int(z["K"]), tuple(float(v) for v in z["tau"])
+    cfg = _cfg(K, anchor, tau)
+    ocfg = opt.Cfg(num_classes=K, anchor_generator=anchor, tau=tau)
+    model = modeling.build_model(cfg)
+    model.train()
+    _load_params(model, opt.golden_params(ocfg, int(z["seed"])))
+    flat = FlatParams(model)
+    named = dict(model.named_parameters())
+
+    # ---- supervised branch: losses + gradients vs the reference
+    perm = opt.SeededPerm(77)
+    sampling.set_perm_fn(perm)
+    try:
+        flat.zero_grad()
+        losses, _, _, _ = model(_gpu_records(z, "sup", 2), branch="supervised")
+        assert perm.log == list(z["sup_perm_log"]), f"label counts differ: {perm.log} vs {list(z['sup_perm_log'])}"
+        for k, v in losses.items():
+            close(v.detach().cpu(), z["sup_" + k], 1e-4, 1e-6, "sup " + k)
+        sum(losses.values()).backward()
+        _grad_check(z, "supgrad", named)
+
+        # ---- teacher branch
+        sampling.set_perm_fn(opt.SeededPerm(78))
+        with torch.no_grad():
+            _, prop_rpn, prop_roih, pred = model(_gpu_records(z, "weak", 2), branch="unsup_data_weak")
+        for i in range(2):
+            ref_b = z[f"t_rpn{i}_proposal_boxes"]
+            assert len(prop_rpn[i]) == len(ref_b), f"proposal count {len(prop_rpn[i])} vs {len(ref_b)}"
+            close(prop_rpn[i].proposal_boxes.tensor.cpu(), ref_b, 1e-5, 2e-3, "rpn proposals")
+            close(prop_rpn[i].objectness_logits.cpu(), z[f"t_rpn{i}_objectness_logits"], 1e-4, 1e-5, "rpn scores")
+            assert np.array_equal(prop_roih[i].pred_classes.cpu().numpy(), z[f"t_roih{i}_pred_classes"])
+            close(prop_roih[i].pred_boxes.tensor.cpu(), z[f"t_roih{i}_pred_boxes"], 1e-5, 2e-3, "detections")
+            close(prop_roih[i].scores.cpu(), z[f"t_roih{i}_scores"], 1e-4, 1e-6, "det scores")
+            close(prop_roih[i].scores_logists.cpu(), z[f"t_roih{i}_scores_logists"], 1e-4, 1e-5, "det logits")
+            close(prop_roih[i].boxes_sigma.cpu(), z[f"t_roih{i}_boxes_sigma"], 1e-4, 1e-5, "det sigma")
+        close(pred[0].cpu(), z["t_pred_scores"], 1e-4, 1e-5, "roi scores")
+        close(pred[1].cpu(), z["t_pred_deltas"], 1e-4, 1e-5, "roi deltas")
+
+        # ---- unsupervised branch fed with the REFERENCE's pseudo labels (the fixture's teacher outputs)
+        from probabilisticteacher_amd.structures import Boxes, FreeInstances
+        strong = _gpu_records(z, "strong", 2)
+        for i, r in enumerate(strong):
+            h, w = r["image"].shape[-2:]
+            inst = FreeInstances((h, w))
+            inst.pseudo_boxes = Boxes(torch.from_numpy(z[f"t_roih{i}_pred_boxes"]))
+            inst.scores_logists = torch.from_numpy(z[f"t_roih{i}_scores_logists"])
+            inst.boxes_sigma = torch.from_numpy(z[f"t_roih{i}_boxes_sigma"])
+            r["instances"] = inst
+        flat.zero_grad()
+        sampling.set_perm_fn(opt.SeededPerm(79))
+        losses_u, _, _, _ = model(strong, branch="unsupervised", danchor=True)
+        for k, v in losses_u.items():
+            close(v.detach().cpu(), z["unsup_" + k], 1e-4, 1e-6, "unsup " + k)
+        sum(losses_u.values()).backward()
+        _grad_check(z, "unsupgrad", named)
+    finally:
+        sampling.set_perm_fn(None)
+
+
+def test_run_step_matches_reference_golden():
+    """Three real PTrainer.run_step iterations of the reference (burn-in, EMA copy + mutual, EMA + mutual) replayed
+    on the HIP trainer: metrics and parameter probes."""
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    z = load("run_step")
+    K, tau, B = int(z["K"]), tuple(float(v) for v in z["tau"]), int(z["B"])
+    cfg = _cfg(K, "DifferentiableAnchorGenerator", tau, burn=1)
+    ocfg = opt.Cfg(num_classes=K, anchor_generator="DifferentiableAnchorGenerator", tau=tau, burn_up_step=1)
+    ratios = []
+    tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
+    _load_params(tr.model, opt.golden_params(ocfg, int(z["seed"])))
+    _load_params(tr.model_teacher, opt.golden_params(ocfg, int(z["teacher_seed"])))
+    probes = sorted({k.split("_s_sum_")[1] for k in z.files if "_s_sum_" in k})
+    try:
+        for it in range(3):
+            data = tuple(_gpu_records(z, f"it{it}_{nm}", B) for nm in ("lq", "lk", "uq", "uk"))
+            ratios[:] = [float(v) for v in z[f"it{it}_ratios"]]
+            tr.pseudo_override = None
+            if f"it{it}_pseudo0_pseudo_boxes" in z.files:
+                ov = []
+                for i in range(B):
+                    h, w = data[3][i]["image"].shape[-2:]
+                    inst = FreeInstances((h, w))
+                    inst.pseudo_boxes = Boxes(torch.from_numpy(z[f"it{it}_pseudo{i}_pseudo_boxes"]).to(DEV))
+                    inst.scores_logists = torch.from_numpy(z[f"it{it}_pseudo{i}_scores_logists"]).to(DEV)
+                    inst.boxes_sigma = torch.from_numpy(z[f"it{it}_pseudo{i}_boxes_sigma"]).to(DEV)
+                    ov.append(inst)
+                tr.pseudo_override = ov
+            sampling.set_perm_fn(opt.SeededPerm(500 + it))
+            m = tr.run_step(data)
+            if tr.pseudo_override is not None:
+                for mine, ref in zip(tr.last_pseudo, tr.pseudo_override):
+                    assert len(mine) == len(ref)
+                    close(mine.pseudo_boxes.tensor.cpu(), ref.pseudo_boxes.tensor.cpu(), 1e-4, 2e-2, "pseudo boxes")
+                    close(mine.scores_logists.cpu(), ref.scores_logists.cpu(), 1e-3, 2e-3, "pseudo logits")
+            for k in z.files:
+                if k.startswith(f"it{it}_m_"):
+                    close(torch.tensor(m[k[len(f"it{it}_m_"):]]), z[k], 3e-4, 1e-6, k)
+            ssd, tsd = tr.model.state_dict(), tr.model_teacher.state_dict()
+            for k in probes:
+                close(ssd[k].double().sum().cpu(), z[f"it{it}_s_sum_{k}"], 1e-5, 2e-4, f"student sum {k}")
+                close(ssd[k].flatten()[:16].cpu(), z[f"it{it}_s_head_{k}"], 1e-4, 1e-6, f"student head {k}")
+                close(tsd[k].double().sum().cpu(), z[f"it{it}_t_sum_{k}"], 1e-5, 2e-4, f"teacher sum {k}")
+                close(tsd[k].flatten()[:16].cpu(), z[f"it{it}_t_head_{k}"], 1e-4, 1e-6, f"teacher head {k}")
+    finally:
+        sampling.set_perm_fn(None)
