@@ -6,6 +6,10 @@ symbol is absent this module raises at first use, loudly.
 import ctypes
 import os
 
+# torch must be loaded FIRST: it bundles its own libamdhip64.so.7, and libptmi355.so has to resolve to that same
+# HIP runtime instance (same soname) so that streams / device pointers are shared with the caching allocator.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptmi355.so")
 

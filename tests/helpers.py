@@ -52,3 +52,22 @@ def close(a, b, rtol, atol, what=""):
     err = np.abs(a - b)
     tol = atol + rtol * np.abs(b)
     assert (err <= tol).all(), f"{what}: max abs err {err.max():.3e} (worst rel {np.max(err / (np.abs(b) + 1e-30)):.3e})"
+
+
+def match_detections(boxes_a, cls_a, boxes_b, cls_b, box_tol=5e-3):
+    """Order-insensitive comparison of two detection lists (scores that differ by fp32 noise may swap ranks):
+    returns (fraction of b matched by a same-class box within box_tol px, index map b -> a or -1)."""
+    boxes_a, boxes_b = np.asarray(boxes_a, np.float64), np.asarray(boxes_b, np.float64)
+    cls_a, cls_b = np.asarray(cls_a), np.asarray(cls_b)
+    used = np.zeros(len(boxes_a), bool)
+    idx = -np.ones(len(boxes_b), np.int64)
+    for j in range(len(boxes_b)):
+        cand = np.nonzero((cls_a == cls_b[j]) & ~used)[0]
+        if len(cand) == 0:
+            continue
+        d = np.abs(boxes_a[cand] - boxes_b[j]).max(axis=1)
+        k = int(np.argmin(d))
+        if d[k] <= box_tol * max(1.0, np.abs(boxes_b[j]).max() / 100.0):
+            idx[j] = cand[k]
+            used[cand[k]] = True
+    return float((idx >= 0).mean()) if len(idx) else 1.0, idx

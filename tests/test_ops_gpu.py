@@ -415,7 +415,7 @@ def test_ema_clip_sgd(ops):
     assert torch.equal(td.cpu(), ref), "EMA must be bit-exact (same op order, no FMA contraction)"
     gr = torch.randn(n, generator=gen) * 0.2
     ss = ops.sumsq(gr.to(DEV))
-    close(ss, (gr.double() ** 2).sum().float(), 1e-5, 0, "sumsq")
+    close(ss.reshape(()), (gr.double() ** 2).sum().float(), 1e-5, 0, "sumsq")
     p, buf = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
     for first in (True, False):
         pd, bd = p.to(DEV), buf.to(DEV)
