@@ -92,11 +92,11 @@ def test_model_branches_match_reference_goldens(anchor, tag):
             assert len(prop_roih[i]) == len(z[f"t_roih{i}_scores"]) and frac >= 0.97, f"matched {frac:.3f}"
             ok = idx >= 0
             mine = idx[ok]
-            close(prop_roih[i].scores.cpu()[mine], z[f"t_roih{i}_scores"][ok], 1e-4, 1e-6, "det scores")
-            close(prop_roih[i].scores_logists.cpu()[mine], z[f"t_roih{i}_scores_logists"][ok], 1e-4, 1e-5, "det logits")
-            close(prop_roih[i].boxes_sigma.cpu()[mine], z[f"t_roih{i}_boxes_sigma"][ok], 1e-4, 1e-5, "det sigma")
-        close(pred[0].cpu(), z["t_pred_scores"], 1e-4, 1e-5, "roi scores")
-        close(pred[1].cpu(), z["t_pred_deltas"], 1e-4, 1e-5, "roi deltas")
+            close(prop_roih[i].scores.cpu()[mine], z[f"t_roih{i}_scores"][ok], 5e-4, 1e-6, "det scores")
+            close(prop_roih[i].scores_logists.cpu()[mine], z[f"t_roih{i}_scores_logists"][ok], 1e-3, 5e-4, "det logits")
+            close(prop_roih[i].boxes_sigma.cpu()[mine], z[f"t_roih{i}_boxes_sigma"][ok], 1e-3, 5e-4, "det sigma")
+        close(pred[0].cpu(), z["t_pred_scores"], 1e-3, 5e-4, "roi scores")
+        close(pred[1].cpu(), z["t_pred_deltas"], 1e-3, 5e-4, "roi deltas")
 
         # ---- unsupervised branch fed with the REFERENCE's pseudo labels (the fixture's teacher outputs)
         from probabilisticteacher_amd.structures import Boxes, FreeInstances
