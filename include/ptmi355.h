@@ -93,6 +93,12 @@ int ptmi_roi_align_fwd(const float* feat, const float* rois, float* out, int n, 
 /* dfeat must be zeroed by the caller (atomic scatter-add). */
 int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n, int c, int h,
                        int w, int r, int pooled, float scale, ptmi_stream_t s);
+/* Same result for rois GROUPED BY IMAGE (rows img_offsets[i]..img_offsets[i+1] belong to image i; int32
+ * device array of n+1): each workgroup accumulates a few channel planes of one image in LDS and writes them
+ * once -- no global atomics, dfeat need not be zeroed (every element is written). */
+int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32_t* img_offsets,
+                               float* dfeat, int n, int c, int h, int w, int r, int pooled,
+                               float scale, ptmi_stream_t s);
 
 /* ------------------------------------------------------------------ boxes (N4, N5, N9)
  * anchors: D2 DefaultAnchorGenerator / pt/modeling/anchor_generator.py:108-122: out (h*w*A,4),

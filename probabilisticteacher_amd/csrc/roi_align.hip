@@ -106,6 +106,51 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
     }
 }
 
+// Backward without global atomics: one workgroup owns CG channel planes of ONE image in LDS, walks that image's
+// ROIs (rois are grouped by image), scatter-adds with LDS atomics (ds_add_f32) and writes each plane once,
+// coalesced.  HBM traffic = read dout once + write dfeat once; no pre-zeroing of dfeat needed.
+__global__ __launch_bounds__(256) void roi_align_bwd_lds_kernel(const float* __restrict__ dout,
+                                                                const float* __restrict__ rois,
+                                                                const int32_t* __restrict__ img_off,
+                                                                float* __restrict__ dfeat, int C, int H, int W, int P,
+                                                                float scale, int CG)
+{
+    extern __shared__ float plane[];   // CG * H * W
+    const int n = blockIdx.y, c0 = blockIdx.x * CG;
+    const int HW = H * W, PP = P * P;
+    const int cg = min(CG, C - c0);
+    for (int i = threadIdx.x; i < cg * HW; i += 256) plane[i] = 0.f;
+    __syncthreads();
+    const int r0 = img_off[n], r1 = img_off[n + 1];
+    const int items = cg * PP;
+    for (int r = r0; r < r1; ++r) {
+        const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, P);
+        const float* ob = dout + ((size_t)r * C + c0) * PP;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int c = i / PP, rem = i - c * PP;
+            const int ph = rem / P, pw = rem - ph * P;
+            float* f = plane + c * HW;
+            const float go = ob[i];
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const float y = g.sh + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+                for (int ix = 0; ix < g.gw; ++ix) {
+                    const float x = g.sw + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                    int yl, xl, yh, xh;
+                    float w1, w2, w3, w4;
+                    if (!bilin(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+                    atomicAdd(f + yl * W + xl, go * w1 / g.count);
+                    atomicAdd(f + yl * W + xh, go * w2 / g.count);
+                    atomicAdd(f + yh * W + xl, go * w3 / g.count);
+                    atomicAdd(f + yh * W + xh, go * w4 / g.count);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = dfeat + ((size_t)n * C + c0) * HW;
+    for (int i = threadIdx.x; i < cg * HW; i += 256) dst[i] = plane[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -131,6 +176,35 @@ int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(r), dim3(256), 0, (hipStream_t)s, dout, rois, dfeat, c, h, w, pooled,
                        scale);
     PTMI_LAUNCH_CHECK("roi_align_bwd");
+    return 0;
+}
+
+int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32_t* img_offsets, float* dfeat, int n,
+                               int c, int h, int w, int r, int pooled, float scale, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(dfeat && img_offsets && n > 0 && c > 0 && h > 0 && w > 0 && r >= 0 && pooled > 0,
+                   "roi_align_bwd_grouped: bad args");
+    hipStream_t st = (hipStream_t)s;
+    const size_t plane_bytes = (size_t)h * w * sizeof(float);
+    const size_t budget = 150 * 1024;
+    if (plane_bytes > budget || r == 0) {   // map too large for LDS (or nothing to scatter): zero + atomic path
+        hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)n * c * plane_bytes, st);
+        if (e != hipSuccess) { ptmi_set_error("roi_align_bwd_grouped: memset failed"); return -2; }
+        return r == 0 ? 0 : ptmi_roi_align_bwd(dout, rois, dfeat, n, c, h, w, r, pooled, scale, s);
+    }
+    PTMI_CHECK_ARG(dout && rois, "roi_align_bwd_grouped: null buffer");
+    int cg = (int)(budget / plane_bytes);
+    if (cg > 8) cg = 8;
+    if (cg > c) cg = c;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(roi_align_bwd_lds_kernel, dim3(cdiv(c, cg), n), dim3(256), (size_t)cg * plane_bytes, st, dout,
+                       rois, img_offsets, dfeat, c, h, w, pooled, scale, cg);
+    PTMI_LAUNCH_CHECK("roi_align_bwd_grouped");
     return 0;
 }
 

@@ -39,7 +39,11 @@ class ROIPooler(nn.Module):
         dev = x[0].device
         rows = [torch.cat([torch.full((len(b), 1), float(i), device=dev), b.tensor], 1) for i, b in enumerate(box_lists)]
         rois = torch.cat(rows, 0) if rows else torch.zeros((0, 5), device=dev)
-        return ops.roi_align(x[0], rois.contiguous(), self.output_size, self.scale)
+        offs = [0]
+        for b in box_lists:
+            offs.append(offs[-1] + len(b))
+        img_offsets = torch.tensor(offs, dtype=torch.int32, device=dev) if len(box_lists) == x[0].shape[0] else None
+        return ops.roi_align(x[0], rois.contiguous(), self.output_size, self.scale, img_offsets)
 
 
 @ROI_BOX_HEAD_REGISTRY.register()

@@ -301,7 +301,7 @@ def conv1x1(x, weight, bias):
 # ============================================================================ ROIAlign
 class _ROIAlign(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, rois, pooled: int, scale: float):
+    def forward(ctx, feat, rois, pooled: int, scale: float, img_offsets):
         feat = _chk(feat.contiguous())
         rois = _chk(rois.contiguous())
         n, c, h, w = feat.shape
@@ -310,23 +310,33 @@ class _ROIAlign(torch.autograd.Function):
         with _prof("roi_align_fwd"):
             _lib.call("ptmi_roi_align_fwd", _ptr(feat), _ptr(rois), _ptr(out), n, c, h, w, r, pooled, float(scale),
                       _stream())
-        ctx.save_for_backward(rois)
+        ctx.save_for_backward(rois, img_offsets)
         ctx.meta = (n, c, h, w, pooled, float(scale))
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (rois,) = ctx.saved_tensors
+        rois, img_offsets = ctx.saved_tensors
         n, c, h, w, pooled, scale = ctx.meta
-        dfeat = torch.zeros((n, c, h, w), dtype=F32, device=dout.device)
-        with _prof("roi_align_bwd"):
-            _lib.call("ptmi_roi_align_bwd", _ptr(_chk(dout.contiguous())), _ptr(rois), _ptr(dfeat), n, c, h, w,
-                      rois.shape[0], pooled, scale, _stream())
-        return dfeat, None, None, None
+        dout = _chk(dout.contiguous())
+        if img_offsets is not None:
+            # rois grouped by image: LDS-accumulating kernel, no global atomics, writes every element of dfeat
+            dfeat = torch.empty((n, c, h, w), dtype=F32, device=dout.device)
+            with _prof("roi_align_bwd"):
+                _lib.call("ptmi_roi_align_bwd_grouped", _ptr(dout), _ptr(rois), _ptr(_chk(img_offsets, torch.int32)),
+                          _ptr(dfeat), n, c, h, w, rois.shape[0], pooled, scale, _stream())
+        else:
+            dfeat = torch.zeros((n, c, h, w), dtype=F32, device=dout.device)
+            with _prof("roi_align_bwd"):
+                _lib.call("ptmi_roi_align_bwd", _ptr(dout), _ptr(rois), _ptr(dfeat), n, c, h, w, rois.shape[0], pooled,
+                          scale, _stream())
+        return dfeat, None, None, None, None
 
 
-def roi_align(feat, rois, pooled: int, scale: float):
-    return _ROIAlign.apply(feat, rois, pooled, scale)
+def roi_align(feat, rois, pooled: int, scale: float, img_offsets=None):
+    """rois (R,5) = [image index, x1, y1, x2, y2].  If the rows are grouped by image, pass `img_offsets`
+    (int32 (N+1,) device tensor of row offsets) to enable the atomic-free backward."""
+    return _ROIAlign.apply(feat, rois, pooled, scale, img_offsets)
 
 
 # ============================================================================ boxes

@@ -169,6 +169,13 @@ def test_roi_align(ops):
     close(fd.grad, fr.grad, 1e-4, 1e-4, "roi_align bwd (atomics: tolerance, not bit-exact)")
     empty = ops.roi_align(fd, torch.zeros((0, 5), device=DEV), 7, 1 / 16)
     assert empty.shape == (0, 16, 7, 7)
+    # grouped-by-image backward (LDS accumulation, no global atomics) gives the same gradient
+    order = torch.argsort(rois[:, 0], stable=True)
+    rs = rois[order]
+    offs = torch.tensor([0, int((rs[:, 0] == 0).sum()), len(rs)], dtype=torch.int32, device=DEV)
+    fd2 = feat.to(DEV).requires_grad_()
+    ops.roi_align(fd2, rs.to(DEV), 7, 1 / 16, offs).backward(gy[order].to(DEV))
+    close(fd2.grad, fr.grad, 1e-4, 1e-4, "roi_align grouped bwd")
 
 
 # ------------------------------------------------------------------------------------------ boxes
