@@ -20,6 +20,8 @@
 //     mask can be applied in the epilogue (epilogue 3).
 //   * wgrad: M = Cout, N = Cin (x 9 taps as 9 accumulator tiles), K = pixels; split-K over pixel
 //     tiles with a fixed-order second-stage reduction (deterministic).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -185,6 +187,159 @@ __global__ __launch_bounds__(256, 3) void conv3x3_mfma_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ forward, LDS-DMA pipeline
+// Same tiling as conv3x3_mfma_kernel, but operands go global -> LDS directly (global_load_lds, no VGPR
+// staging, no ds_write), double-buffered with ONE workgroup barrier per 4-channel chunk:
+//   issue DMA(chunk c+1 -> buf^1) ; 72 MFMAs on buf ; s_waitcnt vmcnt(0) ; s_barrier
+// The weight slab is linear in both address spaces (16-B DMA pieces); the halo patch is a per-lane gather
+// (4-B pieces) whose out-of-image / padded-channel lanes read the zero page appended to the packed weights.
+// ~90 VGPRs and 43 KB LDS => three workgroups per CU, none of them holding staging registers.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ void dma16(const float* g, float* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const float* g, float* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 4, 0, 0);
+}
+
+template <int BM>
+__global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
+    int tilesX, int tilesY, int coTiles, int nChunks, int epi, const float* __restrict__ zero_page)
+{
+    using C = FwdCfg<BM>;
+    constexpr int CK = 4;
+    constexpr int TH = C::TH, PLANE = C::PLANE;
+    constexpr int WS = 9 * CK * BM;
+    constexpr int PS = CK * PLANE;
+    constexpr int WS4 = WS / 4;
+    constexpr int NW4 = (WS4 + 255) / 256;
+    constexpr int NP = (PS + 255) / 256;
+    constexpr int STAGE = WS + ((PS + 63) / 64) * 64;       // floats per buffer (patch padded to a wave multiple)
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int cot = bid % coTiles;
+    int pt = bid / coTiles;
+    const int tx = pt % tilesX;
+    pt /= tilesX;
+    const int ty = pt % tilesY;
+    const int n = pt / tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int HW = H * W;
+
+    int poff[NP];
+    unsigned pvalid = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int idx = tid + i * 256;
+        poff[i] = 0;
+        if (idx < PS) {
+            const int ci = idx / PLANE, rem = idx - ci * PLANE;
+            const int r = rem / PW, c = rem - r * PW;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                poff[i] = ci * HW + gy * W + gx;
+                pvalid |= 1u << i;
+            }
+        }
+    }
+    const float* xn = x + (size_t)n * Cin * HW;
+    const float* wbase = wp + (size_t)cot * nChunks * WS;
+    const int wave_base = tid & ~63;
+
+    auto issue = [&](int chunk, int buf) {
+        float* Wd = lds + buf * STAGE;
+        float* Pd = Wd + WS;
+        const float* wsrc = wbase + (size_t)chunk * WS;
+#pragma unroll
+        for (int i = 0; i < NW4; ++i) {
+            const int idx = tid + i * 256;                       // float4 index
+            if (wave_base + i * 256 < WS4) {                     // wave-uniform guard (WS4 is a multiple of 64)
+                dma16(wsrc + (size_t)idx * 4, Wd + (size_t)(wave_base + i * 256) * 4);
+            }
+        }
+        const int c0 = chunk * CK;
+        const float* xc = xn + (size_t)c0 * HW;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = tid + i * 256;
+            if (wave_base + i * 256 < PS) {                      // wave-uniform: whole wave beyond the patch skips
+                const bool ok = idx < PS && ((pvalid >> i) & 1u) && (c0 + idx / PLANE) < Cin;
+                const float* src = ok ? xc + poff[i] : zero_page + (lane & 63);
+                dma4(src, Pd + wave_base + i * 256);
+            }
+        }
+    };
+
+    const int wm = (BM == 128) ? (wave >> 1) : 0;
+    const int wn = (BM == 128) ? (wave & 1) : wave;
+    const int a_off = wm * 64 + (lane & 31) + (lane >> 5) * BM;
+    const int b_off = WS + (lane >> 5) * PLANE + (wn * 2) * PW + (lane & 31);
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+
+    issue(0, 0);
+    for (int chunk = 0; chunk < nChunks; ++chunk) {
+        const int buf = chunk & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's DMA pieces of `buf` have landed
+        __syncthreads();                                          // everyone's pieces landed; buf^1 is free
+        if (chunk + 1 < nChunks) issue(chunk + 1, buf ^ 1);
+        const float* wsl = lds + buf * STAGE + a_off;
+        const float* psl = lds + buf * STAGE + b_off;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int j = 0; j < CK / 2; ++j) {
+                const float a0 = wsl[(tap * CK + 2 * j) * BM];
+                const float a1 = wsl[(tap * CK + 2 * j) * BM + 32];
+                const float b0 = psl[2 * j * PLANE + (0 + ky) * PW + kx];
+                const float b1 = psl[2 * j * PLANE + (1 + ky) * PW + kx];
+                acc00 = mfma32(a0, b0, acc00);
+                acc01 = mfma32(a0, b1, acc01);
+                acc10 = mfma32(a1, b0, acc10);
+                acc11 = mfma32(a1, b1, acc11);
+            }
+        }
+    }
+
+    const int px = x0 + (lane & 31);
+    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
+    const int yrow = y0 + wn * 2;
+    float* yn = y + (size_t)n * Cout * HW;
+    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
+            if (co >= Cout) continue;
+            const float b = (epi <= 1) ? bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int yy = yrow + q;
+                if (yy >= H || px >= W) continue;
+                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
+                const size_t o = (size_t)co * HW + (size_t)yy * W + px;
+                if (epi <= 1) {
+                    v += b;
+                    if (epi == 1) v = fmaxf(v, 0.f);
+                } else if (epi == 3) {
+                    v = (mn[o] > 0.f) ? v : 0.f;
+                }
+                yn[o] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ weight pack
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int wCout,
                                     int wCin, int mode, int BM, int CK, int coTiles, int nChunks)
@@ -208,6 +363,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         }
         wp[i] = v;
     }
+    // 64-float "zero page" after the slabs: the LDS-DMA kernel points halo / channel-padding lanes here
+    if (blockIdx.x == 0 && threadIdx.x < 64) wp[total + threadIdx.x] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------ wgrad
@@ -376,6 +533,17 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
         dz[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
+// 2 = LDS-DMA double-buffered pipeline (CK = 4, default); 1 = register-staged kernel (PTMI_CONV_IMPL=1)
+int conv_impl()
+{
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("PTMI_CONV_IMPL");
+        impl = (e && e[0] == '1') ? 1 : 2;
+    }
+    return impl;
+}
+
 int wgrad_splits(int n, int cin, int cout, int h, int w)
 {
     const int tilesX = cdiv(w, TW), tilesY = h;
@@ -393,12 +561,21 @@ int wgrad_splits(int n, int cin, int cout, int h, int w)
 extern "C" {
 
 int ptmi_conv3x3_bm(int cout) { return cout <= 64 ? 64 : 128; }
-int ptmi_conv3x3_ck(int cin) { return cin <= 4 ? 4 : 8; }
+int ptmi_conv3x3_ck(int cin)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("PTMI_CONV_CK");   // tuning knob: force the channel-chunk depth (4 or 8)
+        forced = (e && (e[0] == '4' || e[0] == '8')) ? (e[0] - '0') : 0;
+    }
+    if (forced) return forced;
+    return (cin <= 4 || conv_impl() == 2) ? 4 : 8;
+}
 
 int64_t ptmi_conv3x3_packed_floats(int cin, int cout)
 {
     const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
-    return (int64_t)cdiv(cout, BM) * cdiv(cin, CK) * 9 * CK * BM;
+    return (int64_t)cdiv(cout, BM) * cdiv(cin, CK) * 9 * CK * BM + 64;   // + zero page
 }
 
 int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode,
@@ -430,6 +607,17 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     PTMI_CHECK_ARG(blocks < (1ll << 31), "conv3x3_fwd: grid too large");
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)s;
+    if (CK == 4 && conv_impl() == 2) {
+        const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
+        if (BM == 128)
+            hipLaunchKernelGGL((conv3x3_dma_kernel<128>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout, h,
+                               w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
+        else
+            hipLaunchKernelGGL((conv3x3_dma_kernel<64>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout, h,
+                               w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
+        PTMI_LAUNCH_CHECK("conv3x3_fwd(dma)");
+        return 0;
+    }
 #define LAUNCH(BM_, CK_)                                                                              \
     hipLaunchKernelGGL((conv3x3_mfma_kernel<BM_, CK_>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, \
                        cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
