@@ -55,7 +55,7 @@ def cpu_baseline(h, w, K, seed=0):
     """The CPU oracle (oracle/pt.py, a port of the reference's algorithm on stock torch CPU fp32 ops) timed on this
     box's host cores: ONE full mutual-learning step with 1 labelled + 1 unlabelled image (bounded sample)."""
     from oracle import d2, pt as opt
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))      # oneDNN scales poorly past ~32 threads at batch 1
     cfg = opt.Cfg(num_classes=K, burn_up_step=0)
     gen = torch.Generator().manual_seed(seed)
     state = {"student": opt.init_params(cfg, 0), "teacher": opt.init_params(cfg, 0), "bufs": {}, "iter": 0}

@@ -479,6 +479,104 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ wgrad, LDS-DMA pipeline
+// Same decomposition as conv3x3_wgrad_kernel (128 co x 32 ci x 9 taps per workgroup, K = pixels, one 32-pixel
+// row segment per stage) but dY rows and the X halo patch are DMA'd straight into double-buffered LDS with 4-byte
+// per-lane gathers (pad / out-of-image lanes read the zero page): no staging registers next to the 144
+// accumulator VGPRs, one barrier per stage.
+constexpr int WD_DY = 128 * DY_PITCH;                       // 4224 floats (multiple of 64)
+constexpr int WD_X = ((32 * XP_PITCH + 63) / 64) * 64;      // 3328 floats
+constexpr int WD_STAGE = WD_DY + WD_X;
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
+    int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S,
+    const float* __restrict__ zero_page)
+{
+    constexpr int NDY = (WD_DY + 255) / 256;                 // 17
+    constexpr int NX = WD_X / 256;                           // 13
+    __shared__ __attribute__((aligned(16))) float lds[2 * WD_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_base = tid & ~63;
+    int bid = blockIdx.x;
+    const int s = bid % S; bid /= S;
+    const int cit = bid % ciTiles;
+    const int cot = bid / ciTiles;
+    const int HW = H * W;
+    const int co0 = cot * 128, ci0 = cit * 32;
+    const int nTiles = N * tilesY * tilesX;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+
+    auto issue = [&](int tile, int buf) {
+        const int tx = tile % tilesX;
+        int t2 = tile / tilesX;
+        const int ty = t2 % tilesY;
+        const int n = t2 / tilesY;
+        const int x0 = tx * TW, y0 = ty;
+        const float* dyn = dy + (size_t)n * Cout * HW + (size_t)y0 * W + x0;
+        const float* xn = x + (size_t)n * Cin * HW;
+        float* Dd = lds + buf * WD_STAGE;
+        float* Xd = Dd + WD_DY;
+#pragma unroll 1
+        for (int i = 0; i < NDY; ++i) {
+            if (wave_base + i * 256 < WD_DY) {
+                const int idx = tid + i * 256;
+                const int col = idx / DY_PITCH, p = idx - col * DY_PITCH;
+                const bool ok = p < 32 && (co0 + col) < Cout && (x0 + p) < W;
+                const float* src = ok ? dyn + (size_t)(co0 + col) * HW + p : zero_page + lane;
+                dma4(src, Dd + wave_base + i * 256);
+            }
+        }
+#pragma unroll 1
+        for (int i = 0; i < NX; ++i) {
+            const int idx = tid + i * 256;
+            const int cil = idx / XP_PITCH, rem = idx - cil * XP_PITCH;
+            const int r = rem / PW, c = rem - r * PW;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            const bool ok = cil < 32 && rem < XP_PLANE && (ci0 + cil) < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const float* src = ok ? xn + (size_t)(ci0 + cil) * HW + (size_t)gy * W + gx : zero_page + lane;
+            dma4(src, Xd + wave_base + i * 256);
+        }
+    };
+
+    const int a_off = (wave * 32 + (lane & 31)) * DY_PITCH + (lane >> 5);
+    const int b_off = WD_DY + (lane & 31) * XP_PITCH + (lane >> 5);
+
+    int tile = s, it = 0;
+    if (tile < nTiles) issue(tile, 0);
+    for (; tile < nTiles; tile += S, ++it) {
+        const int buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tile + S < nTiles) issue(tile + S, buf ^ 1);
+        const float* al = lds + buf * WD_STAGE + a_off;
+        const float* bl = lds + buf * WD_STAGE + b_off;
+#pragma unroll 2
+        for (int kk = 0; kk < 16; ++kk) {
+            const float a = al[2 * kk];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const float b = bl[ky * PW + 2 * kk + kx];
+                acc[tap] = mfma32(a, b, acc[tap]);
+            }
+        }
+    }
+    const int ci = ci0 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        float* dst = partial + ((size_t)s * 9 + tap) * Cout * Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[tap][r];
+        }
+    }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
                                     int Cin, int S, int accumulate)
 {
@@ -632,7 +730,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 {
-    return (int64_t)wgrad_splits(n, cin, cout, h, w) * 9 * cout * cin;
+    return (int64_t)wgrad_splits(n, cin, cout, h, w) * 9 * cout * cin + 64;   // + zero page for the DMA kernel
 }
 
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
@@ -643,8 +741,16 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
     const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
     const int S = wgrad_splits(n, cin, cout, h, w);
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
-                       cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);
+    if (conv_impl() == 2) {
+        float* zero_page = ws + (int64_t)S * 9 * cout * cin;
+        hipError_t e = hipMemsetAsync(zero_page, 0, 64 * sizeof(float), st);
+        if (e != hipSuccess) { ptmi_set_error("conv3x3_wgrad: memset failed"); return -2; }
+        hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
+                           cout, h, w, tilesX, tilesY, coTiles, ciTiles, S, zero_page);
+    } else {
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
+                           cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);
+    }
     PTMI_LAUNCH_CHECK("conv3x3_wgrad");
     const int64_t total = (int64_t)cout * cin * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw,

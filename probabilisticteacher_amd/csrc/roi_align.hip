@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
 // Backward without global atomics: one workgroup owns CG channel planes of ONE image in LDS, walks that image's
 // ROIs (rois are grouped by image), scatter-adds with LDS atomics (ds_add_f32) and writes each plane once,
 // coalesced.  HBM traffic = read dout once + write dfeat once; no pre-zeroing of dfeat needed.
-__global__ __launch_bounds__(256) void roi_align_bwd_lds_kernel(const float* __restrict__ dout,
+__global__ __launch_bounds__(512) void roi_align_bwd_lds_kernel(const float* __restrict__ dout,
                                                                 const float* __restrict__ rois,
                                                                 const int32_t* __restrict__ img_off,
                                                                 float* __restrict__ dfeat, int C, int H, int W, int P,
@@ -119,36 +119,40 @@ __global__ __launch_bounds__(256) void roi_align_bwd_lds_kernel(const float* __r
     const int n = blockIdx.y, c0 = blockIdx.x * CG;
     const int HW = H * W, PP = P * P;
     const int cg = min(CG, C - c0);
-    for (int i = threadIdx.x; i < cg * HW; i += 256) plane[i] = 0.f;
+    for (int i = threadIdx.x; i < cg * HW; i += 512) plane[i] = 0.f;
     __syncthreads();
     const int r0 = img_off[n], r1 = img_off[n + 1];
     const int items = cg * PP;
-    for (int r = r0; r < r1; ++r) {
+    const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;     // two ROIs in flight per workgroup
+    for (int r = r0 + sub; r < r1; r += 2) {
         const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, P);
         const float* ob = dout + ((size_t)r * C + c0) * PP;
-        for (int i = threadIdx.x; i < items; i += 256) {
+        const float inv_count = 1.0f / g.count;
+        const float sy = g.bh / (float)g.gh, sx = g.bw / (float)g.gw;
+        for (int i = t; i < items; i += 256) {
             const int c = i / PP, rem = i - c * PP;
             const int ph = rem / P, pw = rem - ph * P;
             float* f = plane + c * HW;
-            const float go = ob[i];
+            const float go = ob[i] * inv_count;
+            const float ybase = g.sh + (float)ph * g.bh, xbase = g.sw + (float)pw * g.bw;
             for (int iy = 0; iy < g.gh; ++iy) {
-                const float y = g.sh + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+                const float y = ybase + ((float)iy + .5f) * sy;
                 for (int ix = 0; ix < g.gw; ++ix) {
-                    const float x = g.sw + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                    const float x = xbase + ((float)ix + .5f) * sx;
                     int yl, xl, yh, xh;
                     float w1, w2, w3, w4;
                     if (!bilin(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
-                    atomicAdd(f + yl * W + xl, go * w1 / g.count);
-                    atomicAdd(f + yl * W + xh, go * w2 / g.count);
-                    atomicAdd(f + yh * W + xl, go * w3 / g.count);
-                    atomicAdd(f + yh * W + xh, go * w4 / g.count);
+                    atomicAdd(f + yl * W + xl, go * w1);
+                    atomicAdd(f + yl * W + xh, go * w2);
+                    atomicAdd(f + yh * W + xl, go * w3);
+                    atomicAdd(f + yh * W + xh, go * w4);
                 }
             }
         }
     }
     __syncthreads();
     float* dst = dfeat + ((size_t)n * C + c0) * HW;
-    for (int i = threadIdx.x; i < cg * HW; i += 256) dst[i] = plane[i];
+    for (int i = threadIdx.x; i < cg * HW; i += 512) dst[i] = plane[i];
 }
 
 }  // namespace
@@ -186,7 +190,7 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
                    "roi_align_bwd_grouped: bad args");
     hipStream_t st = (hipStream_t)s;
     const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    const size_t budget = 150 * 1024;
+    const size_t budget = 72 * 1024;      // two workgroups per CU
     if (plane_bytes > budget || r == 0) {   // map too large for LDS (or nothing to scatter): zero + atomic path
         hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)n * c * plane_bytes, st);
         if (e != hipSuccess) { ptmi_set_error("roi_align_bwd_grouped: memset failed"); return -2; }
@@ -194,7 +198,7 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
     }
     PTMI_CHECK_ARG(dout && rois, "roi_align_bwd_grouped: null buffer");
     int cg = (int)(budget / plane_bytes);
-    if (cg > 8) cg = 8;
+    if (cg > 4) cg = 4;
     if (cg > c) cg = c;
     static bool attr_set = false;
     if (!attr_set) {
@@ -202,7 +206,7 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
                                   160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(roi_align_bwd_lds_kernel, dim3(cdiv(c, cg), n), dim3(256), (size_t)cg * plane_bytes, st, dout,
+    hipLaunchKernelGGL(roi_align_bwd_lds_kernel, dim3(cdiv(c, cg), n), dim3(512), (size_t)cg * plane_bytes, st, dout,
                        rois, img_offsets, dfeat, c, h, w, pooled, scale, cg);
     PTMI_LAUNCH_CHECK("roi_align_bwd_grouped");
     return 0;
