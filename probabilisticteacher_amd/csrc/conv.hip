@@ -488,16 +488,34 @@ constexpr int WD_DY = 128 * DY_PITCH;                       // 4224 floats (mult
 constexpr int WD_X = ((32 * XP_PITCH + 63) / 64) * 64;      // 3328 floats
 constexpr int WD_STAGE = WD_DY + WD_X;
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(
+// 512 threads = 8 waves: wave w owns co sub-tile (w & 3) and tap group (w >> 2) = taps {0..4} or {5..8}, so a wave
+// carries 5 (4) accumulator tiles = 80 (64) VGPRs instead of 144 and four waves fit per SIMD (two workgroups/CU).
+template <int TAP0, int NTAP>
+__device__ __forceinline__ void wgrad_stage(const float* __restrict__ al, const float* __restrict__ bl, f32x16 (&acc)[5])
+{
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+        const float a = al[2 * kk];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const int tap = TAP0 + t, ky = tap / 3, kx = tap % 3;
+            const float b = bl[ky * PW + 2 * kk + kx];
+            acc[t] = mfma32(a, b, acc[t]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void conv3x3_wgrad_dma_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
     int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S,
     const float* __restrict__ zero_page)
 {
-    constexpr int NDY = (WD_DY + 255) / 256;                 // 17
-    constexpr int NX = WD_X / 256;                           // 13
+    constexpr int NDY = (WD_DY + 511) / 512;                 // 9
+    constexpr int NX = (WD_X + 511) / 512;                   // 7
     __shared__ __attribute__((aligned(16))) float lds[2 * WD_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_base = tid & ~63;
+    const int cw = wave & 3, tg = wave >> 2;
     int bid = blockIdx.x;
     const int s = bid % S; bid /= S;
     const int cit = bid % ciTiles;
@@ -506,9 +524,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(
     const int co0 = cot * 128, ci0 = cit * 32;
     const int nTiles = N * tilesY * tilesX;
 
-    f32x16 acc[9];
+    f32x16 acc[5];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
+    for (int t = 0; t < 5; ++t) acc[t] = (f32x16){0};
 
     auto issue = [&](int tile, int buf) {
         const int tx = tile % tilesX;
@@ -522,27 +540,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(
         float* Xd = Dd + WD_DY;
 #pragma unroll 1
         for (int i = 0; i < NDY; ++i) {
-            if (wave_base + i * 256 < WD_DY) {
-                const int idx = tid + i * 256;
+            if (wave_base + i * 512 < WD_DY) {
+                const int idx = tid + i * 512;
                 const int col = idx / DY_PITCH, p = idx - col * DY_PITCH;
                 const bool ok = p < 32 && (co0 + col) < Cout && (x0 + p) < W;
                 const float* src = ok ? dyn + (size_t)(co0 + col) * HW + p : zero_page + lane;
-                dma4(src, Dd + wave_base + i * 256);
+                dma4(src, Dd + wave_base + i * 512);
             }
         }
 #pragma unroll 1
         for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * 256;
-            const int cil = idx / XP_PITCH, rem = idx - cil * XP_PITCH;
-            const int r = rem / PW, c = rem - r * PW;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            const bool ok = cil < 32 && rem < XP_PLANE && (ci0 + cil) < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            const float* src = ok ? xn + (size_t)(ci0 + cil) * HW + (size_t)gy * W + gx : zero_page + lane;
-            dma4(src, Xd + wave_base + i * 256);
+            if (wave_base + i * 512 < WD_X) {
+                const int idx = tid + i * 512;
+                const int cil = idx / XP_PITCH, rem = idx - cil * XP_PITCH;
+                const int r = rem / PW, c = rem - r * PW;
+                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+                const bool ok = cil < 32 && rem < XP_PLANE && (ci0 + cil) < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                const float* src = ok ? xn + (size_t)(ci0 + cil) * HW + (size_t)gy * W + gx : zero_page + lane;
+                dma4(src, Xd + wave_base + i * 512);
+            }
         }
     };
 
-    const int a_off = (wave * 32 + (lane & 31)) * DY_PITCH + (lane >> 5);
+    const int a_off = (cw * 32 + (lane & 31)) * DY_PITCH + (lane >> 5);
     const int b_off = WD_DY + (lane & 31) * XP_PITCH + (lane >> 5);
 
     int tile = s, it = 0;
@@ -554,25 +574,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(
         if (tile + S < nTiles) issue(tile + S, buf ^ 1);
         const float* al = lds + buf * WD_STAGE + a_off;
         const float* bl = lds + buf * WD_STAGE + b_off;
-#pragma unroll 2
-        for (int kk = 0; kk < 16; ++kk) {
-            const float a = al[2 * kk];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap % 3;
-                const float b = bl[ky * PW + 2 * kk + kx];
-                acc[tap] = mfma32(a, b, acc[tap]);
-            }
-        }
+        if (tg == 0) wgrad_stage<0, 5>(al, bl, acc);
+        else wgrad_stage<5, 4>(al, bl, acc);
     }
     const int ci = ci0 + (lane & 31);
+    const int tap0 = tg == 0 ? 0 : 5, ntap = tg == 0 ? 5 : 4;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        float* dst = partial + ((size_t)s * 9 + tap) * Cout * Cin;
+    for (int t = 0; t < 5; ++t) {
+        if (t >= ntap) break;
+        float* dst = partial + ((size_t)s * 9 + tap0 + t) * Cout * Cin;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[tap][r];
+            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[t][r];
         }
     }
 }
@@ -594,19 +608,39 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
     }
 }
 
-// db[co] = sum_{n,p} dy[n][co][p]   (one workgroup per channel, fixed order)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
-                                                        int N, int C, int HW, int accumulate)
+// db[co] = sum_{n,p} dy[n][co][p]: stage 1 = one workgroup per (channel, image slot) -> partial[c][slot];
+// stage 2 = fixed-order sum over the slots (deterministic).
+constexpr int BG_SLOTS = 16;
+
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part,
+                                                                int N, int C, int HW)
 {
     __shared__ float sm[4];
-    const int c = blockIdx.x;
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
+    const int c = blockIdx.x, slot = blockIdx.y;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int n = slot; n < N; n += BG_SLOTS) {
         const float* p = dy + ((size_t)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) acc += p[i];
+        int i = threadIdx.x;
+        for (; i + 768 < HW; i += 1024) {
+            a0 += p[i];
+            a1 += p[i + 256];
+            a2 += p[i + 512];
+            a3 += p[i + 768];
+        }
+        for (; i < HW; i += 256) a0 += p[i];
     }
-    const float t = block_sum_256(acc, sm);
-    if (threadIdx.x == 0) db[c] = accumulate ? db[c] + t : t;
+    const float t = block_sum_256((a0 + a1) + (a2 + a3), sm);
+    if (threadIdx.x == 0) part[c * BG_SLOTS + slot] = t;
+}
+
+__global__ void bias_grad_final_kernel(const float* __restrict__ part, float* __restrict__ db, int C, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < BG_SLOTS; ++s) t += part[c * BG_SLOTS + s];
+    db[c] = accumulate ? db[c] + t : t;
 }
 
 __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -730,7 +764,8 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 {
-    return (int64_t)wgrad_splits(n, cin, cout, h, w) * 9 * cout * cin + 64;   // + zero page for the DMA kernel
+    // split-K partials + zero page for the DMA kernel + bias-gradient partials
+    return (int64_t)wgrad_splits(n, cin, cout, h, w) * 9 * cout * cin + 64 + (int64_t)cout * BG_SLOTS;
 }
 
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
@@ -745,7 +780,7 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
         float* zero_page = ws + (int64_t)S * 9 * cout * cin;
         hipError_t e = hipMemsetAsync(zero_page, 0, 64 * sizeof(float), st);
         if (e != hipSuccess) { ptmi_set_error("conv3x3_wgrad: memset failed"); return -2; }
-        hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
+        hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n, cin,
                            cout, h, w, tilesX, tilesY, coTiles, ciTiles, S, zero_page);
     } else {
         hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
@@ -757,8 +792,11 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
                        cout, cin, S, accumulate);
     PTMI_LAUNCH_CHECK("conv3x3_wgrad_reduce");
     if (db) {
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(cout), dim3(256), 0, st, dy, db, n, cout, h * w, accumulate);
-        PTMI_LAUNCH_CHECK("conv3x3_bias_grad");
+        float* part = ws + (int64_t)S * 9 * cout * cin + 64;
+        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
+        PTMI_LAUNCH_CHECK("conv3x3_bias_grad_partial");
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, part, db, cout, accumulate);
+        PTMI_LAUNCH_CHECK("conv3x3_bias_grad_final");
     }
     return 0;
 }
