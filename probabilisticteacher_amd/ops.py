@@ -284,10 +284,10 @@ class _Conv1x1(torch.autograd.Function):
             gemm(w2, dy, ci, hw, co, ci, hw, 1, 0, out=dx, batch=n, stride_a=0, stride_b=co * hw, stride_c=ci * hw,
                  ldc=hw)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((co, ci), dtype=F32, device=x.device)
-            for i in range(n):                                               # accumulate over images, fixed order
-                gemm(dy[i], x[i], co, ci, hw, hw, hw, 0, 1, out=dw, accumulate=True)
-            dw = dw.view(ctx.wshape)
+            # per-image partials in ONE batched launch, then a fixed-order sum over images
+            part = gemm(dy, x, co, ci, hw, hw, hw, 0, 1, batch=n, stride_a=co * hw, stride_b=ci * hw,
+                        stride_c=co * ci)
+            dw = colsum(part.view(n, co * ci)).view(ctx.wshape)
         if ctx.needs_input_grad[2]:
             db = torch.empty(co, dtype=F32, device=x.device)
             _lib.call("ptmi_rowsum_batched", _ptr(dy), _ptr(db), n, co, hw, 0, _stream())
