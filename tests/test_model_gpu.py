@@ -173,3 +173,89 @@ def test_run_step_matches_reference_golden():
                 close(tsd[k].flatten()[:16].cpu(), z[f"it{it}_t_head_{k}"], 1e-4, 1e-6, f"teacher head {k}")
     finally:
         sampling.set_perm_fn(None)
+
+
+def test_full_size_1333x800_backbone_and_rpn_vs_oracle():
+    """BASELINE-size parity: one synthetic 1333x800 image through the HIP VGG16 + RPN head vs the CPU oracle
+    (features rtol 2e-4 of the max, anchors bit-exact, objectness / deltas 1e-3), plus size-independent properties
+    of the proposal stage (scores sorted, boxes inside the image, NMS idempotent)."""
+    from probabilisticteacher_amd import modeling, ops
+    g = torch.Generator().manual_seed(9)
+    K = 8
+    cfg = _cfg(K, "DefaultAnchorGenerator", (0.25, 0.25))
+    ocfg = opt.Cfg(num_classes=K)
+    params = opt.golden_params(ocfg, 2)
+    model = modeling.build_model(cfg).train()
+    _load_params(model, params)
+    img = torch.randint(0, 256, (3, 800, 1333), generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        images = model.preprocess_image([{"image": img}])
+        feat = model.backbone(images.tensor)["vgg_block5"]
+        torch.set_num_threads(min(32, torch.get_num_threads()))
+        oimg = opt.preprocess_image(ocfg, [{"image": img}])
+        assert torch.equal(images.tensor.cpu(), oimg.tensor)
+        ofeat = opt.vgg_forward(params, oimg.tensor)
+        assert feat.shape == (1, 512, 50, 83)
+        scale = float(ofeat.abs().max())
+        assert float((feat.cpu() - ofeat).abs().max()) <= 2e-4 * scale, "block5 features"
+        obj, deltas = model.proposal_generator.rpn_head([feat])
+        oobj, odl = opt.rpn_head_forward(params, ofeat)
+        logits = obj[0].permute(0, 2, 3, 1).reshape(1, -1)
+        close(logits.cpu(), oobj, 1e-3, 1e-3 * float(oobj.abs().max()), "objectness")
+        d8 = deltas[0].view(1, 9, 8, 50, 83).permute(0, 3, 4, 1, 2).reshape(1, -1, 8)
+        close(d8.cpu(), odl, 1e-3, 1e-3 * float(odl.abs().max()), "anchor deltas")
+        anchors = model.proposal_generator.anchor_generator([feat])[0].tensor
+        assert torch.equal(anchors.cpu(), opt.make_anchors(ocfg, params, (50, 83), False)) and len(anchors) == 37350
+        props, _ = model.proposal_generator(images, {"vgg_block5": feat}, None, compute_loss=False)
+        p = props[0]
+        b, s = p.proposal_boxes.tensor, p.objectness_logits
+        assert 0 < len(p) <= 2000
+        assert bool((s[:-1] >= s[1:]).all()), "proposals are sorted by (rescored) score"
+        assert bool((b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 2] <= 1333).all() and (b[:, 3] <= 800).all())
+        assert bool(((b[:, 2] - b[:, 0]) > 0).all() and ((b[:, 3] - b[:, 1]) > 0).all())
+        seg = torch.tensor([0, len(p)], dtype=torch.int32, device=DEV)
+        keep, cnt = ops.nms_batched(b.contiguous(), seg, len(p), 0.7, len(p))
+        assert int(cnt[0]) == len(p) and torch.equal(keep[0].cpu().long(), torch.arange(len(p))), "NMS is idempotent"
+
+
+def test_edge_cases_empty_gt_and_no_pseudo_matches():
+    """Edge cases of the reference's control flow: an image without ground truth in the supervised branch
+    (rpn.py:435-437, roi_heads.py:238-242) and an unsupervised image whose pseudo boxes match no proposal."""
+    from probabilisticteacher_amd import modeling
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    K = 8
+    cfg = _cfg(K, "DefaultAnchorGenerator", (0.25, 0.25))
+    ocfg = opt.Cfg(num_classes=K)
+    params = opt.golden_params(ocfg, 5)
+    model = modeling.build_model(cfg).train()
+    _load_params(model, params)
+    g = torch.Generator().manual_seed(1)
+    recs, orecs = [], []
+    for i in range(2):
+        img = torch.randint(0, 256, (3, 96, 128), generator=g, dtype=torch.uint8)
+        boxes = torch.tensor([[10.0, 12.0, 70.0, 80.0]]) if i == 0 else torch.zeros((0, 4))
+        cls = torch.tensor([3]) if i == 0 else torch.zeros(0, dtype=torch.int64)
+        a, b = FreeInstances((96, 128)), opt.FreeInstances((96, 128))
+        a.gt_boxes, a.gt_classes = Boxes(boxes.clone()), cls.clone()
+        b.gt_boxes, b.gt_classes = d2.Boxes(boxes.clone()), cls.clone()
+        recs.append({"image": img, "instances": a})
+        orecs.append({"image": img, "instances": b})
+    from probabilisticteacher_amd.modeling import sampling
+    sampling.set_perm_fn(opt.SeededPerm(11))
+    try:
+        got, _, _, _ = model(recs, branch="supervised")
+    finally:
+        sampling.set_perm_fn(None)
+    ref, _, _, _ = opt.model_forward(ocfg, params, orecs, "supervised", perm_fn=opt.SeededPerm(11))
+    for k in ref:
+        close(got[k].detach().cpu(), ref[k].detach(), 2e-4, 1e-6, "empty-gt " + k)
+    sum(got.values()).backward()
+    # unsupervised with a pseudo box far away from every proposal -> no ROI survives: cls loss is NaN (0/0) exactly
+    # like the reference (fast_rcnn.py:209), the box loss too (mean of an empty tensor)
+    inst = FreeInstances((96, 128))
+    inst.pseudo_boxes = Boxes(torch.tensor([[0.0, 0.0, 1.0, 1.0]]))
+    inst.scores_logists = torch.zeros(1, K + 1)
+    inst.boxes_sigma = torch.zeros(1, 4)
+    un = [{"image": recs[0]["image"], "instances": inst}]
+    lu, _, _, _ = model(un, branch="unsupervised", danchor=True)
+    assert torch.isnan(lu["loss_cls"]) and torch.isfinite(lu["loss_rpn_cls"])
