@@ -48,7 +48,9 @@ int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, 
                               ptmi_stream_t s);
 /* epilogue: 0 = y = acc + bias;  1 = y = relu(acc + bias);  2 = y = acc (bias may be NULL);
  *           3 = y = (mask_ref[idx] > 0) ? acc : 0   (dgrad through the producer's ReLU;
- *               mask_ref has the shape of y). */
+ *               mask_ref has the shape of y);
+ *           4 = y = maxpool2x2(relu(acc + bias)), y is (n, cout, h/2, w/2): conv + F.relu_ + MaxPool2d of a
+ *               VGG block (vgg.py:66-71) in one pass, for blocks whose activations are not kept. */
 int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
                      float* y, int n, int cin, int cout, int h, int w, int epilogue,
                      ptmi_stream_t s);
@@ -65,8 +67,10 @@ int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptm
  * replaces ATen MaxPool2d(2,2) fwd/bwd at vgg.py:59,71 (floor mode).  bwd routes the gradient to
  * the first maximum of each window in (0,0),(0,1),(1,0),(1,1) order (ATen CPU semantics). */
 int ptmi_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, ptmi_stream_t s);
+/* relu_mask != 0: x is a post-ReLU activation and the result is additionally multiplied by (x > 0), i.e. the
+ * gradient w.r.t. the conv pre-activation (MaxPool2d backward + F.relu_ backward of vgg.py:66-71 in one pass). */
 int ptmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w,
-                        ptmi_stream_t s);
+                        int relu_mask, ptmi_stream_t s);
 
 /* ------------------------------------------------------------------ GEMM (N3 1x1 convs, N13 FC)
  * replaces cuBLAS Linear (D2 FastRCNNConvFCHead; fast_rcnn.py:164) and the 1x1 RPN convs.

@@ -313,6 +313,28 @@ __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
     const int px = x0 + (lane & 31);
     const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
     const int yrow = y0 + wn * 2;
+    if (epi == 4) {
+        // bias + ReLU + 2x2/2 max pool (floor mode) fused: the wave's two pixel rows are the vertical pair, the
+        // horizontal partner is lane^1; even lanes store to the pooled (H/2, W/2) tensor.  The full-resolution
+        // activation never reaches HBM (used for the frozen blocks, whose activations are not kept for backward).
+        const int OH = H >> 1, OW = W >> 1;
+        const int oy = yrow >> 1, ox = px >> 1;
+        float* yn = y + (size_t)n * Cout * OH * OW;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
+                const float b = (co < Cout) ? bias[co] : 0.f;
+                const float v0 = fmaxf((s == 0 ? acc00[r] : acc10[r]) + b, 0.f);
+                const float v1 = fmaxf((s == 0 ? acc01[r] : acc11[r]) + b, 0.f);
+                float m = fmaxf(v0, v1);
+                m = fmaxf(m, __shfl_xor(m, 1, 64));
+                if (co < Cout && !(lane & 1) && oy < OH && ox < OW) yn[((size_t)co * OH + oy) * OW + ox] = m;
+            }
+        }
+        return;
+    }
     float* yn = y + (size_t)n * Cout * HW;
     const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
 #pragma unroll
@@ -729,7 +751,9 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
                      float* y, int n, int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
-    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "conv3x3_fwd: bad epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_fwd: bad epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue != 4 || (ptmi_conv3x3_ck(cin) == 4 && conv_impl() == 2),
+                   "conv3x3_fwd: the fused pool epilogue needs the LDS-DMA kernel");
     PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
     const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);

@@ -31,7 +31,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 
 // dx[pos] = dy[window] iff pos is the FIRST maximum of its window (scan order (0,0),(0,1),(1,0),(1,1)).
 __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                   float* __restrict__ dx, int nc, int h, int w, int oh, int ow)
+                                   float* __restrict__ dx, int nc, int h, int w, int oh, int ow, int relu_mask)
 {
     const int64_t total = (int64_t)nc * h * w;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -51,7 +51,8 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
             for (int k = 1; k < 4; ++k)
                 if (v[k] > m || v[k] != v[k]) { m = v[k]; am = k; }
             const int me = (yy & 1) * 2 + (xx & 1);
-            if (me == am) g = dy[(c * oh + oy) * (int64_t)ow + ox];
+            // relu_mask: x is a post-ReLU activation; also apply d/d(pre-activation) = (x > 0) in the same pass
+            if (me == am && (!relu_mask || m > 0.f)) g = dy[(c * oh + oy) * (int64_t)ow + ox];
         }
         dx[i] = g;
     }
@@ -206,12 +207,13 @@ int ptmi_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, ptmi_str
     return 0;
 }
 
-int ptmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w, ptmi_stream_t s)
+int ptmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int h, int w, int relu_mask,
+                        ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && dy && dx && nc > 0 && h >= 2 && w >= 2, "maxpool2x2_bwd: bad args");
     const int oh = h / 2, ow = w / 2;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)nc * h * w)), dim3(256), 0, (hipStream_t)s, x, dy,
-                       dx, nc, h, w, oh, ow);
+                       dx, nc, h, w, oh, ow, relu_mask);
     PTMI_LAUNCH_CHECK("maxpool2x2_bwd");
     return 0;
 }

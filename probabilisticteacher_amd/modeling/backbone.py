@@ -48,8 +48,17 @@ class VGGBlock(nn.Module):
         self.stride = 2
 
     def forward(self, x):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            params = []
+            for i in range(self.num_convs):
+                c = getattr(self, f"conv{i + 1}")
+                params += [c.weight, c.bias]
+            return ops.vgg_block(x, self.pool, params)            # one autograd node, fused backward chain
+        fuse_pool = self.pool and not torch.is_grad_enabled()     # frozen block: full-res activation not needed
         for i in range(self.num_convs):
             c = getattr(self, f"conv{i + 1}")
+            if fuse_pool and i == self.num_convs - 1:
+                return ops.conv3x3_relu_pool_nograd(x, c.weight, c.bias)
             x = ops.conv3x3(x, c.weight, c.bias, True)
         if self.pool:
             x = ops.maxpool2x2(x)

@@ -117,6 +117,19 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     return y
 
 
+def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
+    """conv3x3 + bias + ReLU + MaxPool(2,2) in ONE kernel (epilogue 4); inference-only (no autograd state)."""
+    x = _chk(x.contiguous(), name="conv input")
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    wp = conv3x3_pack(_chk(weight.contiguous()), 0)
+    y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
+    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n):
+        _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None, _ptr(y), n, cin, cout, h,
+                  w, 4, _stream())
+    return y
+
+
 def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     dz = torch.empty_like(dy)
     if dy.numel() == 0:
@@ -183,12 +196,79 @@ class _MaxPool2x2(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
-        _lib.call("ptmi_maxpool2x2_bwd", _ptr(x), _ptr(_chk(dy.contiguous())), _ptr(dx), n * c, h, w, _stream())
+        _lib.call("ptmi_maxpool2x2_bwd", _ptr(x), _ptr(_chk(dy.contiguous())), _ptr(dx), n * c, h, w, 0, _stream())
         return dx
 
 
 def maxpool2x2(x):
     return _MaxPool2x2.apply(x)
+
+
+class _VGGBlock(torch.autograd.Function):
+    """One VGG block = k x [conv3x3 + bias + ReLU] (+ MaxPool 2x2) as a single autograd node (vgg.py:65-72).
+
+    The backward chain is fused: max-pool backward also applies the last ReLU's mask, and every dgrad launch
+    applies the mask of the producing layer's ReLU in its epilogue (epilogue 3), so no separate ReLU-backward
+    passes (read dy + read y + write dz per layer) remain inside a block."""
+
+    @staticmethod
+    def forward(ctx, x, pool: bool, *wb):
+        k = len(wb) // 2
+        acts = [_chk(x.contiguous(), name="block input")]
+        ws = []
+        for j in range(k):
+            w, b = _chk(wb[2 * j].contiguous()), _chk(wb[2 * j + 1].contiguous())
+            ws.append(w)
+            acts.append(conv3x3_raw(acts[-1], conv3x3_pack(w, 0), b, None, w.shape[0], 1))
+        out = acts[-1]
+        if pool:
+            n, c, h, wd = out.shape
+            pooled = torch.empty((n, c, h // 2, wd // 2), dtype=F32, device=out.device)
+            with _prof("maxpool_fwd"):
+                _lib.call("ptmi_maxpool2x2_fwd", _ptr(out), _ptr(pooled), n * c, h, wd, _stream())
+            out = pooled
+        ctx.k, ctx.pool = k, pool
+        ctx.save_for_backward(*acts, *ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k = ctx.k
+        saved = ctx.saved_tensors
+        acts, ws = saved[: k + 1], saved[k + 1:]
+        dout = _chk(dout.contiguous())
+        yk = acts[k]
+        if ctx.pool:
+            n, c, h, w = yk.shape
+            dz = torch.empty_like(yk)
+            _lib.call("ptmi_maxpool2x2_bwd", _ptr(yk), _ptr(dout), _ptr(dz), n * c, h, w, 1, _stream())
+        else:
+            dz = relu_bwd(dout, yk)
+        grads = [None] * (2 * k)
+        dx = None
+        for j in range(k, 0, -1):
+            xin, w = acts[j - 1], ws[j - 1]
+            n, cin, h, wd = xin.shape
+            cout = w.shape[0]
+            if ctx.needs_input_grad[2 + 2 * (j - 1)] or ctx.needs_input_grad[3 + 2 * (j - 1)]:
+                dw = torch.empty_like(w)
+                db = torch.empty(cout, dtype=F32, device=xin.device)
+                nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, wd)
+                wsb = _ws("wgrad", nws * 4, xin.device)
+                with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * wd * n):
+                    _lib.call("ptmi_conv3x3_wgrad", _ptr(xin), _ptr(dz), _ptr(dw), _ptr(db), _ptr(wsb), n, cin, cout, h,
+                              wd, 0, _stream())
+                grads[2 * (j - 1)], grads[2 * (j - 1) + 1] = dw, db
+            if j > 1:
+                dz = conv3x3_raw(dz, conv3x3_pack(w, 1), None, xin, cin, 3)      # dgrad + ReLU mask of layer j-1
+            elif ctx.needs_input_grad[0]:
+                dx = conv3x3_raw(dz, conv3x3_pack(w, 1), None, None, cin, 2)
+        return (dx, None, *grads)
+
+
+def vgg_block(x, pool: bool, params):
+    """params = [w1, b1, w2, b2, ...]."""
+    return _VGGBlock.apply(x, pool, *params)
 
 
 # ============================================================================ GEMM family

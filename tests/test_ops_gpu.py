@@ -450,3 +450,48 @@ def test_preprocess_and_shrink_paste(ops):
         diff = (out.cpu().int() - ref_rec["image"].int()).abs()
         # truncation of a float that sits within rounding of an integer may flip by 1 (FMA vs no FMA)
         assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3, "shrink_paste mismatch"
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 37, 45), (1, 128, 128, 20, 83), (1, 3, 64, 24, 33)])
+def test_conv3x3_fused_relu_pool(ops, n, cin, cout, h, w):
+    gen = g(cin + h)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    ref = F.max_pool2d(F.relu(F.conv2d(x, wt, b, padding=1)), 2, 2)
+    got = ops.conv3x3_relu_pool_nograd(x.to(DEV), wt.to(DEV), b.to(DEV))
+    close(got, ref, 1e-4, 1e-4, "fused conv+relu+pool")
+    with torch.no_grad():
+        unfused = ops.maxpool2x2(ops.conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), True))
+    assert torch.equal(got, unfused), "fused epilogue must equal conv -> pool bit for bit"
+
+
+@pytest.mark.parametrize("pool", [True, False])
+def test_vgg_block_fused_backward(ops, pool):
+    """The single-node VGG block (fused ReLU masks in dgrad / pool backward) vs stock torch autograd."""
+    gen = g(97)
+    x = torch.randn(2, 16, 22, 37, generator=gen)
+    ws = [torch.randn(24, 16, 3, 3, generator=gen) * 0.1, torch.randn(24, 24, 3, 3, generator=gen) * 0.08,
+          torch.randn(32, 24, 3, 3, generator=gen) * 0.08]
+    bs = [torch.randn(c, generator=gen) * 0.1 for c in (24, 24, 32)]
+    xr = x.clone().requires_grad_()
+    wr = [t.clone().requires_grad_() for t in ws]
+    br = [t.clone().requires_grad_() for t in bs]
+    y = xr
+    for w_, b_ in zip(wr, br):
+        y = F.relu(F.conv2d(y, w_, b_, padding=1))
+    if pool:
+        y = F.max_pool2d(y, 2, 2)
+    gy = torch.randn(y.shape, generator=gen)
+    y.backward(gy)
+    xd = x.to(DEV).requires_grad_()
+    wd = [t.to(DEV).requires_grad_() for t in ws]
+    bd = [t.to(DEV).requires_grad_() for t in bs]
+    params = [t for pair in zip(wd, bd) for t in pair]
+    yd = ops.vgg_block(xd, pool, params)
+    close(yd, y, 1e-4, 1e-4, "block fwd")
+    yd.backward(gy.to(DEV))
+    close(xd.grad, xr.grad, 1e-4, 2e-4, "block dx")
+    for i in range(3):
+        close(wd[i].grad, wr[i].grad, 1e-4, 1e-3, f"block dw{i}")
+        close(bd[i].grad, br[i].grad, 1e-4, 1e-3, f"block db{i}")
