@@ -550,36 +550,70 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_dma_kernel(
 #pragma unroll
     for (int t = 0; t < 5; ++t) acc[t] = (f32x16){0};
 
+    // Tile-independent piece descriptors, built once: bits 0..23 = element offset from the tile's base pointer,
+    // bits 24..29 = column (dY) / bits 24..25 = row, 26..31 = column (X); -1 = lane never loads (LDS pad slot,
+    // channel beyond Cout/Cin) and reads the zero page.  Requires 128*H*W < 2^24 (checked by the launcher).
+    int ddesc[NDY], xdesc[NX];
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+        const int idx = tid + i * 512;
+        const int col = idx / DY_PITCH, p = idx - col * DY_PITCH;
+        ddesc[i] = (p < 32 && (co0 + col) < Cout && idx < WD_DY) ? ((col * HW + p) | (p << 24)) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int idx = tid + i * 512;
+        const int cil = idx / XP_PITCH, rem = idx - cil * XP_PITCH;
+        const int r = rem / PW, c = rem - r * PW;
+        xdesc[i] = (cil < 32 && rem < XP_PLANE && (ci0 + cil) < Cin) ? ((cil * HW + r * W + c) | (r << 24) | (c << 26)) : -1;
+    }
+
     auto issue = [&](int tile, int buf) {
         const int tx = tile % tilesX;
         int t2 = tile / tilesX;
         const int ty = t2 % tilesY;
         const int n = t2 / tilesY;
         const int x0 = tx * TW, y0 = ty;
-        const float* dyn = dy + (size_t)n * Cout * HW + (size_t)y0 * W + x0;
-        const float* xn = x + (size_t)n * Cin * HW;
+        const float* dyn = dy + ((size_t)n * Cout + co0) * HW + (size_t)y0 * W + x0;
+        // X base points at (ci0, y0-1, x0-1); only dereferenced at offsets whose (row, col) are inside the image
+        const float* xb = x + ((size_t)n * Cin + ci0) * HW + ((ptrdiff_t)y0 - 1) * W + (x0 - 1);
         float* Dd = lds + buf * WD_STAGE;
         float* Xd = Dd + WD_DY;
-#pragma unroll 1
-        for (int i = 0; i < NDY; ++i) {
-            if (wave_base + i * 512 < WD_DY) {
-                const int idx = tid + i * 512;
-                const int col = idx / DY_PITCH, p = idx - col * DY_PITCH;
-                const bool ok = p < 32 && (co0 + col) < Cout && (x0 + p) < W;
-                const float* src = ok ? dyn + (size_t)(co0 + col) * HW + p : zero_page + lane;
-                dma4(src, Dd + wave_base + i * 512);
+        const int wv = W - x0;                                   // valid dY columns in this tile
+        const bool interior = y0 > 0 && y0 < H - 1 && x0 > 0 && (x0 + 33) <= W;
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) {
+                if (wave_base + i * 512 < WD_DY) {
+                    const int d = ddesc[i];
+                    dma4(d != -1 ? dyn + (d & 0xFFFFFF) : zero_page + lane, Dd + wave_base + i * 512);
+                }
             }
-        }
-#pragma unroll 1
-        for (int i = 0; i < NX; ++i) {
-            if (wave_base + i * 512 < WD_X) {
-                const int idx = tid + i * 512;
-                const int cil = idx / XP_PITCH, rem = idx - cil * XP_PITCH;
-                const int r = rem / PW, c = rem - r * PW;
-                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-                const bool ok = cil < 32 && rem < XP_PLANE && (ci0 + cil) < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                const float* src = ok ? xn + (size_t)(ci0 + cil) * HW + (size_t)gy * W + gx : zero_page + lane;
-                dma4(src, Xd + wave_base + i * 512);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if (wave_base + i * 512 < WD_X) {
+                    const int d = xdesc[i];
+                    dma4(d != -1 ? xb + (d & 0xFFFFFF) : zero_page + lane, Xd + wave_base + i * 512);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) {
+                if (wave_base + i * 512 < WD_DY) {
+                    const int d = ddesc[i];
+                    const bool ok = d != -1 && ((d >> 24) & 63) < wv;
+                    dma4(ok ? dyn + (d & 0xFFFFFF) : zero_page + lane, Dd + wave_base + i * 512);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                if (wave_base + i * 512 < WD_X) {
+                    const int d = xdesc[i];
+                    const int r = (d >> 24) & 3, c = (d >> 26) & 63;
+                    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+                    const bool ok = d != -1 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                    dma4(ok ? xb + (d & 0xFFFFFF) : zero_page + lane, Xd + wave_base + i * 512);
+                }
             }
         }
     };
@@ -800,7 +834,7 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
     const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
     const int S = wgrad_splits(n, cin, cout, h, w);
     hipStream_t st = (hipStream_t)s;
-    if (conv_impl() == 2) {
+    if (conv_impl() == 2 && (int64_t)128 * h * w < (1 << 24)) {
         float* zero_page = ws + (int64_t)S * 9 * cout * cin;
         hipError_t e = hipMemsetAsync(zero_page, 0, 64 * sizeof(float), st);
         if (e != hipSuccess) { ptmi_set_error("conv3x3_wgrad: memset failed"); return -2; }
