@@ -206,7 +206,7 @@ __device__ __forceinline__ void dma4(const float* g, float* lds_wave_base)
     __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 4, 0, 0);
 }
 
-template <int BM>
+template <int BM, bool PRIO>
 __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
         if (chunk + 1 < nChunks) issue(chunk + 1, buf ^ 1);
         const float* wsl = lds + buf * STAGE + a_off;
         const float* psl = lds + buf * STAGE + b_off;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
                 acc11 = mfma32(a1, b1, acc11);
             }
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
 
     const int px = x0 + (lane & 31);
@@ -799,12 +801,13 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     hipStream_t st = (hipStream_t)s;
     if (CK == 4 && conv_impl() == 2) {
         const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
-        if (BM == 128)
-            hipLaunchKernelGGL((conv3x3_dma_kernel<128>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout, h,
-                               w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
-        else
-            hipLaunchKernelGGL((conv3x3_dma_kernel<64>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout, h,
-                               w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
+        static int prio = -1;
+        if (prio < 0) { const char* e = getenv("PTMI_CONV_PRIO"); prio = (e && e[0] == '1') ? 1 : 0; }
+#define LDMA(BM_, P_) hipLaunchKernelGGL((conv3x3_dma_kernel<BM_, P_>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, \
+                                         cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page)
+        if (BM == 128) { if (prio) LDMA(128, true); else LDMA(128, false); }
+        else { if (prio) LDMA(64, true); else LDMA(64, false); }
+#undef LDMA
         PTMI_LAUNCH_CHECK("conv3x3_fwd(dma)");
         return 0;
     }
