@@ -95,3 +95,28 @@ def test_structures_and_sampler():
         sampling.set_perm_fn(None)
     rp, rn = d2.subsample_labels(labels, 4, 0.5, 0, opt.SeededPerm(3))
     assert torch.equal(pos, rp) and torch.equal(neg, rn)
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    """modelTeacher.* / modelStudent.* key layout (ts_ensemble.py:20-29) survives a save -> load round trip."""
+    import types
+    from probabilisticteacher_amd import checkpoint
+    from probabilisticteacher_amd.engine.flat import FlatParams
+    from probabilisticteacher_amd.modeling import EnsembleTSModel
+    torch.manual_seed(0)
+    s, t = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
+    tr = types.SimpleNamespace(model=s, model_teacher=t, ensem_ts_model=EnsembleTSModel(t, s), iter=7, start_iter=0,
+                               student=FlatParams(s), _first_step=False)
+    tr.momentum_buf = torch.arange(tr.student.n_trainable, dtype=torch.float32)
+    p = str(tmp_path / "model_0000006.pth")
+    checkpoint.save_checkpoint(tr, p)
+    raw = torch.load(p)
+    assert sorted(raw["model"]) == ["modelStudent.bias", "modelStudent.weight", "modelTeacher.bias", "modelTeacher.weight"]
+    want = {k: v.clone() for k, v in tr.ensem_ts_model.state_dict().items()}
+    with torch.no_grad():
+        for v in tr.ensem_ts_model.state_dict().values():
+            v.zero_()
+    tr.iter, tr.momentum_buf = 0, torch.zeros_like(tr.momentum_buf)
+    checkpoint.load_checkpoint(tr, p)
+    assert all(torch.equal(v, want[k]) for k, v in tr.ensem_ts_model.state_dict().items())
+    assert tr.iter == 7 and float(tr.momentum_buf[-1]) == tr.student.n_trainable - 1
