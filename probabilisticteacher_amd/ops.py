@@ -388,8 +388,12 @@ class _ROIAlign(torch.autograd.Function):
         r = rois.shape[0]
         out = torch.empty((r, c, pooled, pooled), dtype=F32, device=feat.device)
         with _prof("roi_align_fwd"):
-            _lib.call("ptmi_roi_align_fwd", _ptr(feat), _ptr(rois), _ptr(out), n, c, h, w, r, pooled, float(scale),
-                      _stream())
+            if img_offsets is not None:
+                _lib.call("ptmi_roi_align_fwd_grouped", _ptr(feat), _ptr(rois), _ptr(_chk(img_offsets, torch.int32)),
+                          _ptr(out), n, c, h, w, r, pooled, float(scale), _stream())
+            else:
+                _lib.call("ptmi_roi_align_fwd", _ptr(feat), _ptr(rois), _ptr(out), n, c, h, w, r, pooled, float(scale),
+                          _stream())
         ctx.save_for_backward(rois, img_offsets)
         ctx.meta = (n, c, h, w, pooled, float(scale))
         return out

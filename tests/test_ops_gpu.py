@@ -174,7 +174,9 @@ def test_roi_align(ops):
     rs = rois[order]
     offs = torch.tensor([0, int((rs[:, 0] == 0).sum()), len(rs)], dtype=torch.int32, device=DEV)
     fd2 = feat.to(DEV).requires_grad_()
-    ops.roi_align(fd2, rs.to(DEV), 7, 1 / 16, offs).backward(gy[order].to(DEV))
+    out2 = ops.roi_align(fd2, rs.to(DEV), 7, 1 / 16, offs)
+    assert torch.equal(out2, out[order.to(DEV)]), "grouped (LDS-plane) forward must equal the gather kernel bit for bit"
+    out2.backward(gy[order].to(DEV))
     close(fd2.grad, fr.grad, 1e-4, 1e-4, "roi_align grouped bwd")
 
 
