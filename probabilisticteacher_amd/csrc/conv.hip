@@ -364,6 +364,129 @@ __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ forward, register-streamed
+// Experimental third pipeline (PTMI_CONV_IMPL=3): no LDS, no barriers.  f32 MFMA is so slow (64 cycles per
+// 32x32x2) that a wave needs only four operand dwords per 256 MFMA cycles, so each wave streams its A (packed
+// weights, two 128-B rows per load) and B (32 consecutive pixels of two input channels per load) fragments
+// straight from L1/L2 into VGPRs with a 6-step software pipeline; the hardware scoreboard (counted vmcnt emitted
+// by the compiler) orders loads against MFMAs.  Waves never synchronise with each other.
+template <int BM, bool BORDER>
+__device__ __forceinline__ void direct_mainloop(const float* __restrict__ wrow, const float* __restrict__ xb0,
+                                                const float* __restrict__ xb1, const float* __restrict__ zero_lane,
+                                                int nChunks, int HW, int W, int Cin, bool row_ok00, bool row_ok01,
+                                                bool row_ok02, bool row_ok03, unsigned long long cm0,
+                                                unsigned long long cm1, unsigned long long cm2, int lane,
+                                                f32x16& acc00, f32x16& acc01, f32x16& acc10, f32x16& acc11)
+{
+    constexpr int D = 6, STEPS = 18;
+    float ra0[D], ra1[D], rb0[D], rb1[D];
+    const int half = lane >> 5;
+    // rows touched by pixel row q with tap ky: index q + ky  in {0,1,2,3} -> row_ok0{q+ky}
+    auto rowok = [&](int qk) { return qk == 0 ? row_ok00 : (qk == 1 ? row_ok01 : (qk == 2 ? row_ok02 : row_ok03)); };
+    auto colok = [&](int kx) { return ((kx == 0 ? cm0 : (kx == 1 ? cm1 : cm2)) >> lane) & 1ull; };
+    auto load = [&](int chunk, int st, int slot) {
+        const int tap = st >> 1, j = st & 1, ky = tap / 3, kx = tap % 3;
+        const float* a = wrow + ((size_t)chunk * STEPS + st) * 2 * BM;
+        ra0[slot] = a[0];
+        ra1[slot] = a[32];
+        const size_t boff = (size_t)(chunk * 4 + 2 * j) * HW + ky * W + kx;
+        if (BORDER) {
+            const bool cok = colok(kx) && (chunk * 4 + 2 * j + half) < Cin;
+            rb0[slot] = *((cok && rowok(0 + ky)) ? xb0 + boff : zero_lane);
+            rb1[slot] = *((cok && rowok(1 + ky)) ? xb1 + boff : zero_lane);
+        } else {
+            rb0[slot] = xb0[boff];
+            rb1[slot] = xb1[boff];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s) load(0, s, s);
+    for (int chunk = 0; chunk < nChunks; ++chunk) {
+        const bool more = chunk + 1 < nChunks;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int slot = st % D;
+            acc00 = mfma32(ra0[slot], rb0[slot], acc00);
+            acc01 = mfma32(ra0[slot], rb1[slot], acc01);
+            acc10 = mfma32(ra1[slot], rb0[slot], acc10);
+            acc11 = mfma32(ra1[slot], rb1[slot], acc11);
+            if (st + D < STEPS) load(chunk, st + D, slot);
+            else if (more) load(chunk + 1, st + D - STEPS, slot);
+        }
+    }
+}
+
+template <int BM>
+__global__ __launch_bounds__(256, 3) void conv3x3_direct_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
+    int tilesX, int tilesY, int coTiles, int nChunks, int epi, const float* __restrict__ zero_page)
+{
+    using C = FwdCfg<BM>;
+    constexpr int TH = C::TH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    const int cot = bid % coTiles;
+    int pt = bid / coTiles;
+    const int tx = pt % tilesX;
+    pt /= tilesX;
+    const int ty = pt % tilesY;
+    const int n = pt / tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int HW = H * W;
+    const int wm = (BM == 128) ? (wave >> 1) : 0;
+    const int wn = (BM == 128) ? (wave & 1) : wave;
+    const int yrow = y0 + wn * 2;
+
+    const float* wrow = wp + (size_t)cot * nChunks * (9 * 4 * BM) + (lane >> 5) * BM + wm * 64 + (lane & 31);
+    const float* xn = x + (size_t)n * Cin * HW + (size_t)(lane >> 5) * HW;
+    // pointers at tap (ky,kx) = (0,0) of pixel rows q = 0,1; only dereferenced where the tap is inside the image
+    const float* xb0 = xn + ((ptrdiff_t)yrow - 1) * W + (x0 - 1) + (lane & 31);
+    const float* xb1 = xb0 + W;
+    const float* zero_lane = zero_page + lane;
+    const bool r0 = (yrow - 1) >= 0 && (yrow - 1) < H, r1 = yrow < H, r2 = (yrow + 1) < H, r3 = (yrow + 2) < H;
+    const int colx = x0 - 1 + (lane & 31);
+    const unsigned long long cm0 = __ballot(colx >= 0 && colx < W), cm1 = __ballot(colx + 1 < W),
+                             cm2 = __ballot(colx + 2 < W);
+    const bool interior = r0 && r3 && x0 >= 1 && (x0 + 33) <= W && (Cin & 3) == 0;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    if (interior)
+        direct_mainloop<BM, false>(wrow, xb0, xb1, zero_lane, nChunks, HW, W, Cin, r0, r1, r2, r3, cm0, cm1, cm2, lane,
+                                   acc00, acc01, acc10, acc11);
+    else
+        direct_mainloop<BM, true>(wrow, xb0, xb1, zero_lane, nChunks, HW, W, Cin, r0, r1, r2, r3, cm0, cm1, cm2, lane,
+                                  acc00, acc01, acc10, acc11);
+
+    const int px = x0 + (lane & 31);
+    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
+    float* yn = y + (size_t)n * Cout * HW;
+    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
+            if (co >= Cout) continue;
+            const float b = (epi <= 1) ? bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int yy = yrow + q;
+                if (yy >= H || px >= W) continue;
+                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
+                const size_t o = (size_t)co * HW + (size_t)yy * W + px;
+                if (epi <= 1) {
+                    v += b;
+                    if (epi == 1) v = fmaxf(v, 0.f);
+                } else if (epi == 3) {
+                    v = (mn[o] > 0.f) ? v : 0.f;
+                }
+                yn[o] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ weight pack
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int wCout,
                                     int wCin, int mode, int BM, int CK, int coTiles, int nChunks)
@@ -729,7 +852,7 @@ int conv_impl()
     static int impl = -1;
     if (impl < 0) {
         const char* e = getenv("PTMI_CONV_IMPL");
-        impl = (e && e[0] == '1') ? 1 : 2;
+        impl = (e && e[0] == '1') ? 1 : ((e && e[0] == '3') ? 3 : 2);
     }
     return impl;
 }
@@ -759,7 +882,7 @@ int ptmi_conv3x3_ck(int cin)
         forced = (e && (e[0] == '4' || e[0] == '8')) ? (e[0] - '0') : 0;
     }
     if (forced) return forced;
-    return (cin <= 4 || conv_impl() == 2) ? 4 : 8;
+    return (cin <= 4 || conv_impl() >= 2) ? 4 : 8;
 }
 
 int64_t ptmi_conv3x3_packed_floats(int cin, int cout)
@@ -788,7 +911,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_fwd: bad epilogue %d", epilogue);
-    PTMI_CHECK_ARG(epilogue != 4 || (ptmi_conv3x3_ck(cin) == 4 && conv_impl() == 2),
+    PTMI_CHECK_ARG(epilogue != 4 || (ptmi_conv3x3_ck(cin) == 4 && conv_impl() >= 2),
                    "conv3x3_fwd: the fused pool epilogue needs the LDS-DMA kernel");
     PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
@@ -799,7 +922,21 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     PTMI_CHECK_ARG(blocks < (1ll << 31), "conv3x3_fwd: grid too large");
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)s;
-    if (CK == 4 && conv_impl() == 2) {
+    // register-streamed kernel: everywhere with PTMI_CONV_IMPL=3 (A/B experiments: slower than LDS-DMA on the big
+    // layers, 66-80 vs 115-131 TF/s) and by default for the 3-channel stem, whose K = 36 loop is too short to
+    // amortise the LDS pipeline's prologue (25 vs 18 TF/s; that layer is HBM-write bound)
+    if (CK == 4 && (conv_impl() == 3 || (conv_impl() == 2 && cin <= 4)) && epilogue != 4) {
+        const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
+        if (BM == 128)
+            hipLaunchKernelGGL((conv3x3_direct_kernel<128>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
+                               h, w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
+        else
+            hipLaunchKernelGGL((conv3x3_direct_kernel<64>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
+                               h, w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
+        PTMI_LAUNCH_CHECK("conv3x3_fwd(direct)");
+        return 0;
+    }
+    if (CK == 4 && conv_impl() >= 2) {
         const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
         static int prio = -1;
         if (prio < 0) { const char* e = getenv("PTMI_CONV_PRIO"); prio = (e && e[0] == '1') ? 1 : 0; }
@@ -837,7 +974,7 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
     const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
     const int S = wgrad_splits(n, cin, cout, h, w);
     hipStream_t st = (hipStream_t)s;
-    if (conv_impl() == 2 && (int64_t)128 * h * w < (1 << 24)) {
+    if (conv_impl() >= 2 && (int64_t)128 * h * w < (1 << 24)) {
         float* zero_page = ws + (int64_t)S * 9 * cout * cin;
         hipError_t e = hipMemsetAsync(zero_page, 0, 64 * sizeof(float), st);
         if (e != hipSuccess) { ptmi_set_error("conv3x3_wgrad: memset failed"); return -2; }
