@@ -206,20 +206,21 @@ __device__ __forceinline__ void dma4(const float* g, float* lds_wave_base)
     __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 4, 0, 0);
 }
 
-template <int BM, bool PRIO>
-__global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
+template <int BM, bool PRIO, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_dma_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
     int tilesX, int tilesY, int coTiles, int nChunks, int epi, const float* __restrict__ zero_page)
 {
-    using C = FwdCfg<BM>;
     constexpr int CK = 4;
-    constexpr int TH = C::TH, PLANE = C::PLANE;
+    constexpr int NT = 64 * NWAVE;
+    constexpr int WN = NWAVE / (BM / 64);            // wave columns (pixel row pairs) per workgroup
+    constexpr int TH = 2 * WN, PLANE = (TH + 2) * PW;
     constexpr int WS = 9 * CK * BM;
     constexpr int PS = CK * PLANE;
     constexpr int WS4 = WS / 4;
-    constexpr int NW4 = (WS4 + 255) / 256;
-    constexpr int NP = (PS + 255) / 256;
+    constexpr int NW4 = (WS4 + NT - 1) / NT;
+    constexpr int NP = (PS + NT - 1) / NT;
     constexpr int STAGE = WS + ((PS + 63) / 64) * 64;       // floats per buffer (patch padded to a wave multiple)
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
 
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
     unsigned pvalid = 0;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-        const int idx = tid + i * 256;
+        const int idx = tid + i * NT;
         poff[i] = 0;
         if (idx < PS) {
             const int ci = idx / PLANE, rem = idx - ci * PLANE;
@@ -260,26 +261,26 @@ __global__ __launch_bounds__(256, 3) void conv3x3_dma_kernel(
         const float* wsrc = wbase + (size_t)chunk * WS;
 #pragma unroll
         for (int i = 0; i < NW4; ++i) {
-            const int idx = tid + i * 256;                       // float4 index
-            if (wave_base + i * 256 < WS4) {                     // wave-uniform guard (WS4 is a multiple of 64)
-                dma16(wsrc + (size_t)idx * 4, Wd + (size_t)(wave_base + i * 256) * 4);
+            const int idx = tid + i * NT;                       // float4 index
+            if (wave_base + i * NT < WS4) {                     // wave-uniform guard (WS4 is a multiple of 64)
+                dma16(wsrc + (size_t)idx * 4, Wd + (size_t)(wave_base + i * NT) * 4);
             }
         }
         const int c0 = chunk * CK;
         const float* xc = xn + (size_t)c0 * HW;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * 256;
-            if (wave_base + i * 256 < PS) {                      // wave-uniform: whole wave beyond the patch skips
+            const int idx = tid + i * NT;
+            if (wave_base + i * NT < PS) {                      // wave-uniform: whole wave beyond the patch skips
                 const bool ok = idx < PS && ((pvalid >> i) & 1u) && (c0 + idx / PLANE) < Cin;
                 const float* src = ok ? xc + poff[i] : zero_page + (lane & 63);
-                dma4(src, Pd + wave_base + i * 256);
+                dma4(src, Pd + wave_base + i * NT);
             }
         }
     };
 
-    const int wm = (BM == 128) ? (wave >> 1) : 0;
-    const int wn = (BM == 128) ? (wave & 1) : wave;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
     const int a_off = wm * 64 + (lane & 31) + (lane >> 5) * BM;
     const int b_off = WS + (lane >> 5) * PLANE + (wn * 2) * PW + (lane & 31);
 
@@ -916,7 +917,11 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
     const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
-    const int TH = BM == 128 ? 4 : 8;
+    static int w8 = -1;
+    if (w8 < 0) { const char* e = getenv("PTMI_CONV_W8"); w8 = e ? (e[0] - '0') : 2; }
+    // 8-wave workgroups (8 rows x 32 cols per 128 channels) share one weight slab among twice the pixels
+    const bool use8 = BM == 128 && CK == 4 && conv_impl() == 2 && cin > 4 && (w8 == 1 || (w8 == 2 && h >= 200));   // A/B: +3.5% at 400x666, -3.5% at 100x166 (row-tile waste)
+    const int TH = (BM == 128 && !use8) ? 4 : 8;
     const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
     const int64_t blocks = (int64_t)n * tilesX * tilesY * coTiles;
     PTMI_CHECK_ARG(blocks < (1ll << 31), "conv3x3_fwd: grid too large");
@@ -940,10 +945,12 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
         const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
         static int prio = -1;
         if (prio < 0) { const char* e = getenv("PTMI_CONV_PRIO"); prio = (e && e[0] == '1') ? 1 : 0; }
-#define LDMA(BM_, P_) hipLaunchKernelGGL((conv3x3_dma_kernel<BM_, P_>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, \
-                                         cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page)
-        if (BM == 128) { if (prio) LDMA(128, true); else LDMA(128, false); }
-        else { if (prio) LDMA(64, true); else LDMA(64, false); }
+#define LDMA(BM_, P_, NW_) hipLaunchKernelGGL((conv3x3_dma_kernel<BM_, P_, NW_>), grid, dim3(64 * NW_), 0, st, x, wp, bias, \
+                                              mask_ref, y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue, \
+                                              zero_page)
+        if (BM == 128 && use8) LDMA(128, false, 8);
+        else if (BM == 128) { if (prio) LDMA(128, true, 4); else LDMA(128, false, 4); }
+        else { if (prio) LDMA(64, true, 4); else LDMA(64, false, 4); }
 #undef LDMA
         PTMI_LAUNCH_CHECK("conv3x3_fwd(dma)");
         return 0;
