@@ -773,6 +773,226 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_dma_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ wgrad, buffer-DMA pipeline
+// Third-generation wgrad main loop (default).  Measured with clock64() probes (tools/exp_wgrad_timing.py): in the
+// kernel above a wave spends as long issuing its 16 dword DMAs per stage (address VALU work that has to win issue
+// slots against three MFMA-streaming waves) as it spends in its MFMA block.  This kernel removes that work:
+//   * DMAs are `buffer_load_dwordx4 ... lds` (raw buffer -> LDS, 16 B per lane): the per-lane byte offset is a
+//     loop-invariant VGPR, the tile origin lives in the (scalar) buffer descriptor, and lanes whose piece is
+//     padding / outside the image carry offset 0xFFFFFFFF, which the buffer range check turns into zeros without
+//     touching memory.  4-5 DMA instructions per wave per stage instead of 16, no per-DMA VALU in the common case.
+//   * the MFMA k index is permuted (lane half h, step j <-> pixel 16h + j) so that every lane's A and B operands
+//     are *contiguous* in LDS: 4 + 2 x 6 wide LDS reads per stage instead of 88 ds_read_b32, and the B row is
+//     reused across the three kx taps from registers.
+//   * pitches are odd multiples of 16 B (36 / 124 floats), conflict-free for ds_read_b128.
+// LDS column m of an X row holds image column x0 - 4 + m, so the left halo is a whole (invalid) 16-B piece; pieces
+// that straddle the right image edge are loaded as they lie and the stale lanes are zeroed in registers (only in
+// the right-edge tile of each row).
+constexpr int WB_DYP = 36;                  // dY row pitch: 8 data pieces + 1 pad piece
+constexpr int WB_DY = 128 * WB_DYP;         // 4608 floats = 1152 pieces (18 waves' worth)
+constexpr int WB_XROW = 40;                 // X row pitch: 10 pieces = image columns x0-4 .. x0+35
+constexpr int WB_XPL = 124;                 // X plane pitch: 3 rows + 1 pad piece = 31 pieces
+constexpr int WB_X = 1024 * 4;              // 32 planes x 31 pieces = 992 pieces, rounded to 16 waves' worth
+constexpr int WB_STAGE = WB_DY + WB_X;      // 8704 floats = 34 KB; double buffered, two workgroups per CU
+
+typedef __attribute__((address_space(3))) void lds_void_b_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
+typedef __attribute__((address_space(3))) float lds_f32_t;
+__device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t r, unsigned voff, float* lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_b_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
+}
+
+template <int G>
+__device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, const float* __restrict__ bl,
+                                                f32x16 (&acc)[G == 0 ? 5 : 4])
+{
+    constexpr int TAP0 = G == 0 ? 0 : 5, TAP1 = G == 0 ? 5 : 9;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {                   // pixels 16h + 8*hf + j, j = 0..7
+        float a[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(al + 8 * hf + 4 * t);
+            a[4 * t] = v.x; a[4 * t + 1] = v.y; a[4 * t + 2] = v.z; a[4 * t + 3] = v.w;
+        }
+#pragma unroll
+        for (int ky = (G == 0 ? 0 : 1); ky < (G == 0 ? 2 : 3); ++ky) {
+            // image columns x0 + 16h + 8hf - 1 .. + 8 -> v[0..9]: two aligned 16-B reads and the two end words.
+            // volatile + LDS address space keep the reads as written (the optimiser otherwise narrows the 16-B
+            // reads to the lanes used and re-pairs the remains into 8-B reads).
+            float v[10];
+            const float* br = bl + ky * WB_XROW + 8 * hf + 4;
+            v[0] = *(const volatile lds_f32_t*)(br - 1);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x4 q = *(const volatile lds_f32x4_t*)(br + 4 * t);
+                v[1 + 4 * t] = q[0]; v[2 + 4 * t] = q[1]; v[3 + 4 * t] = q[2]; v[4 + 4 * t] = q[3];
+            }
+            v[9] = *(const volatile lds_f32_t*)(br + 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int tap = ky * 3 + kx;
+                    if (tap >= TAP0 && tap < TAP1) acc[tap - TAP0] = mfma32(a[j], v[j + kx], acc[tap - TAP0]);
+                }
+            }
+        }
+    }
+}
+
+// one tap group's whole life: descriptors, stage loop, partial store.  Instantiated twice and selected by a
+// wave-uniform branch so that each group gets its own register allocation (5 or 4 accumulator tiles).
+template <int G>
+__device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restrict__ x, const float* __restrict__ dy,
+                                               float* __restrict__ partial, int N, int Cin, int Cout, int H, int W,
+                                               int tilesX, int tilesY, int ciTiles, int S, int wave, int lane)
+{
+    constexpr int NT = G == 0 ? 5 : 4;
+    const int cw = wave & 3;
+    int bid = blockIdx.x;
+    const int s = bid % S; bid /= S;
+    const int cit = bid % ciTiles;
+    const int cot = bid / ciTiles;
+    const int HW = H * W;
+    const int co0 = cot * 128, ci0 = cit * 32;
+    const int nTiles = N * tilesY * tilesX;
+    const char* x_end = (const char*)(x + (size_t)N * Cin * HW);
+    const char* dy_end = (const char*)(dy + (size_t)N * Cout * HW);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x16){0};
+
+    // Loop-invariant piece descriptors.  dY: instruction i covers pieces (i*8 + wave)*64 + lane; piece = row*9 + q.
+    // X: pieces (i*8 + wave)*64 + lane; piece = plane*31 + r*10 + q.  Byte offsets from the tile's base pointer,
+    // 0xFFFFFFFF = never loaded.  dqp / xrqp keep the pieces' column (and row) for the per-tile validity test.
+    unsigned dvoff[3], xvoff[2];
+    unsigned dqp = 0, xrqp = 0;          // packed per piece: dY column (6 bits); X row (2 bits) | column + 4 (6 bits)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int pc = (i * 8 + wave) * 64 + lane;
+        const int row = pc / 9, q = pc - row * 9;
+        const bool ok = pc < 1152 && q < 8 && (co0 + row) < Cout;
+        dvoff[i] = ok ? (unsigned)(row * HW + 4 * q) * 4u : 0xFFFFFFFFu;
+        dqp |= (unsigned)(4 * q) << (8 * i);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pc = (i * 8 + wave) * 64 + lane;
+        const int pl = pc / 31, rem = pc - pl * 31;
+        const int r = rem / 10, q = rem - r * 10;
+        const bool ok = pc < 992 && rem < 30 && (ci0 + pl) < Cin;
+        xvoff[i] = ok ? (unsigned)(pl * HW + r * W + 4 * q) * 4u : 0xFFFFFFFFu;
+        xrqp |= ((unsigned)(4 * q) | ((unsigned)r << 6)) << (8 * i);
+    }
+
+    // tile walk: tile = s, s + S, ... decomposed once into (n, ty, tx) and advanced with carries (no divisions)
+    int tx = s % tilesX, ty = (s / tilesX) % tilesY, n = s / (tilesX * tilesY);
+    const int sx = S % tilesX, sy = (S / tilesX) % tilesY, sn = S / (tilesX * tilesY);
+
+    auto issue = [&](int n_, int ty_, int tx_, int buf) {
+        const int x0 = tx_ * TW, y0 = ty_;
+        const float* dyn = dy + ((size_t)n_ * Cout + co0) * HW + (size_t)y0 * W + x0;
+        const float* xb = x + ((size_t)n_ * Cin + ci0) * HW + ((ptrdiff_t)y0 - 1) * W + (x0 - 4);
+        const long long drem = dy_end - (const char*)dyn, xrem = x_end - (const char*)xb;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)dyn, 0, (int)(drem > 0xFFFFFFFEll ? 0xFFFFFFFEll : drem), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)xb, 0, (int)(xrem > 0xFFFFFFFEll ? 0xFFFFFFFEll : xrem), 0x00020000);
+        float* Dd = lds + buf * WB_STAGE + wave * 256;
+        float* Xd = lds + buf * WB_STAGE + WB_DY + wave * 256;
+        const int wv = W - x0;                                   // valid columns right of x0
+        const bool plain = y0 > 0 && y0 < H - 1 && x0 > 0 && wv >= 36;
+        if (plain) {
+            bdma16(rd, dvoff[0], Dd);
+            bdma16(rd, dvoff[1], Dd + 8 * 256);
+            if (wave < 2) bdma16(rd, dvoff[2], Dd + 16 * 256);
+            bdma16(rx, xvoff[0], Xd);
+            bdma16(rx, xvoff[1], Xd + 8 * 256);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q4 = (dqp >> (8 * i)) & 63;
+                if (i < 2 || wave < 2) bdma16(rd, q4 < wv ? dvoff[i] : 0xFFFFFFFFu, Dd + i * 8 * 256);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int gy = y0 - 1 + (int)((xrqp >> (8 * i + 6)) & 3);
+                const int q4 = (int)((xrqp >> (8 * i)) & 63) - 4;
+                const bool ok = gy >= 0 && gy < H && (x0 + q4) >= 0 && q4 < wv;
+                bdma16(rx, ok ? xvoff[i] : 0xFFFFFFFFu, Xd + i * 8 * 256);
+            }
+        }
+    };
+
+    const int h16 = (lane >> 5) * 16;
+    const int a_off = (cw * 32 + (lane & 31)) * WB_DYP + h16;
+    const int b_off = WB_DY + (lane & 31) * WB_XPL + h16;       // LDS column 16h <-> image column x0 + 16h - 4
+
+    int tile = s, it = 0;
+    if (tile < nTiles) issue(n, ty, tx, 0);
+    for (; tile < nTiles; tile += S, ++it) {
+        const int buf = it & 1;
+        const int wv = W - tx * TW;                              // valid columns of this stage's tile
+        int ntx = tx + sx, nty = ty + sy, nn = n + sn;
+        if (ntx >= tilesX) { ntx -= tilesX; ++nty; }
+        if (nty >= tilesY) { nty -= tilesY; ++nn; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wv < 33) {
+            // right-edge tile: the pieces this lane loaded that straddle the image edge carry the next row's
+            // first pixels in their tail; zero those LDS words (own pieces only, so no barrier is needed first)
+            float* Db = lds + buf * WB_STAGE + (wave * 64 + lane) * 4;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q4 = (dqp >> (8 * i)) & 63;
+                if ((i < 2 || wave < 2) && q4 < wv && q4 + 4 > wv && dvoff[i] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (q4 + e >= wv) Db[i * 8 * 256 + e] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q4 = (int)((xrqp >> (8 * i)) & 63) - 4;
+                if (q4 < wv && q4 + 4 > wv && xvoff[i] != 0xFFFFFFFFu) {
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (q4 + e >= wv) Db[WB_DY + i * 8 * 256 + e] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (tile + S < nTiles) issue(nn, nty, ntx, buf ^ 1);
+        wgrad_stage_buf<G>(lds + buf * WB_STAGE + a_off, lds + buf * WB_STAGE + b_off, acc);
+        tx = ntx; ty = nty; n = nn;
+    }
+    const int ci = ci0 + (lane & 31);
+    constexpr int tap0 = G == 0 ? 0 : 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        float* dst = partial + ((size_t)s * 9 + tap0 + t) * Cout * Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 4) void conv3x3_wgrad_buf_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
+    int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * WB_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4) wgrad_buf_body<0>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, wave, lane);
+    else wgrad_buf_body<1>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, wave, lane);
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
                                     int Cin, int S, int accumulate)
 {
@@ -854,6 +1074,17 @@ int conv_impl()
     if (impl < 0) {
         const char* e = getenv("PTMI_CONV_IMPL");
         impl = (e && e[0] == '1') ? 1 : ((e && e[0] == '3') ? 3 : 2);
+    }
+    return impl;
+}
+
+// 3 = buffer-DMA wgrad (default); 2 = global_load_lds dword pipeline (PTMI_WGRAD_IMPL=2)
+int wgrad_impl()
+{
+    static int impl = -1;
+    if (impl < 0) {
+        const char* e = getenv("PTMI_WGRAD_IMPL");
+        impl = (e && e[0] == '2') ? 2 : 3;
     }
     return impl;
 }
@@ -981,7 +1212,10 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
     const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
     const int S = wgrad_splits(n, cin, cout, h, w);
     hipStream_t st = (hipStream_t)s;
-    if (conv_impl() >= 2 && (int64_t)128 * h * w < (1 << 24)) {
+    if (conv_impl() >= 2 && wgrad_impl() == 3 && (int64_t)128 * h * w < (1 << 28)) {
+        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n, cin,
+                           cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);
+    } else if (conv_impl() >= 2 && (int64_t)128 * h * w < (1 << 24)) {
         float* zero_page = ws + (int64_t)S * 9 * cout * cin;
         hipError_t e = hipMemsetAsync(zero_page, 0, 64 * sizeof(float), st);
         if (e != hipSuccess) { ptmi_set_error("conv3x3_wgrad: memset failed"); return -2; }

@@ -46,6 +46,12 @@ def close(a, b, rtol, atol, what=""):
     (1, 128, 256, 13, 33, False),   # no relu
     (1, 256, 512, 9, 83, True),     # W=83 as in the 1333x800 block5 map
     (1, 20, 70, 11, 17, True),      # channel counts that are not multiples of the tiles
+    (1, 32, 128, 5, 166, True),     # W=166 / 333: right-edge tiles whose 16-B pieces straddle the image edge
+    (2, 32, 128, 3, 333, False),
+    (1, 32, 128, 7, 32, True),      # exactly one tile per row
+    (1, 32, 128, 6, 36, True),      # last tile 4 wide
+    (3, 32, 64, 4, 3, True),        # narrower than one 16-B piece
+    (1, 40, 130, 1, 70, True),      # a single row: top and bottom halo at once
 ])
 def test_conv3x3_fwd_bwd(ops, n, cin, cout, h, w, relu):
     gen = g(n * 1000 + cin + cout + h)
