@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_mfma_kernel(
 // (4-B pieces) whose out-of-image / padded-channel lanes read the zero page appended to the packed weights.
 // ~90 VGPRs and 43 KB LDS => three workgroups per CU, none of them holding staging registers.
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) void lds_void_b_t;
 typedef __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base)
@@ -353,6 +355,221 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_dma_
                 if (yy >= H || px >= W) continue;
                 float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
                 const size_t o = (size_t)co * HW + (size_t)yy * W + px;
+                if (epi <= 1) {
+                    v += b;
+                    if (epi == 1) v = fmaxf(v, 0.f);
+                } else if (epi == 3) {
+                    v = (mn[o] > 0.f) ? v : 0.f;
+                }
+                yn[o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward, buffer-DMA pipeline
+// Default forward / dgrad kernel.  Same K loop as conv3x3_dma_kernel (4-channel chunks, double-buffered LDS, one
+// barrier per chunk, 72 MFMAs per wave per chunk) with two changes that came out of clock64() probes of that
+// kernel (tools/exp_conv_timing.py: the main loop already keeps the MFMA pipe ~93-100 % busy; the losses are the
+// MFMAs spent on pixels outside the image and the VALU work of the DMA issue):
+//   * operands arrive through `buffer_load_dwordx4 ... lds`: per-lane byte offsets are loop invariants, the chunk
+//     advance lives in the scalar buffer descriptor, halo / padded-channel pieces carry offset 0xFFFFFFFF and are
+//     zero-filled by the buffer range check.  One 16-B patch DMA per lane per chunk (was four 4-B gathers with
+//     64-bit address selects), no zero page.
+//   * the MFMA N dimension (32 lanes) is a 4-row x 8-column pixel block instead of 32 consecutive pixels of one
+//     row, and a wave skips the MFMAs of pixel blocks that lie wholly outside the image.  The tile granularity
+//     drops from 32 to 8 columns: 100x166 maps waste 1 % instead of 16 %, 50x83 maps 10 % instead of 20 %.
+// LDS patch row pitch is 40 floats (10 pieces; column m <-> image column x0 - 4 + m, so the left halo is one whole
+// piece), which also puts the four rows of a pixel block on disjoint 8-bank groups for ds_read_b32.
+constexpr int PWB = 40;
+
+__device__ __forceinline__ void* uniform_ptr(const void* p)
+{
+    const unsigned long long a = (unsigned long long)p;
+    return (void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a));
+}
+
+template <int BM, int NWAVE>
+__global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
+    int tilesX, int tilesY, int coTiles, int nChunks, int epi)
+{
+    constexpr int CK = 4;
+    constexpr int NT = 64 * NWAVE;
+    constexpr int WN = NWAVE / (BM / 64);            // waves along the pixel dimension: 2 -> 4 rows, 4 -> 8 rows
+    constexpr int TH = 2 * WN, PR = TH + 2, PLANE = PR * PWB;
+    constexpr int WS = 9 * CK * BM;                  // weight slab floats per chunk
+    constexpr int WPC = WS / 4;                      // ... in 16-B pieces
+    constexpr int NWI = (WPC + NT - 1) / NT;
+    constexpr int PPC = CK * PR * 10;                // patch pieces per chunk (240 / 400)
+    constexpr int NPI = (PPC + NT - 1) / NT;         // ... per lane: 1 (2 for the 64-channel, 4-wave variant)
+    constexpr int PS = ((PPC + 63) / 64) * 64 * 4;   // patch floats, padded to whole waves of pieces
+    constexpr int STAGE = WS + PS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int cot = bid % coTiles;
+    int pt = bid / coTiles;
+    const int tx = pt % tilesX;
+    pt /= tilesX;
+    const int ty = pt % tilesY;
+    const int n = pt / tilesY;
+    const int x0 = tx * TW, y0 = ty * TH;
+    const int HW = H * W;
+    const int wv = W - x0;                           // valid columns right of x0
+
+    // this lane's patch piece(s): (channel, patch row, piece) -> byte offset from the chunk's first channel plane
+    unsigned pvoff[NPI];
+    int fix = 0;                                     // words 1..3 of piece i (bits 4i+1..4i+3) beyond the image edge
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+        const int pidx = tid + i * NT;
+        const int ci = pidx / (PR * 10), rem = pidx - ci * (PR * 10);
+        const int r = rem / 10, q = rem - r * 10;
+        const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+        pvoff[i] = 0xFFFFFFFFu;
+        if (pidx < PPC && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            pvoff[i] = (unsigned)(ci * HW + gy * W + gx) * 4u;
+#pragma unroll
+            for (int e = 1; e < 4; ++e) fix |= (gx + e >= W) ? (1 << (4 * i + e)) : 0;
+        }
+    }
+    const unsigned wvoff = (unsigned)tid * 16u;
+    const bool edge = wv < 33;                       // some loaded piece straddles the right image edge
+
+    const char* xc = (const char*)(x + (size_t)n * Cin * HW);
+    const char* wc = (const char*)(wp + (size_t)cot * nChunks * WS);
+    unsigned xleft = (unsigned)Cin * (unsigned)HW * 4u;   // bytes from xc to the end of image n (< 2^32: launcher)
+
+    auto issue = [&](int buf) {
+        float* Wd = lds + buf * STAGE + wave * 256;
+        float* Pd = lds + buf * STAGE + WS + wave * 256;
+        // (both chunk pointers are wave-uniform; readfirstlane keeps the compiler from parking them in VGPRs when
+        // SGPRs run short, which would turn every DMA into a waterfall loop)
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(wc), 0, WS * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            uniform_ptr(xc), 0, __builtin_amdgcn_readfirstlane((int)xleft), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NWI; ++i) {
+            if ((i + 1) * NT <= WPC || wave * 64 + i * NT < WPC)     // wave-uniform (WPC is a multiple of 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_b_t*)(Wd + i * NT * 4), 16, (int)wvoff,
+                                                         i * NT * 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NPI; ++i) {
+            if (wave * 64 + i * NT < PPC)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_b_t*)(Pd + i * NT * 4), 16, (int)pvoff[i], 0, 0, 0);
+        }
+        wc += WS * 4;
+        xc += (size_t)CK * HW * 4;
+        xleft -= (unsigned)CK * (unsigned)HW * 4u;
+    };
+
+    constexpr int WNX = 2;                            // two waves side by side cover the 32 columns
+    const int wm = wave / WN, wn = wave % WN;
+    const int cb = (wn % WNX) * 16, rb = (wn / WNX) * 4;
+    const int nl = lane & 31;
+    const int pr = nl >> 3, pc = nl & 7;              // pixel inside the 4 x 8 block
+    const bool row_in = y0 + rb < H;
+    const int mode = !row_in ? 0 : (cb + 8 < wv ? 2 : (cb < wv ? 1 : 0));      // pixel blocks with work: 0 / 1 / 2
+    const int a_off = wm * 64 + nl + (lane >> 5) * BM;
+    const int b_off = WS + (lane >> 5) * PLANE + (rb + pr) * PWB + cb + pc + 3;
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};     // acc[co half][pixel block]
+
+    // One copy of the chunk loop per amount of MFMA work (2, 1 or 0 pixel blocks inside the image), selected once
+    // by a wave-uniform branch: every copy runs the same DMA issue / wait / barrier sequence, and each gets a
+    // register allocation of its own.
+    auto run = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+        issue(0);
+        for (int chunk = 0; chunk < nChunks; ++chunk) {
+            const int buf = chunk & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces of `buf` have landed
+            if (edge && fix) {
+                float* pw = lds + buf * STAGE + WS + tid * 4;
+#pragma unroll
+                for (int i = 0; i < NPI; ++i) {
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (fix & (1 << (4 * i + e))) pw[i * NT * 4 + e] = 0.f;
+                }
+            }
+            __syncthreads();                                      // everyone's pieces landed; buf^1 is free
+            if (chunk + 1 < nChunks) issue(buf ^ 1);
+            if (MODE == 0) continue;
+            const float* wsl = lds + buf * STAGE + a_off;
+            const float* psl = lds + buf * STAGE + b_off;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+                for (int j = 0; j < CK / 2; ++j) {
+                    const float a0 = wsl[(tap * CK + 2 * j) * BM];
+                    const float a1 = wsl[(tap * CK + 2 * j) * BM + 32];
+                    const float b0 = psl[2 * j * PLANE + ky * PWB + kx];
+                    acc00 = mfma32(a0, b0, acc00);
+                    acc10 = mfma32(a1, b0, acc10);
+                    if (MODE == 2) {
+                        const float b1 = psl[2 * j * PLANE + ky * PWB + kx + 8];
+                        acc01 = mfma32(a0, b1, acc01);
+                        acc11 = mfma32(a1, b1, acc11);
+                    }
+                }
+            }
+        }
+    };
+    if (mode == 2) run(std::integral_constant<int, 2>{});
+    else if (mode == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
+    if (mode == 0) return;
+
+    const int py = y0 + rb + pr;
+    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
+    if (epi == 4) {
+        // bias + ReLU + 2x2/2 max pool (floor mode) fused: the vertical partner of a pixel is lane^8, the
+        // horizontal partner lane^1 (both inside the 4 x 8 block); lanes with even row and column store to the
+        // pooled (H/2, W/2) tensor.  The full-resolution activation never reaches HBM (frozen blocks only).
+        const int OH = H >> 1, OW = W >> 1;
+        float* yn = y + (size_t)n * Cout * OH * OW;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
+                const float b = (co < Cout) ? bias[co] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && mode < 2) continue;
+                    const float v = fmaxf(((s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r])) + b, 0.f);
+                    float m = fmaxf(v, __shfl_xor(v, 8, 64));
+                    m = fmaxf(m, __shfl_xor(m, 1, 64));
+                    const int oy = py >> 1, ox = (x0 + cb + 8 * q + pc) >> 1;
+                    if (co < Cout && !(pr & 1) && !(pc & 1) && oy < OH && ox < OW) yn[((size_t)co * OH + oy) * OW + ox] = m;
+                }
+            }
+        }
+        return;
+    }
+    float* yn = y + (size_t)n * Cout * HW;
+    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
+            if (co >= Cout) continue;
+            const float b = (epi <= 1) ? bias[co] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int px = x0 + cb + 8 * q + pc;
+                if ((q == 1 && mode < 2) || py >= H || px >= W) continue;
+                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
+                const size_t o = (size_t)co * HW + (size_t)py * W + px;
                 if (epi <= 1) {
                     v += b;
                     if (epi == 1) v = fmaxf(v, 0.f);
@@ -795,7 +1012,6 @@ constexpr int WB_XPL = 124;                 // X plane pitch: 3 rows + 1 pad pie
 constexpr int WB_X = 1024 * 4;              // 32 planes x 31 pieces = 992 pieces, rounded to 16 waves' worth
 constexpr int WB_STAGE = WB_DY + WB_X;      // 8704 floats = 34 KB; double buffered, two workgroups per CU
 
-typedef __attribute__((address_space(3))) void lds_void_b_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
 typedef __attribute__((address_space(3))) float lds_f32_t;
@@ -1067,13 +1283,14 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
         dz[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
-// 2 = LDS-DMA double-buffered pipeline (CK = 4, default); 1 = register-staged kernel (PTMI_CONV_IMPL=1)
+// PTMI_CONV_IMPL: 4 = buffer-DMA pipeline with 4x8 pixel blocks (default); 2 = global_load_lds pipeline;
+// 3 = LDS-free register-streamed kernel; 1 = register-staged kernel with ds_write
 int conv_impl()
 {
     static int impl = -1;
     if (impl < 0) {
         const char* e = getenv("PTMI_CONV_IMPL");
-        impl = (e && e[0] == '1') ? 1 : ((e && e[0] == '3') ? 3 : 2);
+        impl = (e && e[0] >= '1' && e[0] <= '4') ? (e[0] - '0') : 4;
     }
     return impl;
 }
@@ -1087,6 +1304,13 @@ int wgrad_impl()
         impl = (e && e[0] == '2') ? 2 : 3;
     }
     return impl;
+}
+
+bool stem_direct()
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PTMI_CONV_STEM_DIRECT"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
 }
 
 int wgrad_splits(int n, int cin, int cout, int h, int w)
@@ -1151,7 +1375,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     static int w8 = -1;
     if (w8 < 0) { const char* e = getenv("PTMI_CONV_W8"); w8 = e ? (e[0] - '0') : 2; }
     // 8-wave workgroups (8 rows x 32 cols per 128 channels) share one weight slab among twice the pixels
-    const bool use8 = BM == 128 && CK == 4 && conv_impl() == 2 && cin > 4 && (w8 == 1 || (w8 == 2 && h >= 200));   // A/B: +3.5% at 400x666, -3.5% at 100x166 (row-tile waste)
+    const bool use8 = BM == 128 && CK == 4 && (conv_impl() == 2 || conv_impl() == 4) && cin > 4 && (w8 == 1 || (w8 == 2 && h >= 200));   // A/B: +3.5% at 400x666, -3.5% at 100x166 (row-tile waste)
     const int TH = (BM == 128 && !use8) ? 4 : 8;
     const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
     const int64_t blocks = (int64_t)n * tilesX * tilesY * coTiles;
@@ -1161,7 +1385,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     // register-streamed kernel: everywhere with PTMI_CONV_IMPL=3 (A/B experiments: slower than LDS-DMA on the big
     // layers, 66-80 vs 115-131 TF/s) and by default for the 3-channel stem, whose K = 36 loop is too short to
     // amortise the LDS pipeline's prologue (25 vs 18 TF/s; that layer is HBM-write bound)
-    if (CK == 4 && (conv_impl() == 3 || (conv_impl() == 2 && cin <= 4)) && epilogue != 4) {
+    if (CK == 4 && (conv_impl() == 3 || (conv_impl() >= 2 && cin <= 4 && stem_direct())) && epilogue != 4) {
         const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
         if (BM == 128)
             hipLaunchKernelGGL((conv3x3_direct_kernel<128>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
@@ -1170,6 +1394,16 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
             hipLaunchKernelGGL((conv3x3_direct_kernel<64>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
                                h, w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
         PTMI_LAUNCH_CHECK("conv3x3_fwd(direct)");
+        return 0;
+    }
+    if (CK == 4 && conv_impl() == 4 && (int64_t)cin * h * w * 4 < (1ll << 32)) {
+#define LBUF(BM_, NW_) hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, \
+                                          y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
+        if (BM == 128 && use8) LBUF(128, 8);
+        else if (BM == 128) LBUF(128, 4);
+        else LBUF(64, 4);
+#undef LBUF
+        PTMI_LAUNCH_CHECK("conv3x3_fwd(buf)");
         return 0;
     }
     if (CK == 4 && conv_impl() >= 2) {
