@@ -28,6 +28,32 @@ void ptmi_set_error(const char* fmt, ...);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- buffer -> LDS DMA helpers (buffer_load_dword[x4] ... lds) ----------------------------------------------
+// Raw buffer resource over [base, base + bytes): lanes whose offset is >= bytes (e.g. 0xFFFFFFFF) are zero-filled
+// by the range check without touching memory.  0x00020000 = DATA_FORMAT 32 (gfx9 raw buffer).
+typedef __attribute__((address_space(3))) void ptmi_lds_void_t;
+typedef __attribute__((address_space(3))) f32x4 ptmi_lds_f32x4_t;
+typedef __attribute__((address_space(3))) float ptmi_lds_f32_t;
+
+// A wave-uniform pointer the compiler may have parked in VGPRs: pull it back into SGPRs (a descriptor built from
+// VGPRs turns every DMA into a waterfall loop).
+__device__ __forceinline__ void* ptmi_uniform_ptr(const void* p)
+{
+    const unsigned long long a = (unsigned long long)p;
+    return (void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32)) << 32) |
+                   (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ptmi_rsrc(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(base), 0, __builtin_amdgcn_readfirstlane((int)bytes),
+                                             0x00020000);
+}
+// 16 B per lane: LDS destination = lds_wave_base + lane * 16 B; global source = base + voff + soff
+__device__ __forceinline__ void ptmi_bdma16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float* lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (ptmi_lds_void_t*)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 

@@ -1012,7 +1012,6 @@ constexpr int WB_XPL = 124;                 // X plane pitch: 3 rows + 1 pad pie
 constexpr int WB_X = 1024 * 4;              // 32 planes x 31 pieces = 992 pieces, rounded to 16 waves' worth
 constexpr int WB_STAGE = WB_DY + WB_X;      // 8704 floats = 34 KB; double buffered, two workgroups per CU
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f32x4 lds_f32x4_t;
 typedef __attribute__((address_space(3))) float lds_f32_t;
 __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t r, unsigned voff, float* lds_wave_base)

@@ -12,6 +12,7 @@
 //     k (coalesced 128-B global rows) without bank conflicts (stride 129 = 1 mod 32).
 // Accumulation is strictly k-ordered inside a tile chain => bitwise reproducible run to run.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -126,6 +127,190 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ buffer-DMA pipeline
+// Default kernel.  Same 128x128x32 tiling and wave layout, but the operand tiles go global -> LDS directly with
+// `buffer_load_dwordx4 ... lds` (no VGPR staging, no ds_write), double-buffered with one barrier per K step:
+//   * a k-fastest operand (row-major A, or B stored (N,K)) lands as T[mn][36]: 8 data pieces + 1 pad piece per row;
+//     the MFMA k index is permuted (lane half h, step j <-> k = 16h + j) so that a lane's 16 k values are
+//     contiguous: four ds_read_b128 per 32-row sub-tile, conflict-free at pitch 36 (= 4 * odd);
+//   * an mn-fastest operand lands as T[k][128] and is read with ds_read_b32 (32 consecutive mn per lane group);
+//   * rows beyond M / N and K-tail rows / pieces carry offset 0xFFFFFFFF (zero-filled by the range check); a 16-B
+//     piece that straddles K (K % 4 != 0) is loaded whole and its tail words are zeroed in LDS by the loading lane.
+// The k permutation is the same for both operands, so the sum is unchanged up to fp32 ordering, and the order is
+// fixed => bitwise reproducible run to run.
+constexpr int KF_PITCH = 36, KF_SLOTS = 128 * 9, KF_FLOATS = KF_SLOTS * 4 + 256;      // 1152 slots (+ DMA overhang)
+constexpr int MF_FLOATS = 32 * 128;
+constexpr int OP_FLOATS = KF_FLOATS;                                                   // per operand per stage
+
+template <bool KF>
+struct OpTile {
+    unsigned voff[KF ? 5 : 1];      // loop-invariant byte offsets of this lane's pieces (0xFFFFFFFF = never loaded)
+    unsigned qpack;                 // KF: first k of piece i in bits 6i..6i+5;  !KF: k row of piece 0 (rows 8i + that)
+    const char* base;               // this tile at the current K step (wave-uniform)
+    long long left;                 // bytes from base to the end of the operand
+    int step_bytes, row8_bytes;
+
+    __device__ __forceinline__ void init(const float* p, int ld, int mn0, int MN, int K, int tid, int64_t total_floats)
+    {
+        if constexpr (KF) {
+            qpack = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int sl = tid + i * 256;
+                const int row = sl / 9, q = sl - row * 9;
+                voff[i] = (sl < KF_SLOTS && q < 8 && mn0 + row < MN) ? (unsigned)(row * ld + 4 * q) * 4u : 0xFFFFFFFFu;
+                qpack |= (unsigned)(4 * q) << (6 * i);
+            }
+            base = (const char*)(p + (size_t)mn0 * ld);
+            left = (total_floats - (int64_t)mn0 * ld) * 4;
+            step_bytes = 32 * 4;
+            row8_bytes = 0;
+        } else {
+            const int kr = tid >> 5, q = tid & 31;
+            voff[0] = (mn0 + 4 * q < MN) ? (unsigned)(kr * ld + 4 * q) * 4u : 0xFFFFFFFFu;
+            qpack = kr;
+            base = (const char*)(p + mn0);
+            left = (total_floats - mn0) * 4;
+            step_bytes = 32 * ld * 4;
+            row8_bytes = 8 * ld * 4;
+        }
+    }
+    // krem = K - k0 (>= 32 except in the tail step)
+    __device__ __forceinline__ void issue(float* dst_wave, int wave, int krem)
+    {
+        const __amdgpu_buffer_rsrc_t r = ptmi_rsrc(base, (unsigned)(left > 0xFFFFFFFEll ? 0xFFFFFFFEll : (left < 0 ? 0 : left)));
+        if constexpr (KF) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (i < 4 || wave < 2) {
+                    unsigned v = voff[i];
+                    if (krem < 32) v = ((int)((qpack >> (6 * i)) & 63) < krem) ? v : 0xFFFFFFFFu;
+                    ptmi_bdma16(r, v, 0, dst_wave + i * 1024);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned v = voff[0];
+                if (krem < 32) v = ((int)qpack + 8 * i < krem) ? v : 0xFFFFFFFFu;
+                ptmi_bdma16(r, v, i * row8_bytes, dst_wave + i * 1024);
+            }
+        }
+        base += step_bytes;
+        left -= step_bytes;
+    }
+    // zero the words of own pieces that lie beyond K (KF only, tail step with K % 4 != 0)
+    __device__ __forceinline__ void fixup(float* dst_lane, int wave, int krem)
+    {
+        if constexpr (KF) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int k4 = (qpack >> (6 * i)) & 63;
+                if ((i < 4 || wave < 2) && voff[i] != 0xFFFFFFFFu && k4 < krem && k4 + 4 > krem) {
+#pragma unroll
+                    for (int e = 1; e < 4; ++e)
+                        if (k4 + e >= krem) dst_lane[i * 1024 + e] = 0.f;
+                }
+            }
+        }
+    }
+    // fragment for the 32-row sub-tile starting at row r0: f[j] = T(row r0 + (lane & 31), k = 16 * (lane >> 5) + j)
+    __device__ __forceinline__ static void frag(const float* T, int r0, int lane, float (&f)[16])
+    {
+        if constexpr (KF) {
+            const float* p = T + (r0 + (lane & 31)) * KF_PITCH + (lane >> 5) * 16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 v = *(const volatile ptmi_lds_f32x4_t*)(p + 4 * t);
+                f[4 * t] = v[0]; f[4 * t + 1] = v[1]; f[4 * t + 2] = v[2]; f[4 * t + 3] = v[3];
+            }
+        } else {
+            const float* p = T + (lane >> 5) * 16 * 128 + r0 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) f[j] = p[j * 128];
+        }
+    }
+};
+
+template <bool AK, bool BKF>
+__global__ __launch_bounds__(256, 2) void gemm_buf_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+    const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc, int bias_mode, int relu,
+    int accumulate, int64_t sa, int64_t sb, int64_t sc, int tilesN)
+{
+    __shared__ __attribute__((aligned(16))) float lds[4 * OP_FLOATS];      // [buf][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bm = blockIdx.x / tilesN, bn = blockIdx.x % tilesN;
+    const int m0 = bm * BMN, n0 = bn * BMN;
+    const int b = blockIdx.y;
+    A += (size_t)b * sa;
+    B += (size_t)b * sb;
+    C += (size_t)b * sc;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    OpTile<AK> ta;
+    OpTile<BKF> tb;
+    ta.init(A, lda, m0, M, K, tid, AK ? ((int64_t)(M - 1) * lda + K) : ((int64_t)(K - 1) * lda + M));
+    tb.init(B, ldb, n0, N, K, tid, BKF ? ((int64_t)(N - 1) * ldb + K) : ((int64_t)(K - 1) * ldb + N));
+
+    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const int nSteps = (K + BK - 1) / BK;
+    ta.issue(lds + wave * 256, wave, K);
+    tb.issue(lds + OP_FLOATS + wave * 256, wave, K);
+    for (int st = 0; st < nSteps; ++st) {
+        const int buf = st & 1;
+        float* As = lds + buf * 2 * OP_FLOATS;
+        float* Bs = As + OP_FLOATS;
+        const int krem = K - st * BK;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (krem < 32 && (krem & 3)) {
+            ta.fixup(As + tid * 4, wave, krem);
+            tb.fixup(Bs + tid * 4, wave, krem);
+        }
+        __syncthreads();
+        if (st + 1 < nSteps) {
+            float* An = lds + (buf ^ 1) * 2 * OP_FLOATS + wave * 256;
+            ta.issue(An, wave, krem - BK);
+            tb.issue(An + OP_FLOATS, wave, krem - BK);
+        }
+        float a0[16], a1[16], b0[16], b1[16];
+        OpTile<AK>::frag(As, wm * 64, lane, a0);
+        OpTile<AK>::frag(As, wm * 64 + 32, lane, a1);
+        OpTile<BKF>::frag(Bs, wn * 64, lane, b0);
+        OpTile<BKF>::frag(Bs, wn * 64 + 32, lane, b1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            acc00 = mfma32(a0[j], b0[j], acc00);
+            acc01 = mfma32(a0[j], b1[j], acc01);
+            acc10 = mfma32(a1[j], b0[j], acc10);
+            acc11 = mfma32(a1[j], b1[j], acc11);
+        }
+    }
+    // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = n0 + wn * 64 + q * 32 + (lane & 31);
+            if (n >= N) continue;
+            const float bn_ = (bias_mode == 2) ? bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m >= M) continue;
+                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
+                if (bias_mode == 1) v += bias[m];
+                else if (bias_mode == 2) v += bn_;
+                float* dst = C + (size_t)m * ldc + n;
+                if (accumulate) v += *dst;
+                if (relu) v = fmaxf(v, 0.f);
+                *dst = v;
+            }
+        }
+    }
+}
+
 // out[j] (+)= sum_i a[i][j]: a workgroup owns 16 columns; 16 row-partitions are reduced through LDS in a
 // fixed order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, float* __restrict__ out,
@@ -185,9 +370,18 @@ int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, i
     hipStream_t st = (hipStream_t)s;
     // A k-fast  <=> stored (M,K) row-major (ta == 0);  B k-fast <=> stored (N,K) (tb == 1)
     const bool ak = (ta == 0), bk = (tb != 0);
+    static int impl = -1;      // PTMI_GEMM_IMPL=1: register-staged kernel (also used when a leading dimension is huge)
+    if (impl < 0) { const char* e = getenv("PTMI_GEMM_IMPL"); impl = (e && e[0] == '1') ? 1 : 2; }
+    const bool buf_ok = impl == 2 && (int64_t)128 * lda * 4 < (1ll << 31) && (int64_t)128 * ldb * 4 < (1ll << 31);
 #define L(AK_, BK_)                                                                                     \
-    hipLaunchKernelGGL((gemm_f32_kernel<AK_, BK_>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, ldc, \
-                       bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN)
+    do {                                                                                                \
+        if (buf_ok)                                                                                     \
+            hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, \
+                               ldc, bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN);  \
+        else                                                                                            \
+            hipLaunchKernelGGL((gemm_f32_kernel<AK_, BK_>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, \
+                               ldc, bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN);  \
+    } while (0)
     if (ak && bk) L(true, true);
     else if (ak && !bk) L(true, false);
     else if (!ak && bk) L(false, true);

@@ -51,6 +51,8 @@ def close(a, b, rtol, atol, what=""):
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
     err = np.abs(a - b)
     tol = atol + rtol * np.abs(b)
+    if os.environ.get("PTMI_TEST_VERBOSE") and err.size:
+        print(f"[close] {what}: max abs err {err.max():.3e}, max tol-ratio {np.max(err / tol):.3f}")
     assert (err <= tol).all(), f"{what}: max abs err {err.max():.3e} (worst rel {np.max(err / (np.abs(b) + 1e-30)):.3e})"
 
 

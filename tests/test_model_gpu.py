@@ -166,10 +166,14 @@ def test_run_step_matches_reference_golden():
                     # optimiser step and the (order-nondeterministic) ROIAlign scatter: 1e-3
                     close(torch.tensor(m[k[len(f"it{it}_m_"):]]), z[k], 1e-4 if it == 0 else 1e-3, 1e-6, k)
             ssd, tsd = tr.model.state_dict(), tr.model_teacher.state_dict()
+            # parameter sums are cancellation-heavy (25.7 M fc1 weights summing to ~4): identical weights at it 0
+            # agree to ~4e-6; afterwards the fp32 summation-order noise of the GEMM / conv kernels compounds
+            # through the optimiser (measured 4e-5 .. 3e-4 at it 1-2 with either GEMM kernel)
+            sum_atol = 2e-4 if it == 0 else 1e-3
             for k in probes:
-                close(ssd[k].double().sum().cpu(), z[f"it{it}_s_sum_{k}"], 1e-5, 2e-4, f"student sum {k}")
+                close(ssd[k].double().sum().cpu(), z[f"it{it}_s_sum_{k}"], 1e-5, sum_atol, f"student sum {k}")
                 close(ssd[k].flatten()[:16].cpu(), z[f"it{it}_s_head_{k}"], 1e-4, 1e-6, f"student head {k}")
-                close(tsd[k].double().sum().cpu(), z[f"it{it}_t_sum_{k}"], 1e-5, 2e-4, f"teacher sum {k}")
+                close(tsd[k].double().sum().cpu(), z[f"it{it}_t_sum_{k}"], 1e-5, sum_atol, f"teacher sum {k}")
                 close(tsd[k].flatten()[:16].cpu(), z[f"it{it}_t_head_{k}"], 1e-4, 1e-6, f"teacher head {k}")
     finally:
         sampling.set_perm_fn(None)

@@ -129,6 +129,27 @@ def test_linear(ops, r, k, nout, relu):
     close(bd.grad, br.grad, 1e-4, 1e-3, "linear db")
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(130, 66, 70), (64, 257, 31), (5, 3, 2), (256, 128, 96)])
+def test_gemm_all_layouts(ops, ta, tb, m, n, k):
+    """ptmi_gemm_f32 in all four storage combinations, ragged M / N / K (K % 4 != 0 exercises the straddling 16-B
+    pieces), batched with strides, against a float64 matmul."""
+    gen = g(m * 7 + n * 3 + k + ta * 2 + tb)
+    batch = 2
+    a = torch.randn(batch, *((k, m) if ta else (m, k)), generator=gen)
+    b = torch.randn(batch, *((n, k) if tb else (k, n)), generator=gen)
+    am = a.transpose(1, 2) if ta else a
+    bm = b.transpose(1, 2) if tb else b
+    ref = torch.bmm(am.double(), bm.double()).float()
+    ad, bd = a.to(DEV).contiguous(), b.to(DEV).contiguous()
+    out = ops.gemm(ad, bd, m, n, k, a.shape[2], b.shape[2], ta, tb, batch=batch, stride_a=a.shape[1] * a.shape[2],
+                   stride_b=b.shape[1] * b.shape[2], stride_c=m * n)
+    close(out, ref, 1e-4, 1e-4, f"gemm ta={ta} tb={tb}")
+    out2 = ops.gemm(ad, bd, m, n, k, a.shape[2], b.shape[2], ta, tb, batch=batch, stride_a=a.shape[1] * a.shape[2],
+                    stride_b=b.shape[1] * b.shape[2], stride_c=m * n)
+    assert torch.equal(out, out2), "gemm must be bitwise reproducible"
+
+
 def test_conv1x1(ops):
     gen = g(17)
     x = torch.randn(3, 96, 13, 21, generator=gen)
