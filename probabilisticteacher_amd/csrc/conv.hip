@@ -411,13 +411,14 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    const int cot = bid % coTiles;
-    int pt = bid / coTiles;
-    const int tx = pt % tilesX;
-    pt /= tilesX;
-    const int ty = pt % tilesY;
-    const int n = pt / tilesY;
+    // grid = (coTiles, tilesX * tilesY, N): channel tile fastest in the linear workgroup order, no integer divisions
+    // beyond one.
+    // Tiles are numbered column-major (ty fastest): the XCD of a workgroup is its linear id mod 8 = cot + coTiles *
+    // (tile parity ...), and with row-major numbering and an even tilesX every (light) right-edge tile would land
+    // on the same half of the XCDs (measured: 13 % of the slot-time empty on 100x166 maps).
+    const int cot = blockIdx.x;
+    const int tx = blockIdx.y / tilesY, ty = blockIdx.y - tx * tilesY;
+    const int n = blockIdx.z;
     const int x0 = tx * TW, y0 = ty * TH;
     const int HW = H * W;
     const int wv = W - x0;                           // valid columns right of x0
@@ -528,55 +529,83 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
     else run(std::integral_constant<int, 0>{});
     if (mode == 0) return;
 
+    // Epilogue.  clock64() probes showed the straightforward version (64-bit address arithmetic and bounds tests
+    // per element, issued while the CU's other waves stream MFMAs) holding the workgroup's slot for 30-40 us after
+    // its last MFMA -- 5-17 % of its life.  Here every store is `buffer_store_dword`: the per-lane byte offset
+    // (pixel, + 4 channels for the upper lane half) is computed once, the channel advance is a scalar offset, and
+    // out-of-image pixels (offset 0xFFFFFFFF) / channels >= Cout (past num_records) are dropped by the range check.
     const int py = y0 + rb + pr;
-    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
+    const int half4 = 4 * (lane >> 5);
+    const int co_w = cot * BM + wm * 64;                                   // wave-uniform first channel
+    const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
+    f32x4 bv[2][4];                                                        // bias of channels co_w + 32s + 8g + half4 + 0..3
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bv[s][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (epi <= 1 || epi == 4)
+                bv[s][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, half4 * 4, (co_w + s * 32 + g * 8) * 4, 0));
+        }
+    }
     if (epi == 4) {
         // bias + ReLU + 2x2/2 max pool (floor mode) fused: the vertical partner of a pixel is lane^8, the
         // horizontal partner lane^1 (both inside the 4 x 8 block); lanes with even row and column store to the
         // pooled (H/2, W/2) tensor.  The full-resolution activation never reaches HBM (frozen blocks only).
-        const int OH = H >> 1, OW = W >> 1;
-        float* yn = y + (size_t)n * Cout * OH * OW;
+        const int OH = H >> 1, OW = W >> 1, OHW = OH * OW;
+        const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)Cout * (unsigned)OHW * 4u);
+        unsigned pv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int oy = py >> 1, ox = (x0 + cb + 8 * q + pc) >> 1;
+            const bool ok = !(pr & 1) && !(pc & 1) && oy < OH && ox < OW && (q == 0 || mode == 2);
+            pv[q] = ok ? (unsigned)(half4 * OHW + oy * OW + ox) * 4u : 0xFFFFFFFFu;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
-                const float b = (co < Cout) ? bias[co] : 0.f;
+                const int soff = (co_w + s * 32 + (r & 3) + 8 * (r >> 2)) * OHW * 4;
+                const float b = bv[s][r >> 2][r & 3];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     if (q == 1 && mode < 2) continue;
                     const float v = fmaxf(((s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r])) + b, 0.f);
                     float m = fmaxf(v, __shfl_xor(v, 8, 64));
                     m = fmaxf(m, __shfl_xor(m, 1, 64));
-                    const int oy = py >> 1, ox = (x0 + cb + 8 * q + pc) >> 1;
-                    if (co < Cout && !(pr & 1) && !(pc & 1) && oy < OH && ox < OW) yn[((size_t)co * OH + oy) * OW + ox] = m;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ry, (int)pv[q], soff, 0);
                 }
             }
         }
         return;
     }
-    float* yn = y + (size_t)n * Cout * HW;
-    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
+    const unsigned img_bytes = (unsigned)Cout * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * HW, img_bytes);
+    const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(epi == 3 ? mref + (size_t)n * Cout * HW : y, epi == 3 ? img_bytes : 0u);
+    unsigned pv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int px = x0 + cb + 8 * q + pc;
+        pv[q] = (py < H && px < W && (q == 0 || mode == 2)) ? (unsigned)(half4 * HW + py * W + px) * 4u : 0xFFFFFFFFu;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
-            if (co >= Cout) continue;
-            const float b = (epi <= 1) ? bias[co] : 0.f;
+            const int soff = (co_w + s * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4;
+            const float b = bv[s][r >> 2][r & 3];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int px = x0 + cb + 8 * q + pc;
-                if ((q == 1 && mode < 2) || py >= H || px >= W) continue;
+                if (q == 1 && mode < 2) continue;
                 float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
-                const size_t o = (size_t)co * HW + (size_t)py * W + px;
                 if (epi <= 1) {
                     v += b;
                     if (epi == 1) v = fmaxf(v, 0.f);
                 } else if (epi == 3) {
-                    v = (mn[o] > 0.f) ? v : 0.f;
+                    const float mk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)pv[q], soff, 0));
+                    v = (mk > 0.f) ? v : 0.f;
                 }
-                yn[o] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, (int)pv[q], soff, 0);
             }
         }
     }
@@ -1395,8 +1424,10 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
         PTMI_LAUNCH_CHECK("conv3x3_fwd(direct)");
         return 0;
     }
-    if (CK == 4 && conv_impl() == 4 && (int64_t)cin * h * w * 4 < (1ll << 32)) {
-#define LBUF(BM_, NW_) hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, \
+    if (CK == 4 && conv_impl() == 4 && (int64_t)cin * h * w * 4 < (1ll << 32) && ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) &&
+        (int64_t)tilesX * tilesY < 65536 && n < 65536) {
+        const dim3 grid3((unsigned)coTiles, (unsigned)(tilesX * tilesY), (unsigned)n);
+#define LBUF(BM_, NW_) hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, \
                                           y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
         if (BM == 128 && use8) LBUF(128, 8);
         else if (BM == 128) LBUF(128, 4);
