@@ -1087,12 +1087,35 @@ __device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, co
     }
 }
 
+// Right-edge stage with few valid columns (wv <= 24): the k index is interleaved instead (lane half h, step j <->
+// pixel 2j + h), so only ceil(wv / 2) MFMA steps are issued instead of 16.  Operands are single-word LDS reads here.
+template <int G>
+__device__ __forceinline__ void wgrad_stage_edge(const float* __restrict__ al0, const float* __restrict__ bl0,
+                                                 f32x16 (&acc)[G == 0 ? 5 : 4], int nj)
+{
+    constexpr int TAP0 = G == 0 ? 0 : 5, TAP1 = G == 0 ? 5 : 9;
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+        const float a = al0[2 * j];
+#pragma unroll
+        for (int ky = (G == 0 ? 0 : 1); ky < (G == 0 ? 2 : 3); ++ky) {
+            const float* br = bl0 + ky * WB_XROW + 2 * j + 3;          // image column x0 + (2j + h) - 1
+            const float v0 = br[0], v1 = br[1], v2 = br[2];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tap = ky * 3 + kx;
+                if (tap >= TAP0 && tap < TAP1) acc[tap - TAP0] = mfma32(a, kx == 0 ? v0 : (kx == 1 ? v1 : v2), acc[tap - TAP0]);
+            }
+        }
+    }
+}
+
 // one tap group's whole life: descriptors, stage loop, partial store.  Instantiated twice and selected by a
 // wave-uniform branch so that each group gets its own register allocation (5 or 4 accumulator tiles).
-template <int G>
+template <int G, bool EDGE>
 __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restrict__ x, const float* __restrict__ dy,
                                                float* __restrict__ partial, int N, int Cin, int Cout, int H, int W,
-                                               int tilesX, int tilesY, int ciTiles, int S, int wave, int lane)
+                                               int tilesX, int tilesY, int ciTiles, int S, int txb, int wave, int lane)
 {
     constexpr int NT = G == 0 ? 5 : 4;
     const int cw = wave & 3;
@@ -1138,7 +1161,7 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
     const int sx = S % tilesX, sy = (S / tilesX) % tilesY, sn = S / (tilesX * tilesY);
 
     auto issue = [&](int n_, int ty_, int tx_, int buf) {
-        const int x0 = tx_ * TW, y0 = ty_;
+        const int x0 = (txb + tx_) * TW, y0 = ty_;
         const float* dyn = dy + ((size_t)n_ * Cout + co0) * HW + (size_t)y0 * W + x0;
         const float* xb = x + ((size_t)n_ * Cin + ci0) * HW + ((ptrdiff_t)y0 - 1) * W + (x0 - 4);
         const long long drem = dy_end - (const char*)dyn, xrem = x_end - (const char*)xb;
@@ -1180,7 +1203,7 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
     if (tile < nTiles) issue(n, ty, tx, 0);
     for (; tile < nTiles; tile += S, ++it) {
         const int buf = it & 1;
-        const int wv = W - tx * TW;                              // valid columns of this stage's tile
+        const int wv = W - (txb + tx) * TW;                      // valid columns of this stage's tile
         int ntx = tx + sx, nty = ty + sy, nn = n + sn;
         if (ntx >= tilesX) { ntx -= tilesX; ++nty; }
         if (nty >= tilesY) { nty -= tilesY; ++nn; }
@@ -1210,7 +1233,11 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
         }
         __syncthreads();
         if (tile + S < nTiles) issue(nn, nty, ntx, buf ^ 1);
-        wgrad_stage_buf<G>(lds + buf * WB_STAGE + a_off, lds + buf * WB_STAGE + b_off, acc);
+        if (!EDGE)
+            wgrad_stage_buf<G>(lds + buf * WB_STAGE + a_off, lds + buf * WB_STAGE + b_off, acc);
+        else
+            wgrad_stage_edge<G>(lds + buf * WB_STAGE + a_off - h16 + (lane >> 5), lds + buf * WB_STAGE + b_off - h16 + (lane >> 5),
+                                acc, (wv + 1) >> 1);
         tx = ntx; ty = nty; n = nn;
     }
     const int ci = ci0 + (lane & 31);
@@ -1226,15 +1253,19 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
     }
 }
 
+// EDGE = false: tile columns txb .. txb + tilesX - 1 with the full 16-step stage; EDGE = true: the (single) right-edge
+// tile column with the interleaved short stage.  The launcher uses the second variant when the last tile of a row
+// has <= 24 valid columns; its split-K partials follow the main launch's in the workspace.
+template <bool EDGE>
 __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_buf_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
-    int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S)
+    int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S, int txb)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * WB_STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave < 4) wgrad_buf_body<0>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, wave, lane);
-    else wgrad_buf_body<1>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, wave, lane);
+    if (wave < 4) wgrad_buf_body<0, EDGE>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, txb, wave, lane);
+    else wgrad_buf_body<1, EDGE>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, txb, wave, lane);
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
@@ -1332,6 +1363,18 @@ int wgrad_impl()
         impl = (e && e[0] == '2') ? 2 : 3;
     }
     return impl;
+}
+
+// split-K factor of the separate right-edge launch of the buffer-DMA wgrad (0 = no separate launch)
+int wgrad_edge_splits(int n, int cin, int cout, int h, int w)
+{
+    const int tilesX = cdiv(w, TW), wv = w - (tilesX - 1) * TW;
+    if (!(conv_impl() >= 2 && wgrad_impl() == 3) || tilesX < 2 || wv > 24) return 0;
+    const int base = cdiv(cout, 128) * cdiv(cin, 32);
+    const int64_t nTiles = (int64_t)n * h;
+    int S = cdiv(512, base);
+    if (S > nTiles) S = (int)nTiles;
+    return S < 1 ? 1 : S;
 }
 
 bool stem_direct()
@@ -1464,8 +1507,9 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 {
-    // split-K partials + zero page for the DMA kernel + bias-gradient partials
-    return (int64_t)wgrad_splits(n, cin, cout, h, w) * 9 * cout * cin + 64 + (int64_t)cout * BG_SLOTS;
+    // split-K partials (main + right-edge launch) + zero page for the DMA kernel + bias-gradient partials
+    return (int64_t)(wgrad_splits(n, cin, cout, h, w) + wgrad_edge_splits(n, cin, cout, h, w)) * 9 * cout * cin + 64 +
+           (int64_t)cout * BG_SLOTS;
 }
 
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
@@ -1474,13 +1518,25 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0, "conv3x3_wgrad: bad args");
     const int tilesX = cdiv(w, TW), tilesY = h;
     const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
-    const int S = wgrad_splits(n, cin, cout, h, w);
+    int S = wgrad_splits(n, cin, cout, h, w);
+    const int Se = wgrad_edge_splits(n, cin, cout, h, w);
+    const int64_t bg_off = (int64_t)(S + Se) * 9 * cout * cin;
     hipStream_t st = (hipStream_t)s;
     if (conv_impl() >= 2 && wgrad_impl() == 3 && (int64_t)128 * h * w < (1 << 28)) {
-        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n, cin,
-                           cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);
+        if (Se > 0) {
+            // the right-edge tile column has few valid pixels: give it the short interleaved stage in its own launch
+            hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n,
+                               cin, cout, h, w, tilesX - 1, tilesY, coTiles, ciTiles, S, 0);
+            hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<true>, dim3(coTiles * ciTiles * Se), dim3(512), 0, st, x, dy,
+                               ws + (int64_t)S * 9 * cout * cin, n, cin, cout, h, w, 1, tilesY, coTiles, ciTiles, Se,
+                               tilesX - 1);
+            S += Se;
+        } else {
+            hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n,
+                               cin, cout, h, w, tilesX, tilesY, coTiles, ciTiles, S, 0);
+        }
     } else if (conv_impl() >= 2 && (int64_t)128 * h * w < (1 << 24)) {
-        float* zero_page = ws + (int64_t)S * 9 * cout * cin;
+        float* zero_page = ws + bg_off;
         hipError_t e = hipMemsetAsync(zero_page, 0, 64 * sizeof(float), st);
         if (e != hipSuccess) { ptmi_set_error("conv3x3_wgrad: memset failed"); return -2; }
         hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n, cin,
@@ -1495,7 +1551,7 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
                        cout, cin, S, accumulate);
     PTMI_LAUNCH_CHECK("conv3x3_wgrad_reduce");
     if (db) {
-        float* part = ws + (int64_t)S * 9 * cout * cin + 64;
+        float* part = ws + bg_off + 64;
         hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
         PTMI_LAUNCH_CHECK("conv3x3_bias_grad_partial");
         hipLaunchKernelGGL(bias_grad_final_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, part, db, cout, accumulate);
