@@ -94,11 +94,13 @@ int ptmi_rowsum_batched(const float* a, float* out, int batch, int rows, int col
  * pt/modeling/roi_heads/roi_heads.py:68-73 and called at :126.  rois (R,5)=[img,x1,y1,x2,y2]. */
 int ptmi_roi_align_fwd(const float* feat, const float* rois, float* out, int n, int c, int h,
                        int w, int r, int pooled, float scale, ptmi_stream_t s);
-/* Same result (bit for bit) for rois GROUPED BY IMAGE (img_offsets int32 (n+1) device array): channel planes are
- * staged in LDS once per image and the per-ROI sample geometry is tabulated once instead of once per channel. */
+/* Same result (bit for bit) for rois GROUPED BY IMAGE (img_offsets int32 (n+1) device array): the per-ROI sample
+ * taps are tabulated once into `ws` (ptmi_roi_align_ws_bytes(r, h, w) bytes of device scratch), channel planes are
+ * staged in LDS once per image.  ws == NULL falls back to ptmi_roi_align_fwd. */
+int64_t ptmi_roi_align_ws_bytes(int r, int h, int w);
 int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32_t* img_offsets,
-                               float* out, int n, int c, int h, int w, int r, int pooled, float scale,
-                               ptmi_stream_t s);
+                               float* out, void* ws, int n, int c, int h, int w, int r, int pooled,
+                               float scale, ptmi_stream_t s);
 /* dfeat must be zeroed by the caller (atomic scatter-add). */
 int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n, int c, int h,
                        int w, int r, int pooled, float scale, ptmi_stream_t s);

@@ -187,6 +187,92 @@ __global__ __launch_bounds__(RF_THREADS) void roi_align_fwd_grouped_kernel(const
     }
 }
 
+// Second-generation grouped forward (default).  The kernel above rebuilds each ROI's tap tables in every channel-group
+// workgroup (128 times per ROI for C = 512) behind two barriers per pair of ROIs, and leaves a quarter of its threads
+// idle.  Here the tables are built once per ROI by roi_tables_kernel into a workspace (header + 2 * TS entries per
+// ROI); the gather kernel keeps CG = 4 channel planes of one image in LDS, runs 5 ROIs at a time on 980 of its 1024
+// threads (thread = (roi slot, channel, bin)) and needs no barrier after the planes are loaded.  Per-sample
+// arithmetic and summation order are unchanged, so the result is still bit-identical to the plain gather kernel.
+struct RoiHeader { int gh, gw; float count; int pad; };
+
+__global__ __launch_bounds__(256) void roi_tables_kernel(const float* __restrict__ rois, void* __restrict__ ws, int R,
+                                                         int H, int W, float scale, int TS)
+{
+    const int r = blockIdx.x, t = threadIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, 7);
+    char* base = (char*)ws + (size_t)r * (sizeof(RoiHeader) + 2 * (size_t)TS * sizeof(TapEntry));
+    if (t == 0) {
+        RoiHeader h;
+        h.gh = g.gh; h.gw = g.gw; h.count = g.count; h.pad = 0;
+        *reinterpret_cast<RoiHeader*>(base) = h;
+    }
+    TapEntry* tab = reinterpret_cast<TapEntry*>(base + sizeof(RoiHeader));
+    const int ny = 7 * g.gh, nx = 7 * g.gw;
+    for (int i = t; i < ny + nx; i += 256) {
+        const bool isx = i >= ny;
+        const int sidx = isx ? i - ny : i;
+        const int gn = isx ? g.gw : g.gh, L = isx ? W : H;
+        const int pb = sidx / gn, k = sidx - pb * gn;
+        const float start = isx ? g.sw : g.sh, bsz = isx ? g.bw : g.bh;
+        float v = start + (float)pb * bsz + ((float)k + .5f) * bsz / (float)gn;
+        TapEntry e;
+        if (v < -1.0f || v > (float)L) { e.lo = -1; e.hi = -1; e.wlo = e.whi = 0.f; }
+        else {
+            if (v <= 0.f) v = 0.f;
+            int l = (int)v, h2;
+            if (l >= L - 1) { h2 = l = L - 1; v = (float)l; } else h2 = l + 1;
+            const float lw = v - (float)l;
+            e.lo = l; e.hi = h2; e.whi = lw; e.wlo = 1.f - lw;
+        }
+        if (sidx < TS) tab[(isx ? TS : 0) + sidx] = e;
+    }
+}
+
+constexpr int RF2_THREADS = 1024, RF2_SLOTS = 5;
+
+__global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const float* __restrict__ feat,
+                                                                        const void* __restrict__ ws,
+                                                                        const int32_t* __restrict__ img_off,
+                                                                        float* __restrict__ out, int C, int H, int W,
+                                                                        int CG, int TS)
+{
+    extern __shared__ float smem[];
+    const int HW = H * W;
+    float* plane = smem;                                                 // CG * HW
+    const int n = blockIdx.y, c0 = blockIdx.x * CG;
+    const int cg = min(CG, C - c0);
+    const int tid = threadIdx.x;
+    const float* src = feat + ((size_t)n * C + c0) * HW;
+    for (int i = tid; i < cg * HW; i += RF2_THREADS) plane[i] = src[i];
+    __syncthreads();
+    const int slot = tid / 196, t = tid - slot * 196;
+    const int c = t / 49, rem = t - c * 49;
+    const int ph = rem / 7, pw = rem - ph * 7;
+    if (slot >= RF2_SLOTS || c >= cg) return;
+    const float* f = plane + c * HW;
+    const size_t rstride = sizeof(RoiHeader) + 2 * (size_t)TS * sizeof(TapEntry);
+    const int r1 = img_off[n + 1];
+    for (int r = img_off[n] + slot; r < r1; r += RF2_SLOTS) {
+        const char* base = (const char*)ws + (size_t)r * rstride;
+        const RoiHeader hd = *reinterpret_cast<const RoiHeader*>(base);
+        const TapEntry* yt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + ph * hd.gh;
+        const TapEntry* xt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + TS + pw * hd.gw;
+        float acc = 0.f;
+        for (int iy = 0; iy < hd.gh; ++iy) {
+            const TapEntry ey = yt[iy];
+            if (ey.lo < 0) continue;
+            for (int ix = 0; ix < hd.gw; ++ix) {
+                const TapEntry ex = xt[ix];
+                if (ex.lo < 0) continue;
+                const float w1 = ey.wlo * ex.wlo, w2 = ey.wlo * ex.whi, w3 = ey.whi * ex.wlo, w4 = ey.whi * ex.whi;
+                acc += w1 * f[ey.lo * W + ex.lo] + w2 * f[ey.lo * W + ex.hi] + w3 * f[ey.hi * W + ex.lo] +
+                       w4 * f[ey.hi * W + ex.hi];
+            }
+        }
+        out[((size_t)r * C + c0) * 49 + t] = acc / hd.count;
+    }
+}
+
 // Backward without any atomics.  ROIAlign is separable: a sample's bilinear weight is wy(sample_y, cell_y) *
 // wx(sample_x, cell_x) and its bin is (ph(sample_y), pw(sample_x)), so for one ROI and one channel
 //     dF[fy][fx] += (1/count) * sum_{ph,pw} Wy[fy][ph] * dOut[ph][pw] * Wx[fx][pw]
@@ -316,30 +402,43 @@ int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n
     return 0;
 }
 
-int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32_t* img_offsets, float* out, int n,
-                               int c, int h, int w, int r, int pooled, float scale, ptmi_stream_t s)
+static int roi_tab_stride(int h, int w)
+{
+    // adaptive grid g = ceil(roi/7) in feature cells is at most ceil((dim+1)/7) (+1 slack); a table holds 7*g entries
+    const int gmax = ((h > w ? h : w) + 1 + 6) / 7 + 1;
+    return (7 * gmax + 3) & ~3;
+}
+
+int64_t ptmi_roi_align_ws_bytes(int r, int h, int w)
+{
+    return (int64_t)(r > 0 ? r : 1) * (int64_t)(sizeof(RoiHeader) + 2 * (size_t)roi_tab_stride(h, w) * sizeof(TapEntry));
+}
+
+int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32_t* img_offsets, float* out, void* ws,
+                               int n, int c, int h, int w, int r, int pooled, float scale, ptmi_stream_t s)
 {
     if (r == 0) return 0;
     PTMI_CHECK_ARG(feat && rois && img_offsets && out && n > 0 && c > 0 && h > 0 && w > 0 && r > 0 && pooled > 0,
                    "roi_align_fwd_grouped: bad args");
     const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    const size_t tabs = 4 * RF_MAXS * sizeof(TapEntry);
-    const size_t budget = 76 * 1024;                         // two workgroups per CU
-    // adaptive grid g = ceil(roi/7) in feature cells is at most ceil((dim+1)/7); tables hold 7*g <= RF_MAXS entries
-    const int gmax = ((h > w ? h : w) + 1 + 6) / 7 + 1;
-    if (pooled != 7 || plane_bytes + tabs > budget || 7 * gmax > RF_MAXS)
+    const size_t budget = 72 * 1024;                         // two workgroups per CU
+    if (pooled != 7 || plane_bytes > budget || !ws)
         return ptmi_roi_align_fwd(feat, rois, out, n, c, h, w, r, pooled, scale, s);
-    int cg = (int)((budget - tabs) / plane_bytes);
+    int cg = (int)(budget / plane_bytes);
     if (cg > 4) cg = 4;
     if (cg > c) cg = c;
+    const int TS = roi_tab_stride(h, w);
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(roi_tables_kernel, dim3(r), dim3(256), 0, st, rois, ws, r, h, w, scale, TS);
+    PTMI_LAUNCH_CHECK("roi_align_tables");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)roi_align_fwd_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)roi_align_fwd_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(roi_align_fwd_grouped_kernel, dim3(cdiv(c, cg), n), dim3(RF_THREADS),
-                       (size_t)cg * plane_bytes + tabs, (hipStream_t)s, feat, rois, img_offsets, out, c, h, w, scale, cg);
+    hipLaunchKernelGGL(roi_align_fwd_tab_kernel, dim3(cdiv(c, cg), n), dim3(RF2_THREADS), (size_t)cg * plane_bytes, st,
+                       feat, ws, img_offsets, out, c, h, w, cg, TS);
     PTMI_LAUNCH_CHECK("roi_align_fwd_grouped");
     return 0;
 }

@@ -389,8 +389,9 @@ class _ROIAlign(torch.autograd.Function):
         out = torch.empty((r, c, pooled, pooled), dtype=F32, device=feat.device)
         with _prof("roi_align_fwd"):
             if img_offsets is not None:
+                ws = torch.empty(_lib.load().ptmi_roi_align_ws_bytes(r, h, w), dtype=torch.uint8, device=feat.device)
                 _lib.call("ptmi_roi_align_fwd_grouped", _ptr(feat), _ptr(rois), _ptr(_chk(img_offsets, torch.int32)),
-                          _ptr(out), n, c, h, w, r, pooled, float(scale), _stream())
+                          _ptr(out), _ptr(ws), n, c, h, w, r, pooled, float(scale), _stream())
             else:
                 _lib.call("ptmi_roi_align_fwd", _ptr(feat), _ptr(rois), _ptr(out), n, c, h, w, r, pooled, float(scale),
                           _stream())
