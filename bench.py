@@ -77,6 +77,22 @@ def cpu_baseline(h, w, K, seed=0):
                       f"1 unlabelled {w}x{h} image, {dt:.1f} s"}
 
 
+def pmc_traffic():
+    """HBM-side bytes per conv fwd/dgrad launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_bench_b16_pmc_by_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc passes;
+    FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  None if the profile is absent."""
+    f = os.path.join(ROOT, "profiles", "r01_bench_b16_pmc_by_kernel.json")
+    if not os.path.exists(f):
+        return None
+    d = json.load(open(f))
+    tot, n = 0.0, 0
+    for k, v in d.items():
+        if k.startswith("conv3x3_buf_kernel") or k.startswith("conv3x3_direct_kernel"):
+            tot += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
+            n += v["dispatches"]
+    return tot / n if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,8 +169,9 @@ def main():
                                    f"{B} labelled + {B} unlabelled synthetic {W}x{H} images, BURN_UP_STEP=0, random init",
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "conv3x3_mfma_kernel (fwd + dgrad launches)", "calls": conv["calls"],
+                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, committed profile)",
+                         "kernel": "conv3x3_buf_kernel<BM,NWAVE> (all 3x3 conv fwd + dgrad launches)", "calls": conv["calls"],
                          "avg_launch_ms": conv["ms"] / max(conv["calls"], 1),
                          "flops_per_launch_avg": conv["flops"] / max(conv["calls"], 1)},
             "kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12)
