@@ -258,15 +258,37 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
         const TapEntry* yt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + ph * hd.gh;
         const TapEntry* xt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + TS + pw * hd.gw;
         float acc = 0.f;
-        for (int iy = 0; iy < hd.gh; ++iy) {
-            const TapEntry ey = yt[iy];
-            if (ey.lo < 0) continue;
-            for (int ix = 0; ix < hd.gw; ++ix) {
-                const TapEntry ex = xt[ix];
-                if (ex.lo < 0) continue;
-                const float w1 = ey.wlo * ex.wlo, w2 = ey.wlo * ex.whi, w3 = ey.whi * ex.wlo, w4 = ey.whi * ex.whi;
-                acc += w1 * f[ey.lo * W + ex.lo] + w2 * f[ey.lo * W + ex.hi] + w3 * f[ey.hi * W + ex.lo] +
-                       w4 * f[ey.hi * W + ex.hi];
+        if (hd.gw <= 4) {
+            // common case: the bin's column taps live in registers for all sample rows (same summation order)
+            TapEntry ex[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < hd.gw) ex[k] = xt[k];
+                else { ex[k].lo = -1; ex[k].hi = -1; ex[k].wlo = ex[k].whi = 0.f; }
+            }
+            for (int iy = 0; iy < hd.gh; ++iy) {
+                const TapEntry ey = yt[iy];
+                if (ey.lo < 0) continue;
+                const float* f0 = f + ey.lo * W;
+                const float* f1 = f + ey.hi * W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (ex[k].lo < 0) continue;
+                    const float w1 = ey.wlo * ex[k].wlo, w2 = ey.wlo * ex[k].whi, w3 = ey.whi * ex[k].wlo, w4 = ey.whi * ex[k].whi;
+                    acc += w1 * f0[ex[k].lo] + w2 * f0[ex[k].hi] + w3 * f1[ex[k].lo] + w4 * f1[ex[k].hi];
+                }
+            }
+        } else {
+            for (int iy = 0; iy < hd.gh; ++iy) {
+                const TapEntry ey = yt[iy];
+                if (ey.lo < 0) continue;
+                for (int ix = 0; ix < hd.gw; ++ix) {
+                    const TapEntry ex = xt[ix];
+                    if (ex.lo < 0) continue;
+                    const float w1 = ey.wlo * ex.wlo, w2 = ey.wlo * ex.whi, w3 = ey.whi * ex.wlo, w4 = ey.whi * ex.whi;
+                    acc += w1 * f[ey.lo * W + ex.lo] + w2 * f[ey.lo * W + ex.hi] + w3 * f[ey.hi * W + ex.lo] +
+                           w4 * f[ey.hi * W + ex.hi];
+                }
             }
         }
         out[((size_t)r * C + c0) * 49 + t] = acc / hd.count;
