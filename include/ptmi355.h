@@ -106,9 +106,11 @@ int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n
                        int w, int r, int pooled, float scale, ptmi_stream_t s);
 /* Same result for rois GROUPED BY IMAGE (rows img_offsets[i]..img_offsets[i+1] belong to image i; int32
  * device array of n+1): each workgroup accumulates a few channel planes of one image in LDS and writes them
- * once -- no global atomics, dfeat need not be zeroed (every element is written). */
+ * once -- no global atomics, dfeat need not be zeroed (every element is written).  `ws`:
+ * ptmi_roi_align_bwd_ws_bytes(r, h, w) bytes of device scratch for the per-ROI weight tables (NULL: slower kernel). */
+int64_t ptmi_roi_align_bwd_ws_bytes(int r, int h, int w);
 int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32_t* img_offsets,
-                               float* dfeat, int n, int c, int h, int w, int r, int pooled,
+                               float* dfeat, void* ws, int n, int c, int h, int w, int r, int pooled,
                                float scale, ptmi_stream_t s);
 
 /* ------------------------------------------------------------------ boxes (N4, N5, N9)

@@ -6,6 +6,7 @@
 // channels with threads laid out along (c, ph, pw) so that the (R, C, 7, 7) output is written with
 // fully coalesced stores.  Backward scatters with hardware fp32 atomics (-munsafe-fp-atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -396,6 +397,147 @@ __global__ __launch_bounds__(RB_THREADS) void roi_align_bwd_sep_kernel(const flo
     for (int i = tid; i < cg * HW; i += RB_THREADS) dst[i] = plane[i];
 }
 
+// Third-generation backward (default for 7x7 pooling, W <= 128): same separable formulation, but
+//   * the per-ROI 1-D weight tables (Wy rows y0..y1, Wx rows x0..x1, 8 floats per row) are built ONCE per ROI by
+//     roi_bwd_tables_kernel into a workspace instead of by 14 threads of every channel-group workgroup, and
+//   * every thread owns a FIXED column (channel c = tid / 128, feature column fx = tid % 128) of the LDS planes for
+//     the whole ROI walk, so consecutive ROIs never hand a cell from one thread to another: the ROI loop has no
+//     barrier at all (the kernel above needs three per ROI and keeps ~80 of 512 threads busy).
+// Each wave stages the ROI's Wy rows in a private LDS strip (broadcast reads in the column loop), pulls dOut[r][c]
+// through scalar loads (the channel is wave-uniform) and its own Wx row with two 16-B loads.
+struct RoiBwdHeader { int y0, y1, x0, x1; float count; int pad[3]; };
+constexpr int RB2_THREADS = 512, RB2_XP = 128;
+
+__global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restrict__ rois, void* __restrict__ ws,
+                                                            int H, int W, float scale)
+{
+    extern __shared__ float tsm[];                   // Wy_abs[H][8] | Wx_abs[W][8]
+    __shared__ int rng[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, 7);
+    for (int i = tid; i < (H + W) * 8; i += 64) tsm[i] = 0.f;
+    if (tid < 4) rng[tid] = (tid & 1) ? -1 : (1 << 30);                    // ymin, ymax, xmin, xmax
+    __syncthreads();
+    if (tid < 14) {
+        const bool isx = tid >= 7;
+        const int pb = isx ? tid - 7 : tid;
+        const int gn = isx ? g.gw : g.gh, L = isx ? W : H;
+        const float start = isx ? g.sw : g.sh, bsz = isx ? g.bw : g.bh;
+        float* Wt = isx ? tsm + H * 8 : tsm;
+        int lo = 1 << 30, hi = -1;
+        for (int i = 0; i < gn; ++i) {
+            float v = start + (float)pb * bsz + ((float)i + .5f) * bsz / (float)gn;
+            if (v < -1.0f || v > (float)L) continue;
+            if (v <= 0.f) v = 0.f;
+            int l = (int)v, h2;
+            if (l >= L - 1) { h2 = l = L - 1; v = (float)l; } else h2 = l + 1;
+            const float lw = v - (float)l, hw = 1.f - lw;
+            Wt[l * 8 + pb] += hw;
+            Wt[h2 * 8 + pb] += lw;
+            lo = min(lo, l);
+            hi = max(hi, h2);
+        }
+        if (hi >= 0) {
+            atomicMin(&rng[isx ? 2 : 0], lo);
+            atomicMax(&rng[isx ? 3 : 1], hi);
+        }
+    }
+    __syncthreads();
+    const size_t stride = sizeof(RoiBwdHeader) + (size_t)(H + W) * 8 * sizeof(float);
+    char* base = (char*)ws + (size_t)r * stride;
+    const int y0 = rng[0], y1 = rng[1], x0 = rng[2], x1 = rng[3];
+    if (tid == 0) {
+        RoiBwdHeader hd;
+        hd.y0 = y0; hd.y1 = (x1 >= 0) ? y1 : -1; hd.x0 = x0; hd.x1 = (y1 >= 0) ? x1 : -1; hd.count = g.count;
+        hd.pad[0] = hd.pad[1] = hd.pad[2] = 0;
+        *reinterpret_cast<RoiBwdHeader*>(base) = hd;
+    }
+    float* wy = reinterpret_cast<float*>(base + sizeof(RoiBwdHeader));
+    float* wx = wy + (size_t)H * 8;
+    if (y1 >= 0 && x1 >= 0) {
+        for (int i = tid; i < (y1 - y0 + 1) * 8; i += 64) wy[i] = tsm[y0 * 8 + i];
+        for (int i = tid; i < (x1 - x0 + 1) * 8; i += 64) wx[i] = tsm[(H + x0) * 8 + i];
+    }
+}
+
+__global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const float* __restrict__ dout,
+                                                                        const void* __restrict__ ws,
+                                                                        const int32_t* __restrict__ img_off,
+                                                                        float* __restrict__ dfeat, int C, int H, int W,
+                                                                        int CG)
+{
+    extern __shared__ float smem[];
+    const int HW = H * W;
+    float* plane = smem;                                         // CG * HW
+    float* wystage = plane + CG * HW;                            // 8 waves x H x 8
+    const int n = blockIdx.y, c0 = blockIdx.x * CG;
+    const int cg = min(CG, C - c0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < cg * HW; i += RB2_THREADS) plane[i] = 0.f;
+    __syncthreads();
+    const int c = wave >> 1;                                     // wave-uniform channel; two waves cover 128 columns
+    const int fx = (wave & 1) * 64 + lane;
+    float* wyl = wystage + wave * H * 8;
+    const size_t stride = sizeof(RoiBwdHeader) + (size_t)(H + W) * 8 * sizeof(float);
+    const int r1 = img_off[n + 1];
+    if (c < cg) {
+        float* col = plane + c * HW + fx;
+        for (int r = img_off[n]; r < r1; ++r) {
+            const char* base = (const char*)ws + (size_t)r * stride;
+            const RoiBwdHeader hd = *reinterpret_cast<const RoiBwdHeader*>(base);
+            if (hd.y1 < 0 || hd.x1 < 0) continue;
+            const int lo = (wave & 1) * 64;
+            if (hd.x1 < lo || hd.x0 > lo + 63) continue;         // no column of this wave inside the ROI (uniform)
+            const float* wyg = reinterpret_cast<const float*>(base + sizeof(RoiBwdHeader));
+            const float* wxg = wyg + (size_t)H * 8;
+            const int ny = hd.y1 - hd.y0 + 1;
+            // stage Wy rows (ny x 8 floats) in this wave's LDS strip
+            for (int i = lane; i < ny * 2; i += 64)
+                reinterpret_cast<f32x4*>(wyl)[i] = reinterpret_cast<const f32x4*>(wyg)[i];
+            __builtin_amdgcn_wave_barrier();                     // the strip is read by other lanes of this wave
+            const bool act = fx >= hd.x0 && fx <= hd.x1;
+            f32x4 wxa = {0.f, 0.f, 0.f, 0.f}, wxb = {0.f, 0.f, 0.f, 0.f};
+            if (act) {
+                wxa = reinterpret_cast<const f32x4*>(wxg)[(fx - hd.x0) * 2];
+                wxb = reinterpret_cast<const f32x4*>(wxg)[(fx - hd.x0) * 2 + 1];
+            }
+            const float* ob = dout + ((size_t)r * C + c0 + c) * 49;     // wave-uniform: scalar loads
+            float t[7];
+#pragma unroll
+            for (int ph = 0; ph < 7; ++ph) {
+                float a = ob[ph * 7 + 0] * wxa[0];
+                a += ob[ph * 7 + 1] * wxa[1];
+                a += ob[ph * 7 + 2] * wxa[2];
+                a += ob[ph * 7 + 3] * wxa[3];
+                a += ob[ph * 7 + 4] * wxb[0];
+                a += ob[ph * 7 + 5] * wxb[1];
+                a += ob[ph * 7 + 6] * wxb[2];
+                t[ph] = a / hd.count;
+            }
+            if (act) {
+                float* cp = col + hd.y0 * W;
+                for (int k = 0; k < ny; ++k) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wyl + k * 8);
+                    const f32x4 wb = *reinterpret_cast<const f32x4*>(wyl + k * 8 + 4);
+                    float a = wa[0] * t[0];
+                    a += wa[1] * t[1];
+                    a += wa[2] * t[2];
+                    a += wa[3] * t[3];
+                    a += wb[0] * t[4];
+                    a += wb[1] * t[5];
+                    a += wb[2] * t[6];
+                    cp[k * W] += a;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                     // next ROI overwrites the strip
+        }
+    }
+    __syncthreads();
+    float* dst = dfeat + ((size_t)n * C + c0) * HW;
+    for (int i = tid; i < cg * HW; i += RB2_THREADS) dst[i] = plane[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -465,8 +607,13 @@ int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32
     return 0;
 }
 
-int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32_t* img_offsets, float* dfeat, int n,
-                               int c, int h, int w, int r, int pooled, float scale, ptmi_stream_t s)
+int64_t ptmi_roi_align_bwd_ws_bytes(int r, int h, int w)
+{
+    return (int64_t)(r > 0 ? r : 1) * (int64_t)(sizeof(RoiBwdHeader) + (size_t)(h + w) * 8 * sizeof(float));
+}
+
+int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32_t* img_offsets, float* dfeat, void* ws,
+                               int n, int c, int h, int w, int r, int pooled, float scale, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(dfeat && img_offsets && n > 0 && c > 0 && h > 0 && w > 0 && r >= 0 && pooled > 0,
                    "roi_align_bwd_grouped: bad args");
@@ -480,6 +627,25 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
         return r == 0 ? 0 : ptmi_roi_align_bwd(dout, rois, dfeat, n, c, h, w, r, pooled, scale, s);
     }
     PTMI_CHECK_ARG(dout && rois, "roi_align_bwd_grouped: null buffer");
+    static int impl = -1;                 // PTMI_ROI_BWD_IMPL=1: the barrier-per-ROI kernel
+    if (impl < 0) { const char* e = getenv("PTMI_ROI_BWD_IMPL"); impl = (e && e[0] == '1') ? 1 : 2; }
+    const size_t stage = (size_t)(RB2_THREADS / 64) * h * 8 * sizeof(float);
+    if (impl == 2 && ws && w <= RB2_XP && 4 * plane_bytes + stage <= 79 * 1024) {
+        hipLaunchKernelGGL(roi_bwd_tables_kernel, dim3(r), dim3(64), (size_t)(h + w) * 8 * sizeof(float), st, rois, ws, h,
+                           w, scale);
+        PTMI_LAUNCH_CHECK("roi_align_bwd_tables");
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr2 = true;
+        }
+        const int cg = c < 4 ? c : 4;
+        hipLaunchKernelGGL(roi_align_bwd_col_kernel, dim3(cdiv(c, cg), n), dim3(RB2_THREADS), 4 * plane_bytes + stage, st,
+                           dout, ws, img_offsets, dfeat, c, h, w, cg);
+        PTMI_LAUNCH_CHECK("roi_align_bwd_grouped(col)");
+        return 0;
+    }
     int cg = (int)((budget - extra) / plane_bytes);
     if (cg > 4) cg = 4;
     if (cg > c) cg = c;

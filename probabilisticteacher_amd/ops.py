@@ -408,8 +408,10 @@ class _ROIAlign(torch.autograd.Function):
             # rois grouped by image: LDS-accumulating kernel, no global atomics, writes every element of dfeat
             dfeat = torch.empty((n, c, h, w), dtype=F32, device=dout.device)
             with _prof("roi_align_bwd"):
+                ws = torch.empty(_lib.load().ptmi_roi_align_bwd_ws_bytes(rois.shape[0], h, w), dtype=torch.uint8,
+                                 device=dout.device)
                 _lib.call("ptmi_roi_align_bwd_grouped", _ptr(dout), _ptr(rois), _ptr(_chk(img_offsets, torch.int32)),
-                          _ptr(dfeat), n, c, h, w, rois.shape[0], pooled, scale, _stream())
+                          _ptr(dfeat), _ptr(ws), n, c, h, w, rois.shape[0], pooled, scale, _stream())
         else:
             dfeat = torch.zeros((n, c, h, w), dtype=F32, device=dout.device)
             with _prof("roi_align_bwd"):
