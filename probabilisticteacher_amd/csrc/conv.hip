@@ -411,14 +411,15 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // grid = (coTiles, tilesX * tilesY, N): channel tile fastest in the linear workgroup order, no integer divisions
-    // beyond one.
-    // Tiles are numbered column-major (ty fastest): the XCD of a workgroup is its linear id mod 8 = cot + coTiles *
-    // (tile parity ...), and with row-major numbering and an even tilesX every (light) right-edge tile would land
-    // on the same half of the XCDs (measured: 13 % of the slot-time empty on 100x166 maps).
+    // grid = (coTiles, N * tilesY, tilesX), linear workgroup order = channel tile, image, tile row, tile column:
+    //   * the four channel tiles of one pixel tile are neighbours in time (they share the input patch through L2);
+    //   * the XCD of a workgroup (linear id mod 8) alternates with the image index, so the light right-edge tiles
+    //     (an even tilesX with row-major numbering put all of them on four XCDs: 13 % of slot-time empty at 100x166)
+    //     spread evenly;
+    //   * the light right-edge tile column is dispatched last, which shortens the tail of the launch.
     const int cot = blockIdx.x;
-    const int tx = blockIdx.y / tilesY, ty = blockIdx.y - tx * tilesY;
-    const int n = blockIdx.z;
+    const int ty = blockIdx.y / N, n = blockIdx.y - ty * N;
+    const int tx = blockIdx.z;
     const int x0 = tx * TW, y0 = ty * TH;
     const int HW = H * W;
     const int wv = W - x0;                           // valid columns right of x0
@@ -1468,8 +1469,8 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
         return 0;
     }
     if (CK == 4 && conv_impl() == 4 && (int64_t)cin * h * w * 4 < (1ll << 32) && ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) &&
-        (int64_t)tilesX * tilesY < 65536 && n < 65536) {
-        const dim3 grid3((unsigned)coTiles, (unsigned)(tilesX * tilesY), (unsigned)n);
+        (int64_t)n * tilesY < 65536 && tilesX < 65536) {
+        const dim3 grid3((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
 #define LBUF(BM_, NW_) hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, \
                                           y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
         if (BM == 128 && use8) LBUF(128, 8);
