@@ -188,190 +188,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_mfma_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------ forward, LDS-DMA pipeline
-// Same tiling as conv3x3_mfma_kernel, but operands go global -> LDS directly (global_load_lds, no VGPR
-// staging, no ds_write), double-buffered with ONE workgroup barrier per 4-channel chunk:
-//   issue DMA(chunk c+1 -> buf^1) ; 72 MFMAs on buf ; s_waitcnt vmcnt(0) ; s_barrier
-// The weight slab is linear in both address spaces (16-B DMA pieces); the halo patch is a per-lane gather
-// (4-B pieces) whose out-of-image / padded-channel lanes read the zero page appended to the packed weights.
-// ~90 VGPRs and 43 KB LDS => three workgroups per CU, none of them holding staging registers.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(3))) void lds_void_b_t;
-typedef __attribute__((address_space(1))) void gbl_void_t;
-
-__device__ __forceinline__ void dma16(const float* g, float* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ void dma4(const float* g, float* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)lds_wave_base, 4, 0, 0);
-}
-
-template <int BM, bool PRIO, int NWAVE>
-__global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_dma_kernel(
-    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
-    int tilesX, int tilesY, int coTiles, int nChunks, int epi, const float* __restrict__ zero_page)
-{
-    constexpr int CK = 4;
-    constexpr int NT = 64 * NWAVE;
-    constexpr int WN = NWAVE / (BM / 64);            // wave columns (pixel row pairs) per workgroup
-    constexpr int TH = 2 * WN, PLANE = (TH + 2) * PW;
-    constexpr int WS = 9 * CK * BM;
-    constexpr int PS = CK * PLANE;
-    constexpr int WS4 = WS / 4;
-    constexpr int NW4 = (WS4 + NT - 1) / NT;
-    constexpr int NP = (PS + NT - 1) / NT;
-    constexpr int STAGE = WS + ((PS + 63) / 64) * 64;       // floats per buffer (patch padded to a wave multiple)
-    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int cot = bid % coTiles;
-    int pt = bid / coTiles;
-    const int tx = pt % tilesX;
-    pt /= tilesX;
-    const int ty = pt % tilesY;
-    const int n = pt / tilesY;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int HW = H * W;
-
-    int poff[NP];
-    unsigned pvalid = 0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int idx = tid + i * NT;
-        poff[i] = 0;
-        if (idx < PS) {
-            const int ci = idx / PLANE, rem = idx - ci * PLANE;
-            const int r = rem / PW, c = rem - r * PW;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                poff[i] = ci * HW + gy * W + gx;
-                pvalid |= 1u << i;
-            }
-        }
-    }
-    const float* xn = x + (size_t)n * Cin * HW;
-    const float* wbase = wp + (size_t)cot * nChunks * WS;
-    const int wave_base = tid & ~63;
-
-    auto issue = [&](int chunk, int buf) {
-        float* Wd = lds + buf * STAGE;
-        float* Pd = Wd + WS;
-        const float* wsrc = wbase + (size_t)chunk * WS;
-#pragma unroll
-        for (int i = 0; i < NW4; ++i) {
-            const int idx = tid + i * NT;                       // float4 index
-            if (wave_base + i * NT < WS4) {                     // wave-uniform guard (WS4 is a multiple of 64)
-                dma16(wsrc + (size_t)idx * 4, Wd + (size_t)(wave_base + i * NT) * 4);
-            }
-        }
-        const int c0 = chunk * CK;
-        const float* xc = xn + (size_t)c0 * HW;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * NT;
-            if (wave_base + i * NT < PS) {                      // wave-uniform: whole wave beyond the patch skips
-                const bool ok = idx < PS && ((pvalid >> i) & 1u) && (c0 + idx / PLANE) < Cin;
-                const float* src = ok ? xc + poff[i] : zero_page + (lane & 63);
-                dma4(src, Pd + wave_base + i * NT);
-            }
-        }
-    };
-
-    const int wm = wave / WN;
-    const int wn = wave % WN;
-    const int a_off = wm * 64 + (lane & 31) + (lane >> 5) * BM;
-    const int b_off = WS + (lane >> 5) * PLANE + (wn * 2) * PW + (lane & 31);
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-
-    issue(0, 0);
-    for (int chunk = 0; chunk < nChunks; ++chunk) {
-        const int buf = chunk & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's DMA pieces of `buf` have landed
-        __syncthreads();                                          // everyone's pieces landed; buf^1 is free
-        if (chunk + 1 < nChunks) issue(chunk + 1, buf ^ 1);
-        const float* wsl = lds + buf * STAGE + a_off;
-        const float* psl = lds + buf * STAGE + b_off;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-            for (int j = 0; j < CK / 2; ++j) {
-                const float a0 = wsl[(tap * CK + 2 * j) * BM];
-                const float a1 = wsl[(tap * CK + 2 * j) * BM + 32];
-                const float b0 = psl[2 * j * PLANE + (0 + ky) * PW + kx];
-                const float b1 = psl[2 * j * PLANE + (1 + ky) * PW + kx];
-                acc00 = mfma32(a0, b0, acc00);
-                acc01 = mfma32(a0, b1, acc01);
-                acc10 = mfma32(a1, b0, acc10);
-                acc11 = mfma32(a1, b1, acc11);
-            }
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-    }
-
-    const int px = x0 + (lane & 31);
-    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
-    const int yrow = y0 + wn * 2;
-    if (epi == 4) {
-        // bias + ReLU + 2x2/2 max pool (floor mode) fused: the wave's two pixel rows are the vertical pair, the
-        // horizontal partner is lane^1; even lanes store to the pooled (H/2, W/2) tensor.  The full-resolution
-        // activation never reaches HBM (used for the frozen blocks, whose activations are not kept for backward).
-        const int OH = H >> 1, OW = W >> 1;
-        const int oy = yrow >> 1, ox = px >> 1;
-        float* yn = y + (size_t)n * Cout * OH * OW;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
-                const float b = (co < Cout) ? bias[co] : 0.f;
-                const float v0 = fmaxf((s == 0 ? acc00[r] : acc10[r]) + b, 0.f);
-                const float v1 = fmaxf((s == 0 ? acc01[r] : acc11[r]) + b, 0.f);
-                float m = fmaxf(v0, v1);
-                m = fmaxf(m, __shfl_xor(m, 1, 64));
-                if (co < Cout && !(lane & 1) && oy < OH && ox < OW) yn[((size_t)co * OH + oy) * OW + ox] = m;
-            }
-        }
-        return;
-    }
-    float* yn = y + (size_t)n * Cout * HW;
-    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
-            if (co >= Cout) continue;
-            const float b = (epi <= 1) ? bias[co] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int yy = yrow + q;
-                if (yy >= H || px >= W) continue;
-                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
-                const size_t o = (size_t)co * HW + (size_t)yy * W + px;
-                if (epi <= 1) {
-                    v += b;
-                    if (epi == 1) v = fmaxf(v, 0.f);
-                } else if (epi == 3) {
-                    v = (mn[o] > 0.f) ? v : 0.f;
-                }
-                yn[o] = v;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------ forward, buffer-DMA pipeline
-// Default forward / dgrad kernel.  Same K loop as conv3x3_dma_kernel (4-channel chunks, double-buffered LDS, one
-// barrier per chunk, 72 MFMAs per wave per chunk) with two changes that came out of clock64() probes of that
-// kernel (tools/exp_conv_timing.py: the main loop already keeps the MFMA pipe ~93-100 % busy; the losses are the
-// MFMAs spent on pixels outside the image and the VALU work of the DMA issue):
+// Default forward / dgrad kernel: K walked in 4-channel chunks, double-buffered LDS, ONE workgroup barrier per chunk,
+// 72 MFMAs per wave per chunk:   issue DMA(chunk c+1 -> buf^1) ; MFMAs on buf ; s_waitcnt vmcnt(0) ; s_barrier.
+// Its predecessor used global_load_lds with per-lane 4-B gathers; clock64() probes of that kernel
+// (tools/exp_conv_timing.py) showed the main loop keeping the MFMA pipe ~93-100 % busy, with the losses in the MFMAs
+// spent on pixels outside the image and in the VALU work of the DMA issue.  Hence:
 //   * operands arrive through `buffer_load_dwordx4 ... lds`: per-lane byte offsets are loop invariants, the chunk
 //     advance lives in the scalar buffer descriptor, halo / padded-channel pieces carry offset 0xFFFFFFFF and are
 //     zero-filled by the buffer range check.  One 16-B patch DMA per lane per chunk (was four 4-B gathers with
@@ -381,6 +203,7 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_dma_
 //     drops from 32 to 8 columns: 100x166 maps waste 1 % instead of 16 %, 50x83 maps 10 % instead of 20 %.
 // LDS patch row pitch is 40 floats (10 pieces; column m <-> image column x0 - 4 + m, so the left halo is one whole
 // piece), which also puts the four rows of a pixel block on disjoint 8-bank groups for ds_read_b32.
+typedef __attribute__((address_space(3))) void lds_void_b_t;
 constexpr int PWB = 40;
 
 __device__ __forceinline__ void* uniform_ptr(const void* p)
@@ -874,152 +697,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------ wgrad, LDS-DMA pipeline
-// Same decomposition as conv3x3_wgrad_kernel (128 co x 32 ci x 9 taps per workgroup, K = pixels, one 32-pixel
-// row segment per stage) but dY rows and the X halo patch are DMA'd straight into double-buffered LDS with 4-byte
-// per-lane gathers (pad / out-of-image lanes read the zero page): no staging registers next to the 144
-// accumulator VGPRs, one barrier per stage.
-constexpr int WD_DY = 128 * DY_PITCH;                       // 4224 floats (multiple of 64)
-constexpr int WD_X = ((32 * XP_PITCH + 63) / 64) * 64;      // 3328 floats
-constexpr int WD_STAGE = WD_DY + WD_X;
-
-// 512 threads = 8 waves: wave w owns co sub-tile (w & 3) and tap group (w >> 2) = taps {0..4} or {5..8}, so a wave
-// carries 5 (4) accumulator tiles = 80 (64) VGPRs instead of 144 and four waves fit per SIMD (two workgroups/CU).
-template <int TAP0, int NTAP>
-__device__ __forceinline__ void wgrad_stage(const float* __restrict__ al, const float* __restrict__ bl, f32x16 (&acc)[5])
-{
-#pragma unroll 4
-    for (int kk = 0; kk < 16; ++kk) {
-        const float a = al[2 * kk];
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-            const int tap = TAP0 + t, ky = tap / 3, kx = tap % 3;
-            const float b = bl[ky * PW + 2 * kk + kx];
-            acc[t] = mfma32(a, b, acc[t]);
-        }
-    }
-}
-
-__global__ __launch_bounds__(512, 4) void conv3x3_wgrad_dma_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
-    int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S,
-    const float* __restrict__ zero_page)
-{
-    constexpr int NDY = (WD_DY + 511) / 512;                 // 9
-    constexpr int NX = (WD_X + 511) / 512;                   // 7
-    __shared__ __attribute__((aligned(16))) float lds[2 * WD_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_base = tid & ~63;
-    const int cw = wave & 3, tg = wave >> 2;
-    int bid = blockIdx.x;
-    const int s = bid % S; bid /= S;
-    const int cit = bid % ciTiles;
-    const int cot = bid / ciTiles;
-    const int HW = H * W;
-    const int co0 = cot * 128, ci0 = cit * 32;
-    const int nTiles = N * tilesY * tilesX;
-
-    f32x16 acc[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) acc[t] = (f32x16){0};
-
-    // Tile-independent piece descriptors, built once: bits 0..23 = element offset from the tile's base pointer,
-    // bits 24..29 = column (dY) / bits 24..25 = row, 26..31 = column (X); -1 = lane never loads (LDS pad slot,
-    // channel beyond Cout/Cin) and reads the zero page.  Requires 128*H*W < 2^24 (checked by the launcher).
-    int ddesc[NDY], xdesc[NX];
-#pragma unroll
-    for (int i = 0; i < NDY; ++i) {
-        const int idx = tid + i * 512;
-        const int col = idx / DY_PITCH, p = idx - col * DY_PITCH;
-        ddesc[i] = (p < 32 && (co0 + col) < Cout && idx < WD_DY) ? ((col * HW + p) | (p << 24)) : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const int idx = tid + i * 512;
-        const int cil = idx / XP_PITCH, rem = idx - cil * XP_PITCH;
-        const int r = rem / PW, c = rem - r * PW;
-        xdesc[i] = (cil < 32 && rem < XP_PLANE && (ci0 + cil) < Cin) ? ((cil * HW + r * W + c) | (r << 24) | (c << 26)) : -1;
-    }
-
-    auto issue = [&](int tile, int buf) {
-        const int tx = tile % tilesX;
-        int t2 = tile / tilesX;
-        const int ty = t2 % tilesY;
-        const int n = t2 / tilesY;
-        const int x0 = tx * TW, y0 = ty;
-        const float* dyn = dy + ((size_t)n * Cout + co0) * HW + (size_t)y0 * W + x0;
-        // X base points at (ci0, y0-1, x0-1); only dereferenced at offsets whose (row, col) are inside the image
-        const float* xb = x + ((size_t)n * Cin + ci0) * HW + ((ptrdiff_t)y0 - 1) * W + (x0 - 1);
-        float* Dd = lds + buf * WD_STAGE;
-        float* Xd = Dd + WD_DY;
-        const int wv = W - x0;                                   // valid dY columns in this tile
-        const bool interior = y0 > 0 && y0 < H - 1 && x0 > 0 && (x0 + 33) <= W;
-        if (interior) {
-#pragma unroll
-            for (int i = 0; i < NDY; ++i) {
-                if (wave_base + i * 512 < WD_DY) {
-                    const int d = ddesc[i];
-                    dma4(d != -1 ? dyn + (d & 0xFFFFFF) : zero_page + lane, Dd + wave_base + i * 512);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                if (wave_base + i * 512 < WD_X) {
-                    const int d = xdesc[i];
-                    dma4(d != -1 ? xb + (d & 0xFFFFFF) : zero_page + lane, Xd + wave_base + i * 512);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NDY; ++i) {
-                if (wave_base + i * 512 < WD_DY) {
-                    const int d = ddesc[i];
-                    const bool ok = d != -1 && ((d >> 24) & 63) < wv;
-                    dma4(ok ? dyn + (d & 0xFFFFFF) : zero_page + lane, Dd + wave_base + i * 512);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                if (wave_base + i * 512 < WD_X) {
-                    const int d = xdesc[i];
-                    const int r = (d >> 24) & 3, c = (d >> 26) & 63;
-                    const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-                    const bool ok = d != -1 && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                    dma4(ok ? xb + (d & 0xFFFFFF) : zero_page + lane, Xd + wave_base + i * 512);
-                }
-            }
-        }
-    };
-
-    const int a_off = (cw * 32 + (lane & 31)) * DY_PITCH + (lane >> 5);
-    const int b_off = WD_DY + (lane & 31) * XP_PITCH + (lane >> 5);
-
-    int tile = s, it = 0;
-    if (tile < nTiles) issue(tile, 0);
-    for (; tile < nTiles; tile += S, ++it) {
-        const int buf = it & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tile + S < nTiles) issue(tile + S, buf ^ 1);
-        const float* al = lds + buf * WD_STAGE + a_off;
-        const float* bl = lds + buf * WD_STAGE + b_off;
-        if (tg == 0) wgrad_stage<0, 5>(al, bl, acc);
-        else wgrad_stage<5, 4>(al, bl, acc);
-    }
-    const int ci = ci0 + (lane & 31);
-    const int tap0 = tg == 0 ? 0 : 5, ntap = tg == 0 ? 5 : 4;
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        if (t >= ntap) break;
-        float* dst = partial + ((size_t)s * 9 + tap0 + t) * Cout * Cin;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[t][r];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------ wgrad, buffer-DMA pipeline
 // Third-generation wgrad main loop (default).  Measured with clock64() probes (tools/exp_wgrad_timing.py): in the
 // kernel above a wave spends as long issuing its 16 dword DMAs per stage (address VALU work that has to win issue
@@ -1343,25 +1020,14 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
         dz[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
-// PTMI_CONV_IMPL: 4 = buffer-DMA pipeline with 4x8 pixel blocks (default); 2 = global_load_lds pipeline;
-// 3 = LDS-free register-streamed kernel; 1 = register-staged kernel with ds_write
+// PTMI_CONV_IMPL (A/B knob): 4 = buffer-DMA pipelines (default); 3 = LDS-free register-streamed forward everywhere;
+// 1 = register-staged kernels with ds_write (also the fallback for shapes whose offsets do not fit 32 bits)
 int conv_impl()
 {
     static int impl = -1;
     if (impl < 0) {
         const char* e = getenv("PTMI_CONV_IMPL");
-        impl = (e && e[0] >= '1' && e[0] <= '4') ? (e[0] - '0') : 4;
-    }
-    return impl;
-}
-
-// 3 = buffer-DMA wgrad (default); 2 = global_load_lds dword pipeline (PTMI_WGRAD_IMPL=2)
-int wgrad_impl()
-{
-    static int impl = -1;
-    if (impl < 0) {
-        const char* e = getenv("PTMI_WGRAD_IMPL");
-        impl = (e && e[0] == '2') ? 2 : 3;
+        impl = (e && (e[0] == '1' || e[0] == '3')) ? (e[0] - '0') : 4;
     }
     return impl;
 }
@@ -1370,7 +1036,7 @@ int wgrad_impl()
 int wgrad_edge_splits(int n, int cin, int cout, int h, int w)
 {
     const int tilesX = cdiv(w, TW), wv = w - (tilesX - 1) * TW;
-    if (!(conv_impl() >= 2 && wgrad_impl() == 3) || tilesX < 2 || wv > 24) return 0;
+    if (conv_impl() == 1 || (int64_t)128 * h * w >= (1 << 28) || tilesX < 2 || wv > 24) return 0;
     const int base = cdiv(cout, 128) * cdiv(cin, 32);
     const int64_t nTiles = (int64_t)n * h;
     int S = cdiv(512, base);
@@ -1410,7 +1076,7 @@ int ptmi_conv3x3_ck(int cin)
         forced = (e && (e[0] == '4' || e[0] == '8')) ? (e[0] - '0') : 0;
     }
     if (forced) return forced;
-    return (cin <= 4 || conv_impl() >= 2) ? 4 : 8;
+    return (cin <= 4 || conv_impl() != 1) ? 4 : 8;
 }
 
 int64_t ptmi_conv3x3_packed_floats(int cin, int cout)
@@ -1439,15 +1105,16 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_fwd: bad epilogue %d", epilogue);
-    PTMI_CHECK_ARG(epilogue != 4 || (ptmi_conv3x3_ck(cin) == 4 && conv_impl() >= 2),
-                   "conv3x3_fwd: the fused pool epilogue needs the LDS-DMA kernel");
+    const bool buf_ok = ptmi_conv3x3_ck(cin) == 4 && conv_impl() == 4 && (int64_t)cin * h * w * 4 < (1ll << 32) &&
+                        ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) && (int64_t)n * cdiv(h, 4) < 65536;
+    PTMI_CHECK_ARG(epilogue != 4 || buf_ok, "conv3x3_fwd: the fused pool epilogue needs the buffer-DMA kernel");
     PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
     const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
     static int w8 = -1;
     if (w8 < 0) { const char* e = getenv("PTMI_CONV_W8"); w8 = e ? (e[0] - '0') : 2; }
     // 8-wave workgroups (8 rows x 32 cols per 128 channels) share one weight slab among twice the pixels
-    const bool use8 = BM == 128 && CK == 4 && (conv_impl() == 2 || conv_impl() == 4) && cin > 4 && (w8 == 1 || (w8 == 2 && h >= 200));   // A/B: +3.5% at 400x666, -3.5% at 100x166 (row-tile waste)
+    const bool use8 = BM == 128 && buf_ok && cin > 4 && (w8 == 1 || (w8 == 2 && h >= 200));   // A/B: +3.5 % at 400x666, -3 .. -14 % on the small maps
     const int TH = (BM == 128 && !use8) ? 4 : 8;
     const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
     const int64_t blocks = (int64_t)n * tilesX * tilesY * coTiles;
@@ -1457,7 +1124,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     // register-streamed kernel: everywhere with PTMI_CONV_IMPL=3 (A/B experiments: slower than LDS-DMA on the big
     // layers, 66-80 vs 115-131 TF/s) and by default for the 3-channel stem, whose K = 36 loop is too short to
     // amortise the LDS pipeline's prologue (25 vs 18 TF/s; that layer is HBM-write bound)
-    if (CK == 4 && (conv_impl() == 3 || (conv_impl() >= 2 && cin <= 4 && stem_direct())) && epilogue != 4) {
+    if (CK == 4 && (conv_impl() == 3 || (conv_impl() == 4 && cin <= 4 && stem_direct())) && epilogue != 4) {
         const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
         if (BM == 128)
             hipLaunchKernelGGL((conv3x3_direct_kernel<128>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
@@ -1468,8 +1135,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
         PTMI_LAUNCH_CHECK("conv3x3_fwd(direct)");
         return 0;
     }
-    if (CK == 4 && conv_impl() == 4 && (int64_t)cin * h * w * 4 < (1ll << 32) && ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) &&
-        (int64_t)n * tilesY < 65536 && tilesX < 65536) {
+    if (buf_ok) {
         const dim3 grid3((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
 #define LBUF(BM_, NW_) hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, \
                                           y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
@@ -1478,20 +1144,6 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
         else LBUF(64, 4);
 #undef LBUF
         PTMI_LAUNCH_CHECK("conv3x3_fwd(buf)");
-        return 0;
-    }
-    if (CK == 4 && conv_impl() >= 2) {
-        const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
-        static int prio = -1;
-        if (prio < 0) { const char* e = getenv("PTMI_CONV_PRIO"); prio = (e && e[0] == '1') ? 1 : 0; }
-#define LDMA(BM_, P_, NW_) hipLaunchKernelGGL((conv3x3_dma_kernel<BM_, P_, NW_>), grid, dim3(64 * NW_), 0, st, x, wp, bias, \
-                                              mask_ref, y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue, \
-                                              zero_page)
-        if (BM == 128 && use8) LDMA(128, false, 8);
-        else if (BM == 128) { if (prio) LDMA(128, true, 4); else LDMA(128, false, 4); }
-        else { if (prio) LDMA(64, true, 4); else LDMA(64, false, 4); }
-#undef LDMA
-        PTMI_LAUNCH_CHECK("conv3x3_fwd(dma)");
         return 0;
     }
 #define LAUNCH(BM_, CK_)                                                                              \
@@ -1523,7 +1175,7 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
     const int Se = wgrad_edge_splits(n, cin, cout, h, w);
     const int64_t bg_off = (int64_t)(S + Se) * 9 * cout * cin;
     hipStream_t st = (hipStream_t)s;
-    if (conv_impl() >= 2 && wgrad_impl() == 3 && (int64_t)128 * h * w < (1 << 28)) {
+    if (conv_impl() != 1 && (int64_t)128 * h * w < (1 << 28)) {
         if (Se > 0) {
             // the right-edge tile column has few valid pixels: give it the short interleaved stage in its own launch
             hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n,
@@ -1536,12 +1188,6 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
             hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n,
                                cin, cout, h, w, tilesX, tilesY, coTiles, ciTiles, S, 0);
         }
-    } else if (conv_impl() >= 2 && (int64_t)128 * h * w < (1 << 24)) {
-        float* zero_page = ws + bg_off;
-        hipError_t e = hipMemsetAsync(zero_page, 0, 64 * sizeof(float), st);
-        if (e != hipSuccess) { ptmi_set_error("conv3x3_wgrad: memset failed"); return -2; }
-        hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n, cin,
-                           cout, h, w, tilesX, tilesY, coTiles, ciTiles, S, zero_page);
     } else {
         hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
                            cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);

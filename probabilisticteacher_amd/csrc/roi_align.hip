@@ -107,93 +107,16 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
     }
 }
 
-// Forward for rois grouped by image: a workgroup keeps CG channel planes of ONE image in LDS (read from HBM/L2 once,
-// coalesced) and walks that image's ROIs two at a time.  Per ROI the sample geometry is separable and identical for
-// every channel, so ~140 threads first write one table entry each (row taps + weights for the 7*gh sample rows,
-// column taps for the 7*gw sample columns), then thread (roi, c, ph, pw) accumulates its bin from LDS.  The
-// arithmetic per sample is exactly the torchvision expression (w1*f1 + w2*f2 + w3*f3 + w4*f4 summed in sample
-// order, / count), so results equal the gather kernel bit for bit.
-constexpr int RF_THREADS = 512;
-constexpr int RF_MAXS = 128;          // max 7*g sample rows / cols held in a table (g <= 18)
-
 struct TapEntry { int lo, hi; float wlo, whi; };   // wlo = 1 - frac (weight of `lo`), whi = frac; lo < 0 => skipped
 
-__global__ __launch_bounds__(RF_THREADS) void roi_align_fwd_grouped_kernel(const float* __restrict__ feat,
-                                                                           const float* __restrict__ rois,
-                                                                           const int32_t* __restrict__ img_off,
-                                                                           float* __restrict__ out, int C, int H, int W,
-                                                                           float scale, int CG)
-{
-    extern __shared__ float smem[];
-    const int HW = H * W;
-    float* plane = smem;                                                 // CG * HW
-    TapEntry* ytab = reinterpret_cast<TapEntry*>(plane + CG * HW);       // [2][RF_MAXS]
-    TapEntry* xtab = ytab + 2 * RF_MAXS;                                 // [2][RF_MAXS]
-    const int n = blockIdx.y, c0 = blockIdx.x * CG;
-    const int cg = min(CG, C - c0);
-    const int tid = threadIdx.x;
-    const float* src = feat + ((size_t)n * C + c0) * HW;
-    for (int i = tid; i < cg * HW; i += RF_THREADS) plane[i] = src[i];
-    const int r0 = img_off[n], r1 = img_off[n + 1];
-    const int sub = tid >> 8, t = tid & 255;                             // two ROIs per pass
-    for (int rb = r0; rb < r1; rb += 2) {
-        const int r = rb + sub;
-        const bool live = r < r1;
-        RoiGeom g;
-        if (live) g = roi_geom(rois + 5 * (size_t)r, scale, 7);
-        else { g.gh = g.gw = 0; g.count = 1.f; g.sh = g.sw = g.bh = g.bw = 0.f; g.b = 0; }
-        __syncthreads();                                                 // previous pass done with the tables (and plane loaded)
-        if (live) {
-            const int ny = 7 * g.gh, nx = 7 * g.gw;
-            if (t < ny + nx) {
-                const bool isx = t >= ny;
-                const int sidx = isx ? t - ny : t;
-                const int gn = isx ? g.gw : g.gh, L = isx ? W : H;
-                const int pb = sidx / gn, i = sidx - pb * gn;
-                const float start = isx ? g.sw : g.sh, bsz = isx ? g.bw : g.bh;
-                float v = start + (float)pb * bsz + ((float)i + .5f) * bsz / (float)gn;
-                TapEntry e;
-                if (v < -1.0f || v > (float)L) { e.lo = -1; e.hi = -1; e.wlo = e.whi = 0.f; }
-                else {
-                    if (v <= 0.f) v = 0.f;
-                    int l = (int)v, h2;
-                    if (l >= L - 1) { h2 = l = L - 1; v = (float)l; } else h2 = l + 1;
-                    const float lw = v - (float)l;
-                    e.lo = l; e.hi = h2; e.whi = lw; e.wlo = 1.f - lw;
-                }
-                (isx ? xtab : ytab)[sub * RF_MAXS + sidx] = e;
-            }
-        }
-        __syncthreads();
-        if (live && t < cg * 49) {
-            const int c = t / 49, rem = t - c * 49;
-            const int ph = rem / 7, pw = rem - ph * 7;
-            const float* f = plane + c * HW;
-            const TapEntry* yt = ytab + sub * RF_MAXS + ph * g.gh;
-            const TapEntry* xt = xtab + sub * RF_MAXS + pw * g.gw;
-            float acc = 0.f;
-            for (int iy = 0; iy < g.gh; ++iy) {
-                const TapEntry ey = yt[iy];
-                if (ey.lo < 0) continue;
-                for (int ix = 0; ix < g.gw; ++ix) {
-                    const TapEntry ex = xt[ix];
-                    if (ex.lo < 0) continue;
-                    const float w1 = ey.wlo * ex.wlo, w2 = ey.wlo * ex.whi, w3 = ey.whi * ex.wlo, w4 = ey.whi * ex.whi;
-                    acc += w1 * f[ey.lo * W + ex.lo] + w2 * f[ey.lo * W + ex.hi] + w3 * f[ey.hi * W + ex.lo] +
-                           w4 * f[ey.hi * W + ex.hi];
-                }
-            }
-            out[((size_t)r * C + c0) * 49 + t] = acc / g.count;
-        }
-    }
-}
-
-// Second-generation grouped forward (default).  The kernel above rebuilds each ROI's tap tables in every channel-group
-// workgroup (128 times per ROI for C = 512) behind two barriers per pair of ROIs, and leaves a quarter of its threads
-// idle.  Here the tables are built once per ROI by roi_tables_kernel into a workspace (header + 2 * TS entries per
-// ROI); the gather kernel keeps CG = 4 channel planes of one image in LDS, runs 5 ROIs at a time on 980 of its 1024
-// threads (thread = (roi slot, channel, bin)) and needs no barrier after the planes are loaded.  Per-sample
-// arithmetic and summation order are unchanged, so the result is still bit-identical to the plain gather kernel.
+// Forward for rois grouped by image.  Per ROI the sample geometry is separable and identical for every channel:
+// roi_tables_kernel writes one table entry per sample row / column (taps + weights; header + 2 * TS entries per ROI)
+// into a workspace, once per ROI.  The gather kernel keeps CG = 4 channel planes of one image in LDS (read from
+// HBM/L2 once, coalesced), runs 5 ROIs at a time on 980 of its 1024 threads (thread = (roi slot, channel, bin)) and
+// needs no barrier after the planes are loaded; a bin's column taps stay in registers across its sample rows.  The
+// arithmetic per sample is exactly the torchvision expression (w1*f1 + w2*f2 + w3*f3 + w4*f4 summed in sample
+// order, / count), so results equal the plain gather kernel bit for bit.  (Its predecessor rebuilt the tables in
+// every channel-group workgroup -- 128 times per ROI -- behind two barriers per pair of ROIs.)
 struct RoiHeader { int gh, gw; float count; int pad; };
 
 __global__ __launch_bounds__(256) void roi_tables_kernel(const float* __restrict__ rois, void* __restrict__ ws, int R,
