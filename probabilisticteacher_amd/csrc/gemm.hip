@@ -138,13 +138,22 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(
 //     piece that straddles K (K % 4 != 0) is loaded whole and its tail words are zeroed in LDS by the loading lane.
 // The k permutation is the same for both operands, so the sum is unchanged up to fp32 ordering, and the order is
 // fixed => bitwise reproducible run to run.
-constexpr int KF_PITCH = 36, KF_SLOTS = 128 * 9, KF_FLOATS = KF_SLOTS * 4 + 256;      // 1152 slots (+ DMA overhang)
-constexpr int MF_FLOATS = 32 * 128;
-constexpr int OP_FLOATS = KF_FLOATS;                                                   // per operand per stage
+// BKT = K extent of a stage: 32 (two workgroups per CU, 64 MFMAs per wave per barrier) or 16 (three per CU, 32).
+template <int BKT>
+struct TileCfg {
+    static constexpr int HK = BKT / 2;                    // k values per lane half
+    static constexpr int KF_PITCH = BKT + 4;              // 36 / 20 floats: odd multiple of 16 B
+    static constexpr int KF_PR = BKT / 4 + 1;             // 16-B slots per row (data pieces + 1 pad)
+    static constexpr int KF_SLOTS = 128 * KF_PR;          // 1152 / 640
+    static constexpr int KF_NI = (KF_SLOTS + 255) / 256;  // DMA instructions per lane: 5 / 3 (the last one: waves 0-1)
+    static constexpr int MF_NI = BKT / 8;                 // 4 / 2
+    static constexpr int OP_FLOATS = KF_SLOTS * 4 + 256;  // per operand per stage (+ DMA overhang)
+};
 
-template <bool KF>
+template <bool KF, int BKT>
 struct OpTile {
-    unsigned voff[KF ? 5 : 1];      // loop-invariant byte offsets of this lane's pieces (0xFFFFFFFF = never loaded)
+    using Cfg = TileCfg<BKT>;
+    unsigned voff[KF ? Cfg::KF_NI : 1];   // loop-invariant byte offsets of this lane's pieces (0xFFFFFFFF = never loaded)
     unsigned qpack;                 // KF: first k of piece i in bits 6i..6i+5;  !KF: k row of piece 0 (rows 8i + that)
     const char* base;               // this tile at the current K step (wave-uniform)
     long long left;                 // bytes from base to the end of the operand
@@ -155,15 +164,16 @@ struct OpTile {
         if constexpr (KF) {
             qpack = 0;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < Cfg::KF_NI; ++i) {
                 const int sl = tid + i * 256;
-                const int row = sl / 9, q = sl - row * 9;
-                voff[i] = (sl < KF_SLOTS && q < 8 && mn0 + row < MN) ? (unsigned)(row * ld + 4 * q) * 4u : 0xFFFFFFFFu;
+                const int row = sl / Cfg::KF_PR, q = sl - row * Cfg::KF_PR;
+                voff[i] = (sl < Cfg::KF_SLOTS && q < Cfg::KF_PR - 1 && mn0 + row < MN) ? (unsigned)(row * ld + 4 * q) * 4u
+                                                                                       : 0xFFFFFFFFu;
                 qpack |= (unsigned)(4 * q) << (6 * i);
             }
             base = (const char*)(p + (size_t)mn0 * ld);
             left = (total_floats - (int64_t)mn0 * ld) * 4;
-            step_bytes = 32 * 4;
+            step_bytes = BKT * 4;
             row8_bytes = 0;
         } else {
             const int kr = tid >> 5, q = tid & 31;
@@ -171,28 +181,28 @@ struct OpTile {
             qpack = kr;
             base = (const char*)(p + mn0);
             left = (total_floats - mn0) * 4;
-            step_bytes = 32 * ld * 4;
+            step_bytes = BKT * ld * 4;
             row8_bytes = 8 * ld * 4;
         }
     }
-    // krem = K - k0 (>= 32 except in the tail step)
+    // krem = K - k0 (>= BKT except in the tail step)
     __device__ __forceinline__ void issue(float* dst_wave, int wave, int krem)
     {
         const __amdgpu_buffer_rsrc_t r = ptmi_rsrc(base, (unsigned)(left > 0xFFFFFFFEll ? 0xFFFFFFFEll : (left < 0 ? 0 : left)));
         if constexpr (KF) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                if (i < 4 || wave < 2) {
+            for (int i = 0; i < Cfg::KF_NI; ++i) {
+                if (i < Cfg::KF_NI - 1 || wave < 2) {
                     unsigned v = voff[i];
-                    if (krem < 32) v = ((int)((qpack >> (6 * i)) & 63) < krem) ? v : 0xFFFFFFFFu;
+                    if (krem < BKT) v = ((int)((qpack >> (6 * i)) & 63) < krem) ? v : 0xFFFFFFFFu;
                     ptmi_bdma16(r, v, 0, dst_wave + i * 1024);
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < Cfg::MF_NI; ++i) {
                 unsigned v = voff[0];
-                if (krem < 32) v = ((int)qpack + 8 * i < krem) ? v : 0xFFFFFFFFu;
+                if (krem < BKT) v = ((int)qpack + 8 * i < krem) ? v : 0xFFFFFFFFu;
                 ptmi_bdma16(r, v, i * row8_bytes, dst_wave + i * 1024);
             }
         }
@@ -204,9 +214,9 @@ struct OpTile {
     {
         if constexpr (KF) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
+            for (int i = 0; i < Cfg::KF_NI; ++i) {
                 const int k4 = (qpack >> (6 * i)) & 63;
-                if ((i < 4 || wave < 2) && voff[i] != 0xFFFFFFFFu && k4 < krem && k4 + 4 > krem) {
+                if ((i < Cfg::KF_NI - 1 || wave < 2) && voff[i] != 0xFFFFFFFFu && k4 < krem && k4 + 4 > krem) {
 #pragma unroll
                     for (int e = 1; e < 4; ++e)
                         if (k4 + e >= krem) dst_lane[i * 1024 + e] = 0.f;
@@ -214,31 +224,33 @@ struct OpTile {
             }
         }
     }
-    // fragment for the 32-row sub-tile starting at row r0: f[j] = T(row r0 + (lane & 31), k = 16 * (lane >> 5) + j)
-    __device__ __forceinline__ static void frag(const float* T, int r0, int lane, float (&f)[16])
+    // fragment for the 32-row sub-tile starting at row r0: f[j] = T(row r0 + (lane & 31), k = HK * (lane >> 5) + j)
+    __device__ __forceinline__ static void frag(const float* T, int r0, int lane, float (&f)[Cfg::HK])
     {
         if constexpr (KF) {
-            const float* p = T + (r0 + (lane & 31)) * KF_PITCH + (lane >> 5) * 16;
+            const float* p = T + (r0 + (lane & 31)) * Cfg::KF_PITCH + (lane >> 5) * Cfg::HK;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < Cfg::HK / 4; ++t) {
                 const f32x4 v = *(const volatile ptmi_lds_f32x4_t*)(p + 4 * t);
                 f[4 * t] = v[0]; f[4 * t + 1] = v[1]; f[4 * t + 2] = v[2]; f[4 * t + 3] = v[3];
             }
         } else {
-            const float* p = T + (lane >> 5) * 16 * 128 + r0 + (lane & 31);
+            const float* p = T + (lane >> 5) * Cfg::HK * 128 + r0 + (lane & 31);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) f[j] = p[j * 128];
+            for (int j = 0; j < Cfg::HK; ++j) f[j] = p[j * 128];
         }
     }
 };
 
-template <bool AK, bool BKF>
-__global__ __launch_bounds__(256, 2) void gemm_buf_kernel(
+template <bool AK, bool BKF, int BKT>
+__global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_buf_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc, int bias_mode, int relu,
     int accumulate, int64_t sa, int64_t sb, int64_t sc, int tilesN)
 {
-    __shared__ __attribute__((aligned(16))) float lds[4 * OP_FLOATS];      // [buf][A | B]
+    using Cfg = TileCfg<BKT>;
+    constexpr int OPF = Cfg::OP_FLOATS, HK = Cfg::HK;
+    __shared__ __attribute__((aligned(16))) float lds[4 * OPF];      // [buf][A | B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bm = blockIdx.x / tilesN, bn = blockIdx.x % tilesN;
@@ -249,38 +261,38 @@ __global__ __launch_bounds__(256, 2) void gemm_buf_kernel(
     C += (size_t)b * sc;
     const int wm = wave >> 1, wn = wave & 1;
 
-    OpTile<AK> ta;
-    OpTile<BKF> tb;
+    OpTile<AK, BKT> ta;
+    OpTile<BKF, BKT> tb;
     ta.init(A, lda, m0, M, K, tid, AK ? ((int64_t)(M - 1) * lda + K) : ((int64_t)(K - 1) * lda + M));
     tb.init(B, ldb, n0, N, K, tid, BKF ? ((int64_t)(N - 1) * ldb + K) : ((int64_t)(K - 1) * ldb + N));
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    const int nSteps = (K + BK - 1) / BK;
+    const int nSteps = (K + BKT - 1) / BKT;
     ta.issue(lds + wave * 256, wave, K);
-    tb.issue(lds + OP_FLOATS + wave * 256, wave, K);
+    tb.issue(lds + OPF + wave * 256, wave, K);
     for (int st = 0; st < nSteps; ++st) {
         const int buf = st & 1;
-        float* As = lds + buf * 2 * OP_FLOATS;
-        float* Bs = As + OP_FLOATS;
-        const int krem = K - st * BK;
+        float* As = lds + buf * 2 * OPF;
+        float* Bs = As + OPF;
+        const int krem = K - st * BKT;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (krem < 32 && (krem & 3)) {
+        if (krem < BKT && (krem & 3)) {
             ta.fixup(As + tid * 4, wave, krem);
             tb.fixup(Bs + tid * 4, wave, krem);
         }
         __syncthreads();
         if (st + 1 < nSteps) {
-            float* An = lds + (buf ^ 1) * 2 * OP_FLOATS + wave * 256;
-            ta.issue(An, wave, krem - BK);
-            tb.issue(An + OP_FLOATS, wave, krem - BK);
+            float* An = lds + (buf ^ 1) * 2 * OPF + wave * 256;
+            ta.issue(An, wave, krem - BKT);
+            tb.issue(An + OPF, wave, krem - BKT);
         }
-        float a0[16], a1[16], b0[16], b1[16];
-        OpTile<AK>::frag(As, wm * 64, lane, a0);
-        OpTile<AK>::frag(As, wm * 64 + 32, lane, a1);
-        OpTile<BKF>::frag(Bs, wn * 64, lane, b0);
-        OpTile<BKF>::frag(Bs, wn * 64 + 32, lane, b1);
+        float a0[HK], a1[HK], b0[HK], b1[HK];
+        OpTile<AK, BKT>::frag(As, wm * 64, lane, a0);
+        OpTile<AK, BKT>::frag(As, wm * 64 + 32, lane, a1);
+        OpTile<BKF, BKT>::frag(Bs, wn * 64, lane, b0);
+        OpTile<BKF, BKT>::frag(Bs, wn * 64 + 32, lane, b1);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < HK; ++j) {
             acc00 = mfma32(a0[j], b0[j], acc00);
             acc01 = mfma32(a0[j], b1[j], acc01);
             acc10 = mfma32(a1[j], b0[j], acc10);
@@ -372,11 +384,17 @@ int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, i
     const bool ak = (ta == 0), bk = (tb != 0);
     static int impl = -1;      // PTMI_GEMM_IMPL=1: register-staged kernel (also used when a leading dimension is huge)
     if (impl < 0) { const char* e = getenv("PTMI_GEMM_IMPL"); impl = (e && e[0] == '1') ? 1 : 2; }
+    static int bkk = -1;       // PTMI_GEMM_BK=16: 16-deep stages, three workgroups per CU
+    if (bkk < 0) { const char* e = getenv("PTMI_GEMM_BK"); bkk = (e && e[0] == '1') ? 16 : 32; }
+    const bool bk16 = bkk == 16;
     const bool buf_ok = impl == 2 && (int64_t)128 * lda * 4 < (1ll << 31) && (int64_t)128 * ldb * 4 < (1ll << 31);
 #define L(AK_, BK_)                                                                                     \
     do {                                                                                                \
-        if (buf_ok)                                                                                     \
-            hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, \
+        if (buf_ok && bk16)                                                                             \
+            hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_, 16>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, \
+                               ldc, bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN);  \
+        else if (buf_ok)                                                                                \
+            hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_, 32>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, \
                                ldc, bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN);  \
         else                                                                                            \
             hipLaunchKernelGGL((gemm_f32_kernel<AK_, BK_>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, \
