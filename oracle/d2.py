@@ -88,6 +88,10 @@ class Boxes:
         b = self.tensor
         return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
 
+    def scale(self, scale_x: float, scale_y: float) -> None:
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
     def clip(self, box_size: Tuple[int, int]) -> None:
         assert torch.isfinite(self.tensor).all(), "Box tensor contains infinite or NaN!"
         h, w = box_size

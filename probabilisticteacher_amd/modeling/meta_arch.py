@@ -36,9 +36,22 @@ class GuassianGeneralizedRCNN(nn.Module):
         sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in imgs]
         return ImageList(ops.preprocess_images(imgs, self._mean, self._std), sizes)
 
+    def inference(self, batched_inputs):
+        """Eval-mode path (rcnn.py:33-34 -> D2 GeneralizedRCNN.inference + detector_postprocess):
+        test-time RPN (6000 -> 1000 proposals), ROI inference, boxes rescaled to each record's height/width."""
+        assert not self.training
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None)
+        results, _ = self.roi_heads(images, features, proposals, None)
+        out = []
+        for res, rec, size in zip(results, batched_inputs, images.image_sizes):
+            out.append({"instances": detector_postprocess(res, rec.get("height", size[0]), rec.get("width", size[1]))})
+        return out
+
     def forward(self, batched_inputs, branch="supervised", danchor=False):
         if not self.training:
-            raise NotImplementedError("eval-mode inference is outside the train-step hot path (SURVEY.md 8f-2)")
+            return self.inference(batched_inputs)
         images = self.preprocess_image(batched_inputs)
         gt_instances = None
         if "instances" in batched_inputs[0]:
@@ -66,6 +79,19 @@ class GuassianGeneralizedRCNN(nn.Module):
             losses.update(proposal_losses)
             return losses, [], [], None
         raise ValueError(f"unknown branch {branch!r}")
+
+
+def detector_postprocess(results, output_height: int, output_width: int):
+    """D2 0.5 detector_postprocess: rescale the detections from the network input size to the requested output
+    size, clip, drop empty boxes."""
+    scale_x = output_width / results.image_size[1]
+    scale_y = output_height / results.image_size[0]
+    res = type(results)((int(output_height), int(output_width)), **results.get_fields())
+    boxes = res.pred_boxes.clone() if res.has("pred_boxes") else res.proposal_boxes.clone()
+    boxes.scale(scale_x, scale_y)
+    boxes.clip(res.image_size)
+    res.set("pred_boxes" if res.has("pred_boxes") else "proposal_boxes", boxes)
+    return res[boxes.nonempty()]
 
 
 class EnsembleTSModel(nn.Module):

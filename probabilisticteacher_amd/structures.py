@@ -41,6 +41,9 @@ class Boxes:
         t = self.tensor
         return ((t[:, 2] - t[:, 0]) > threshold) & ((t[:, 3] - t[:, 1]) > threshold)
 
+    def scale(self, scale_x: float, scale_y: float) -> None:
+        self.tensor = self.tensor * self.tensor.new_tensor([scale_x, scale_y, scale_x, scale_y])
+
     def __getitem__(self, item):
         if isinstance(item, int):
             return Boxes(self.tensor[item].view(1, -1))

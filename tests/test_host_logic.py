@@ -120,3 +120,19 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     checkpoint.load_checkpoint(tr, p)
     assert all(torch.equal(v, want[k]) for k, v in tr.ensem_ts_model.state_dict().items())
     assert tr.iter == 7 and float(tr.momentum_buf[-1]) == tr.student.n_trainable - 1
+
+
+def test_detector_postprocess_rescales_clips_and_drops_empty():
+    """D2 detector_postprocess as used by the eval path: scale to the requested output size, clip,
+    drop boxes that become empty."""
+    import torch
+    from probabilisticteacher_amd.modeling.meta_arch import detector_postprocess
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    r = FreeInstances((100, 200))
+    r.pred_boxes = Boxes(torch.tensor([[10.0, 20.0, 50.0, 60.0], [190.0, 90.0, 260.0, 140.0], [300.0, 10.0, 320.0, 30.0]]))
+    r.scores = torch.tensor([0.9, 0.8, 0.7])
+    out = detector_postprocess(r, 50, 400)          # x * 2, y * 0.5
+    assert out.image_size == (50, 400)
+    assert torch.equal(out.pred_boxes.tensor, torch.tensor([[20.0, 10.0, 100.0, 30.0], [380.0, 45.0, 400.0, 50.0]]))
+    assert torch.equal(out.scores, torch.tensor([0.9, 0.8]))
+    assert torch.equal(r.pred_boxes.tensor[0], torch.tensor([10.0, 20.0, 50.0, 60.0]))      # input not mutated

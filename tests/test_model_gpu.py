@@ -263,3 +263,35 @@ def test_edge_cases_empty_gt_and_no_pseudo_matches():
     un = [{"image": recs[0]["image"], "instances": inst}]
     lu, _, _, _ = model(un, branch="unsupervised", danchor=True)
     assert torch.isnan(lu["loss_cls"]) and torch.isfinite(lu["loss_rpn_cls"])
+
+
+def test_eval_mode_inference_matches_oracle():
+    """`model.eval(); model(batched_inputs)` (rcnn.py:33-34 -> D2 inference + detector_postprocess):
+    test-time RPN top-k, ROI inference and the rescaling of the boxes to the record's height / width, against the
+    CPU oracle (order-insensitive: near-equal scores may swap ranks)."""
+    from probabilisticteacher_amd import modeling
+    K = 8
+    cfg = _cfg(K, "DefaultAnchorGenerator", (0.25, 0.25))
+    ocfg = opt.Cfg(num_classes=K)
+    params = opt.golden_params(ocfg, 9)
+    model = modeling.build_model(cfg).eval()
+    _load_params(model, params)
+    g = torch.Generator().manual_seed(3)
+    recs = []
+    for i, (h, w) in enumerate([(96, 128), (80, 112)]):
+        img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+        recs.append({"image": img, "height": 2 * h + i, "width": 3 * w})          # output size != input size
+    with torch.no_grad():
+        got = model(recs)
+    ref = opt.model_inference(ocfg, params, recs)
+    assert len(got) == len(ref) == 2
+    for a, b, rec in zip(got, ref, recs):
+        a, b = a["instances"], b["instances"]
+        assert a.image_size == b.image_size == (rec["height"], rec["width"])
+        assert abs(len(a) - len(b)) <= max(2, len(b) // 20)
+        if len(b):
+            frac, idx = match_detections(a.pred_boxes.tensor.cpu(), a.pred_classes.cpu(), b.pred_boxes.tensor,
+                                         b.pred_classes, box_tol=5e-2)
+            assert frac >= 0.95, f"eval detections matched {frac:.3f}"
+            bt = a.pred_boxes.tensor.cpu()
+            assert (bt[:, 0::2] <= rec["width"]).all() and (bt[:, 1::2] <= rec["height"]).all() and (bt >= 0).all()
