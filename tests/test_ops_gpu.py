@@ -184,6 +184,7 @@ def test_roi_align(ops):
     boxes[0] = torch.tensor([-30.0, -20.0, 40.0, 35.0])        # partly outside
     boxes[1] = torch.tensor([400.0, 300.0, 520.0, 420.0])      # beyond the far border
     boxes[2] = torch.tensor([10.0, 10.0, 10.5, 10.2])          # tiny
+    boxes[3] = torch.tensor([0.0, 0.0, 496.0, 400.0])          # whole image: 5 x 4 samples per bin (generic tap path)
     rois = torch.cat([torch.randint(0, 2, (40, 1), generator=gen).float(), boxes], 1)
     fr = feat.clone().requires_grad_()
     ref = d2.roi_align(fr, rois, 7, 1 / 16)
@@ -205,6 +206,9 @@ def test_roi_align(ops):
     assert torch.equal(out2, out[order.to(DEV)]), "grouped (LDS-plane) forward must equal the gather kernel bit for bit"
     out2.backward(gy[order].to(DEV))
     close(fd2.grad, fr.grad, 1e-4, 1e-4, "roi_align grouped bwd")
+    fd3 = feat.to(DEV).requires_grad_()
+    ops.roi_align(fd3, rs.to(DEV), 7, 1 / 16, offs).backward(gy[order].to(DEV))
+    assert torch.equal(fd3.grad, fd2.grad), "grouped backward is atomic-free: must be bitwise reproducible"
 
 
 # ------------------------------------------------------------------------------------------ boxes
