@@ -182,8 +182,32 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
         const TapEntry* yt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + ph * hd.gh;
         const TapEntry* xt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + TS + pw * hd.gw;
         float acc = 0.f;
-        if (hd.gw <= 4) {
-            // common case: the bin's column taps live in registers for all sample rows (same summation order)
+        if (hd.gw <= 4 && hd.gh <= 4) {
+            // common case (ROIs up to 28 feature cells a side): all taps of the bin are fetched up front and the
+            // 4 x 4 sample grid is fully unrolled (same summation order), so the LDS reads of different samples overlap
+            TapEntry ex[4], ey[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < hd.gw) ex[k] = xt[k];
+                else { ex[k].lo = -1; ex[k].hi = -1; ex[k].wlo = ex[k].whi = 0.f; }
+                if (k < hd.gh) ey[k] = yt[k];
+                else { ey[k].lo = -1; ey[k].hi = -1; ey[k].wlo = ey[k].whi = 0.f; }
+            }
+#pragma unroll
+            for (int iy = 0; iy < 4; ++iy) {
+                if (ey[iy].lo < 0) continue;
+                const float* f0 = f + ey[iy].lo * W;
+                const float* f1 = f + ey[iy].hi * W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (ex[k].lo < 0) continue;
+                    const float w1 = ey[iy].wlo * ex[k].wlo, w2 = ey[iy].wlo * ex[k].whi, w3 = ey[iy].whi * ex[k].wlo,
+                                w4 = ey[iy].whi * ex[k].whi;
+                    acc += w1 * f0[ex[k].lo] + w2 * f0[ex[k].hi] + w3 * f1[ex[k].lo] + w4 * f1[ex[k].hi];
+                }
+            }
+        } else if (hd.gw <= 4) {
+            // the bin's column taps live in registers for all sample rows
             TapEntry ex[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
