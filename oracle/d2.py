@@ -215,8 +215,12 @@ def subsample_labels(labels: torch.Tensor, num_samples: int, positive_fraction: 
     num_pos = min(positive.numel(), num_pos)
     num_neg = num_samples - num_pos
     num_neg = min(negative.numel(), num_neg)
-    perm1 = perm_fn(positive.numel())[:num_pos]
-    perm2 = perm_fn(negative.numel())[:num_neg]
+    if hasattr(perm_fn, "for_candidates"):      # permutations derived from per-element random keys (KeyedPerm)
+        perm1 = perm_fn.for_candidates(positive, labels.numel())[:num_pos]
+        perm2 = perm_fn.for_candidates(negative, labels.numel())[:num_neg]
+    else:
+        perm1 = perm_fn(positive.numel())[:num_pos]
+        perm2 = perm_fn(negative.numel())[:num_neg]
     return positive[perm1], negative[perm2]
 
 

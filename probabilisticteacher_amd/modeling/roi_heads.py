@@ -15,6 +15,7 @@ from .. import ops
 from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
 from ..structures import Boxes, FreeInstances
 from .box_regression import Box2BoxTransform
+from . import sampling
 from .sampling import subsample_labels
 
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))     # proposal_utils.py:207
@@ -243,11 +244,24 @@ class GuassianROIHead(nn.Module):
         roi_heads.py:257-291 for the unsupervised branch."""
         K = self.num_classes
         out = []
-        for prop, tgt in zip(proposals, targets):
-            if branch == "unsupervised":
+        if branch == "unsupervised":
+            # matched-label-1 proposals only (roi_heads.py:257-291); one count read + one nonzero for the whole batch
+            # instead of a host sync per image
+            ms, offs, o = [], [], 0
+            for prop, tgt in zip(proposals, targets):
+                midx, mlab, _ = ops.iou_match(tgt.pseudo_boxes.tensor, prop.proposal_boxes.tensor, self.iou_thresholds,
+                                              self.iou_labels, False)
+                ms.append((midx, mlab))
+                offs.append(o)
+                o += len(prop.proposal_boxes)
+            hit = torch.cat([m[1] for m in ms]) == 1
+            counts = torch.stack([(m[1] == 1).sum() for m in ms]).cpu().tolist()
+            flat = torch.nonzero(hit).squeeze(1)
+            c0 = 0
+            for (midx, _), prop, tgt, off, cnt in zip(ms, proposals, targets, offs, counts):
+                sel = flat[c0:c0 + cnt] - off
+                c0 += cnt
                 pb = tgt.pseudo_boxes.tensor
-                midx, mlab, _ = ops.iou_match(pb, prop.proposal_boxes.tensor, self.iou_thresholds, self.iou_labels, False)
-                sel = torch.nonzero(mlab == 1).squeeze(1)
                 r = FreeInstances(prop.image_size)
                 r.proposal_boxes = Boxes(prop.proposal_boxes.tensor[sel])
                 if pb.shape[0] == 0:
@@ -260,7 +274,10 @@ class GuassianROIHead(nn.Module):
                     if tgt.has("boxes_sigma"):
                         r.boxes_sigma = tgt.boxes_sigma[m]
                 out.append(r)
-                continue
+            return out
+        legacy = sampling.legacy_path()                # parity tests that inject the reference's permutations
+        pend = []
+        for prop, tgt in zip(proposals, targets):
             gtb = tgt.gt_boxes.tensor
             boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
             if self.proposal_append_gt:
@@ -269,12 +286,21 @@ class GuassianROIHead(nn.Module):
             midx, mlab, _ = ops.iou_match(gtb, boxes.contiguous(), self.iou_thresholds, self.iou_labels, False)
             if tgt.gt_classes.numel() > 0:
                 cls = tgt.gt_classes[midx]
-                cls[mlab == 0] = K
-                cls[mlab == -1] = -1
+                cls = torch.where(mlab == 0, torch.full_like(cls, K), cls)
+                cls = torch.where(mlab == -1, torch.full_like(cls, -1), cls)
             else:
                 cls = torch.zeros_like(midx) + K
-            fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, K)
-            sel = torch.cat([fg, bg], 0)
+            if legacy:
+                fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, K)
+                pend.append((prop, gtb, boxes, logits, midx, cls, torch.cat([fg, bg], 0)))
+            else:
+                pend.append((prop, gtb, boxes, logits, midx, cls) +
+                            sampling.keyed_sample(cls, self.batch_size_per_image, self.positive_fraction, K))
+        if not legacy:
+            # ONE device->host read for the sample sizes of the whole batch
+            cnt = torch.stack([torch.stack((p[7], p[9])) for p in pend]).cpu().tolist()
+            pend = [p[:6] + (torch.cat([p[6][:nf], p[8][:nb]], 0),) for p, (nf, nb) in zip(pend, cnt)]
+        for prop, gtb, boxes, logits, midx, cls, sel in pend:
             r = FreeInstances(prop.image_size)
             r.proposal_boxes = Boxes(boxes[sel])
             r.objectness_logits = logits[sel]

@@ -18,6 +18,7 @@ from ..registry import PROPOSAL_GENERATOR_REGISTRY, RPN_HEAD_REGISTRY
 from ..structures import Boxes, FreeInstances
 from .anchor_generator import build_anchor_generator
 from .box_regression import Box2BoxTransform
+from . import sampling
 from .sampling import subsample_labels
 
 
@@ -159,16 +160,20 @@ class GuassianRPN(nn.Module):
         anc = anchors.detach()
         labels, matched = [], []
         with torch.no_grad():
+            legacy = sampling.legacy_path()            # parity tests that inject the reference's permutations
             for inst in gt_instances:
                 gt = inst.gt_boxes.tensor
                 midx, lab, _ = ops.iou_match(gt, anc, self.iou_thresholds, self.iou_labels, True)
-                pos, neg = subsample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0)
-                lab.fill_(-1)
-                lab[pos] = 1
-                lab[neg] = 0
+                if legacy:
+                    pos, neg = subsample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0)
+                    lab.fill_(-1)
+                    lab[pos] = 1
+                    lab[neg] = 0
                 labels.append(lab)
                 matched.append(torch.zeros_like(anc) if len(gt) == 0 else gt[midx])
             lab_all = torch.stack(labels)                              # (N,R) int8
+            if not legacy:                                             # whole batch, no per-image host syncs
+                lab_all = sampling.keyed_relabel(lab_all, self.batch_size_per_image, self.positive_fraction, 0)
             flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
             gt_rows = torch.stack(matched).view(-1, 4)[flat_pos]
         inv = 1.0 / (self.batch_size_per_image * n)
@@ -185,27 +190,31 @@ class GuassianRPN(nn.Module):
         U = self.cfg.UNSUPNET
         anc = anchors.detach()
         has_box = pseudo[0].has("boxes_sigma")
-        soft, sig, rows, tgt_rows = [], [], [], []
         with torch.no_grad():
-            for i, inst in enumerate(pseudo):
-                pb = inst.pseudo_boxes.tensor
-                midx, lab, _ = ops.iou_match(pb, anc, self.iou_thresholds, self.iou_labels, True)
-                pos = torch.nonzero(lab == 1).squeeze(1)               # positives only, no subsampling
-                sel = midx[pos]
-                soft.append(inst.scores_logists[sel])
-                sig.append((inst.boxes_sigma if has_box else inst.scores_logists)[sel])
-                rows.append(pos + i * r)
-                tgt_rows.append(pb[sel])
-            T = torch.cat(soft, 0).contiguous()
-            flat = torch.cat(rows, 0)
+            # one IoU match per image (different pseudo-box counts), then ONE nonzero for the whole batch: the
+            # positives of image i select rows of the concatenated pseudo-label tensors through per-image offsets
+            labs, midxs, offs, o = [], [], [], 0
+            for inst in pseudo:
+                midx, lab, _ = ops.iou_match(inst.pseudo_boxes.tensor, anc, self.iou_thresholds, self.iou_labels, True)
+                labs.append(lab)
+                midxs.append(midx)
+                offs.append(o)
+                o += len(inst.pseudo_boxes)
+            flat = torch.nonzero(torch.stack(labs).view(-1) == 1).squeeze(1)      # positives only, no subsampling
+            img = torch.div(flat, r, rounding_mode="floor")
+            sel = torch.stack(midxs).view(-1)[flat] + torch.tensor(offs, device=flat.device)[img]
+            all_logits = torch.cat([inst.scores_logists for inst in pseudo], 0)
+            T = all_logits[sel].contiguous()
+            sig_all = torch.cat([(inst.boxes_sigma if has_box else inst.scores_logists) for inst in pseudo], 0)[sel]
+            tgt_all = torch.cat([inst.pseudo_boxes.tensor for inst in pseudo], 0)[sel]
         inv = 1.0 / (self.batch_size_per_image * n)
         x = logits.reshape(-1)[flat]
         loss_cls, fg = ops.rpn_soft_obj_loss(T, x, U.TAU[0], U.EFL_LAMBDA[0], bool(U.EFL), inv)
         out = {"loss_rpn_cls": loss_cls}
         if has_box:
             q = d8.reshape(-1, 8)[flat]
-            mu_p = self.box2box_transform.get_deltas(anchors[flat % r], torch.cat(tgt_rows, 0))
-            out["loss_rpn_loc"] = ops.kl_efl_loss(q, mu_p, torch.cat(sig, 0), fg, U.TAU[1], U.EFL_LAMBDA[1],
+            mu_p = self.box2box_transform.get_deltas(anchors[flat % r], tgt_all)
+            out["loss_rpn_loc"] = ops.kl_efl_loss(q, mu_p, sig_all, fg, U.TAU[1], U.EFL_LAMBDA[1],
                                                   bool(U.EFL), 0, inv)
         return out
 

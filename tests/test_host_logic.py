@@ -136,3 +136,54 @@ def test_detector_postprocess_rescales_clips_and_drops_empty():
     assert torch.equal(out.pred_boxes.tensor, torch.tensor([[20.0, 10.0, 100.0, 30.0], [380.0, 45.0, 400.0, 50.0]]))
     assert torch.equal(out.scores, torch.tensor([0.9, 0.8]))
     assert torch.equal(r.pred_boxes.tensor[0], torch.tensor([10.0, 20.0, 50.0, 60.0]))      # input not mutated
+
+
+def test_keyed_sampling_equals_reference_subsample_labels():
+    """The sync-free sampler (random keys + top-k) selects exactly what D2's subsample_labels selects when the latter
+    draws its two permutations as the key order of the candidates (oracle KeyedPerm) -- labels, counts and order."""
+    import torch
+    from oracle import d2, pt as opt
+    from probabilisticteacher_amd.modeling import sampling
+    g = torch.Generator().manual_seed(5)
+    # --- RPN flavour: batch relabel, 256 samples @ 0.5, bg label 0; rows with few / no positives and few negatives
+    n, r = 4, 3000
+    labels = torch.full((n, r), -1, dtype=torch.int8)
+    labels[0, torch.randperm(r, generator=g)[:400]] = 1
+    labels[0, torch.randperm(r, generator=g)[:2000]] = 0
+    labels[1, torch.randperm(r, generator=g)[:20]] = 1           # fewer positives than 128 -> more negatives
+    labels[1, torch.randperm(r, generator=g)[:1500]] = 0
+    labels[2, torch.randperm(r, generator=g)[:50]] = 0            # no positives, fewer negatives than 256
+    labels[3, :] = 1                                              # no negatives at all
+    kp = opt.KeyedPerm(77)
+    sampling.set_key_fn(kp.draw)
+    try:
+        got = sampling.keyed_relabel(labels.clone(), 256, 0.5, 0)
+    finally:
+        sampling.set_key_fn(None)
+    kp.start_replay()
+    for i in range(n):
+        lab = labels[i].clone()
+        pos, neg = d2.subsample_labels(lab, 256, 0.5, 0, kp)
+        ref = torch.full_like(lab, -1)
+        ref[pos] = 1
+        ref[neg] = 0
+        assert torch.equal(got[i], ref), f"row {i}"
+    p1 = int((labels[1] == 1).sum())
+    assert 0 < p1 <= 20 and int((got[1] == 1).sum()) == p1 and int((got[1] == 0).sum()) == 256 - p1
+    assert int((got[2] == 1).sum()) == 0 and int((got[2] == 0).sum()) == 50 and int((got[3] == 1).sum()) == 128
+    # --- ROI flavour: per-image sample of 512 @ 0.25 with class labels, bg = K
+    K = 8
+    kp = opt.KeyedPerm(78)
+    for p_count, n_fg in ((2007, 300), (640, 12), (100, 0)):
+        cls = torch.full((p_count,), K, dtype=torch.int64)
+        cls[torch.randperm(p_count, generator=g)[:n_fg]] = torch.randint(0, K, (n_fg,), generator=g)
+        cls[torch.randperm(p_count, generator=g)[:p_count // 10]] = -1
+        sampling.set_key_fn(kp.draw)
+        try:
+            i_f, n_f, i_b, n_b = sampling.keyed_sample(cls, 512, 0.25, K)
+        finally:
+            sampling.set_key_fn(None)
+        kp.start_replay()
+        fg, bg = d2.subsample_labels(cls, 512, 0.25, K, kp)
+        assert torch.equal(i_f[:int(n_f)], fg) and torch.equal(i_b[:int(n_b)], bg)
+        kp.replay = None

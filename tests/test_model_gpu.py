@@ -295,3 +295,62 @@ def test_eval_mode_inference_matches_oracle():
             assert frac >= 0.95, f"eval detections matched {frac:.3f}"
             bt = a.pred_boxes.tensor.cpu()
             assert (bt[:, 0::2] <= rec["width"]).all() and (bt[:, 1::2] <= rec["height"]).all() and (bt >= 0).all()
+
+
+def test_supervised_and_unsup_branches_with_keyed_sampling_match_oracle():
+    """The production sampler (random keys + top-k, no per-image host sync) against the oracle: both sides consume the
+    same key stream (oracle KeyedPerm), so the sampled anchors / proposals -- and with them all four supervised losses
+    -- must agree; the unsupervised branch exercises the batched (single-nonzero) positive gathers."""
+    from probabilisticteacher_amd import modeling
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    K = 8
+    cfg = _cfg(K, "DefaultAnchorGenerator", (0.25, 0.25))
+    ocfg = opt.Cfg(num_classes=K)
+    params = opt.golden_params(ocfg, 21)
+    model = modeling.build_model(cfg).train()
+    _load_params(model, params)
+    g = torch.Generator().manual_seed(4)
+    recs, orecs = [], []
+    for i in range(3):
+        img = torch.randint(0, 256, (3, 128, 160), generator=g, dtype=torch.uint8)
+        m = [4, 1, 0][i]                                                  # one image without ground truth
+        xy = torch.rand(m, 2, generator=g) * torch.tensor([90.0, 70.0])
+        wh = 20 + torch.rand(m, 2, generator=g) * 50
+        boxes = torch.cat([xy, xy + wh], 1)
+        cls = torch.randint(0, K, (m,), generator=g)
+        a, b = FreeInstances((128, 160)), opt.FreeInstances((128, 160))
+        a.gt_boxes, a.gt_classes = Boxes(boxes.clone()), cls.clone()
+        b.gt_boxes, b.gt_classes = d2.Boxes(boxes.clone()), cls.clone()
+        recs.append({"image": img, "instances": a})
+        orecs.append({"image": img, "instances": b})
+    kp = opt.KeyedPerm(31)
+    sampling.set_key_fn(kp.draw)
+    try:
+        got, _, _, _ = model(recs, branch="supervised")
+    finally:
+        sampling.set_key_fn(None)
+    kp.start_replay()
+    ref, _, _, _ = opt.model_forward(ocfg, params, orecs, "supervised", perm_fn=kp)
+    assert not kp.replay, "the oracle must consume every key row the product drew"
+    for k in ref:
+        close(got[k].detach().cpu(), ref[k].detach(), 2e-4, 1e-6, "keyed sampling " + k)
+    sum(got.values()).backward()
+    # unsupervised branch (no randomness): pseudo labels on two images, one of them with a single far-away box
+    un, oun = [], []
+    for i in range(2):
+        pb = torch.tensor([[20.0, 30.0, 90.0, 100.0], [60.0, 10.0, 150.0, 90.0]]) if i == 0 else torch.tensor([[5.0, 5.0, 60.0, 70.0]])
+        lg = torch.randn(len(pb), K + 1, generator=g)
+        sg = torch.randn(len(pb), 4, generator=g)
+        a, b = FreeInstances((128, 160)), opt.FreeInstances((128, 160))
+        a.pseudo_boxes, a.scores_logists, a.boxes_sigma = Boxes(pb.clone()), lg.clone(), sg.clone()
+        b.pseudo_boxes, b.scores_logists, b.boxes_sigma = d2.Boxes(pb.clone()), lg.clone(), sg.clone()
+        un.append({"image": recs[i]["image"], "instances": a})
+        oun.append({"image": recs[i]["image"], "instances": b})
+    gu, _, _, _ = model(un, branch="unsupervised", danchor=True)
+    ru, _, _, _ = opt.model_forward(ocfg, params, oun, "unsupervised", danchor=True)
+    for k in ru:
+        if torch.isnan(ru[k]):
+            assert torch.isnan(gu[k]), k
+        else:
+            close(gu[k].detach().cpu(), ru[k].detach(), 5e-4, 1e-6, "unsup " + k)
