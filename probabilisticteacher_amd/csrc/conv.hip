@@ -793,11 +793,11 @@ __device__ __forceinline__ void wgrad_stage_edge(const float* __restrict__ al0, 
 template <int G, bool EDGE>
 __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restrict__ x, const float* __restrict__ dy,
                                                float* __restrict__ partial, int N, int Cin, int Cout, int H, int W,
-                                               int tilesX, int tilesY, int ciTiles, int S, int txb, int wave, int lane)
+                                               int tilesX, int tilesY, int ciTiles, int S, int txb, int bid, int wave,
+                                               int lane)
 {
     constexpr int NT = G == 0 ? 5 : 4;
     const int cw = wave & 3;
-    int bid = blockIdx.x;
     const int s = bid % S; bid /= S;
     const int cit = bid % ciTiles;
     const int cot = bid / ciTiles;
@@ -931,19 +931,27 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
     }
 }
 
-// EDGE = false: tile columns txb .. txb + tilesX - 1 with the full 16-step stage; EDGE = true: the (single) right-edge
-// tile column with the interleaved short stage.  The launcher uses the second variant when the last tile of a row
-// has <= 24 valid columns; its split-K partials follow the main launch's in the workspace.
-template <bool EDGE>
+// One launch, two kinds of workgroups.  Workgroups 0 .. nMain-1 walk tile columns 0 .. tilesXm-1 with the full 16-step
+// stage (split-K factor S).  When the last tile of a row has <= 24 valid columns (nEdge > 0), tilesXm excludes it and
+// workgroups nMain .. nMain+nEdge-1 walk that column alone with the interleaved short stage (split-K factor Se, partials
+// after the main ones in the workspace).  The short-stage workgroups are latency-bound (few MFMAs per DMA round trip);
+// dispatched after the main ones they fill the tail of the launch instead of costing a launch of their own.
 __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_buf_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
-    int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S, int txb)
+    int Cout, int H, int W, int tilesXm, int tilesY, int coTiles, int ciTiles, int S, int nMain, int Se)
 {
     __shared__ __attribute__((aligned(16))) float lds[2 * WB_STAGE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave < 4) wgrad_buf_body<0, EDGE>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, txb, wave, lane);
-    else wgrad_buf_body<1, EDGE>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesX, tilesY, ciTiles, S, txb, wave, lane);
+    const int bid = blockIdx.x;
+    if (bid < nMain) {
+        if (wave < 4) wgrad_buf_body<0, false>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
+        else wgrad_buf_body<1, false>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
+    } else {
+        float* pe = partial + (size_t)S * 9 * Cout * Cin;
+        if (wave < 4) wgrad_buf_body<0, true>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
+        else wgrad_buf_body<1, true>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
+    }
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout,
@@ -1176,18 +1184,11 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
     const int64_t bg_off = (int64_t)(S + Se) * 9 * cout * cin;
     hipStream_t st = (hipStream_t)s;
     if (conv_impl() != 1 && (int64_t)128 * h * w < (1 << 28)) {
-        if (Se > 0) {
-            // the right-edge tile column has few valid pixels: give it the short interleaved stage in its own launch
-            hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n,
-                               cin, cout, h, w, tilesX - 1, tilesY, coTiles, ciTiles, S, 0);
-            hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<true>, dim3(coTiles * ciTiles * Se), dim3(512), 0, st, x, dy,
-                               ws + (int64_t)S * 9 * cout * cin, n, cin, cout, h, w, 1, tilesY, coTiles, ciTiles, Se,
-                               tilesX - 1);
-            S += Se;
-        } else {
-            hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(coTiles * ciTiles * S), dim3(512), 0, st, x, dy, ws, n,
-                               cin, cout, h, w, tilesX, tilesY, coTiles, ciTiles, S, 0);
-        }
+        // Se > 0: the right-edge tile column has few valid pixels and gets the short interleaved stage
+        const int nMain = coTiles * ciTiles * S, nEdge = coTiles * ciTiles * Se;
+        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel, dim3(nMain + nEdge), dim3(512), 0, st, x, dy, ws, n, cin, cout, h, w,
+                           Se > 0 ? tilesX - 1 : tilesX, tilesY, coTiles, ciTiles, S, nMain, Se);
+        S += Se;
     } else {
         hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
                            cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);
