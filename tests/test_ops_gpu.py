@@ -528,3 +528,35 @@ def test_vgg_block_fused_backward(ops, pool):
     for i in range(3):
         close(wd[i].grad, wr[i].grad, 1e-4, 1e-3, f"block dw{i}")
         close(bd[i].grad, br[i].grad, 1e-4, 1e-3, f"block db{i}")
+
+
+# ------------------------------------------------------------------------------------------ shape fuzz
+def test_conv3x3_random_shapes(ops):
+    """24 seeded random shapes (odd widths and heights down to 1, channel counts off the tile sizes, batch 1-3)
+    through forward, dgrad, wgrad and bias gradient against torch CPU: edge-tile, halo and range-check handling."""
+    rng = np.random.RandomState(2024)
+    for case in range(24):
+        n = int(rng.randint(1, 4))
+        cin = int(rng.choice([1, 3, 4, 5, 17, 32, 33, 64]))
+        cout = int(rng.choice([1, 7, 32, 64, 65, 128, 130]))
+        h = int(rng.choice([1, 2, 3, 4, 5, 9, 13]))
+        w = int(rng.choice([1, 2, 3, 5, 8, 25, 31, 32, 33, 39, 57, 64, 71]))
+        relu = bool(rng.randint(0, 2))
+        gen = g(1000 + case)
+        x = torch.randn(n, cin, h, w, generator=gen)
+        wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+        b = torch.randn(cout, generator=gen) * 0.1
+        xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+        yr = F.conv2d(xr, wr, br, padding=1)
+        if relu:
+            yr = F.relu(yr)
+        gy = torch.randn(yr.shape, generator=gen)
+        yr.backward(gy)
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, wt, b))
+        yd = ops.conv3x3(xd, wd, bd, relu)
+        tag = f"case {case} n={n} cin={cin} cout={cout} h={h} w={w} relu={relu}"
+        close(yd, yr, 1e-4, 1e-4, "fwd " + tag)
+        yd.backward(gy.to(DEV))
+        close(xd.grad, xr.grad, 1e-4, 2e-4, "dgrad " + tag)
+        close(wd.grad, wr.grad, 1e-4, 1e-3, "wgrad " + tag)
+        close(bd.grad, br.grad, 1e-4, 1e-3, "bias grad " + tag)
