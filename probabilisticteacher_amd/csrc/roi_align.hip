@@ -350,9 +350,14 @@ __global__ __launch_bounds__(RB_THREADS) void roi_align_bwd_sep_kernel(const flo
 //   * every thread owns a FIXED column (channel c = tid / 128, feature column fx = tid % 128) of the LDS planes for
 //     the whole ROI walk, so consecutive ROIs never hand a cell from one thread to another: the ROI loop has no
 //     barrier at all (the kernel above needs three per ROI and keeps ~80 of 512 threads busy).
-// Each wave stages the ROI's Wy rows in a private LDS strip (broadcast reads in the column loop), pulls dOut[r][c]
-// through scalar loads (the channel is wave-uniform) and its own Wx row with two 16-B loads.
+// Each wave stages the ROI's Wy table in a private LDS strip (broadcast reads in the column loop); lanes 0-48 hold
+// dOut[r][c] (broadcast with v_readlane) and every lane its own Wx row.  The tables are indexed by absolute feature
+// row / column, so none of these loads depends on the ROI header and all of them are issued one ROI ahead.
 struct RoiBwdHeader { int y0, y1, x0, x1; float count; int pad[3]; };
+__device__ __forceinline__ float rdl(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 constexpr int RB2_THREADS = 512, RB2_XP = 128;
 
 __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restrict__ rois, void* __restrict__ ws,
@@ -399,12 +404,10 @@ __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restr
         hd.pad[0] = hd.pad[1] = hd.pad[2] = 0;
         *reinterpret_cast<RoiBwdHeader*>(base) = hd;
     }
-    float* wy = reinterpret_cast<float*>(base + sizeof(RoiBwdHeader));
-    float* wx = wy + (size_t)H * 8;
-    if (y1 >= 0 && x1 >= 0) {
-        for (int i = tid; i < (y1 - y0 + 1) * 8; i += 64) wy[i] = tsm[y0 * 8 + i];
-        for (int i = tid; i < (x1 - x0 + 1) * 8; i += 64) wx[i] = tsm[(H + x0) * 8 + i];
-    }
+    // rows are stored by ABSOLUTE feature row / column (zeros outside the ROI's range), so the consumer's loads do
+    // not depend on the header and can be prefetched a whole ROI ahead
+    float* wt = reinterpret_cast<float*>(base + sizeof(RoiBwdHeader));
+    for (int i = tid; i < (H + W) * 8; i += 64) wt[i] = tsm[i];
 }
 
 __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const float* __restrict__ dout,
@@ -425,59 +428,66 @@ __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const fl
     __syncthreads();
     const int c = wave >> 1;                                     // wave-uniform channel; two waves cover 128 columns
     const int fx = (wave & 1) * 64 + lane;
+    const int fxc = fx < W ? fx : W - 1;                         // clamped: lanes past the map only read
     float* wyl = wystage + wave * H * 8;
     const size_t stride = sizeof(RoiBwdHeader) + (size_t)(H + W) * 8 * sizeof(float);
-    const int r1 = img_off[n + 1];
-    if (c < cg) {
+    const int r0 = img_off[n], r1 = img_off[n + 1];
+    const int nwy = H * 2;                                       // f32x4 pieces of a Wy table (<= 128: two per lane)
+    if (c < cg && r0 < r1) {
         float* col = plane + c * HW + fx;
-        for (int r = img_off[n]; r < r1; ++r) {
+        // everything ROI r needs is fetched while ROI r-1 is being accumulated: its header (scalar), this lane's
+        // dOut value (lanes 0-48 hold the 7x7 gradient of channel c), its Wx row and its two pieces of the Wy table
+        auto fetch = [&](int r, RoiBwdHeader& hd, float& g, f32x4& wxa, f32x4& wxb, f32x4& wy0, f32x4& wy1) {
             const char* base = (const char*)ws + (size_t)r * stride;
-            const RoiBwdHeader hd = *reinterpret_cast<const RoiBwdHeader*>(base);
-            if (hd.y1 < 0 || hd.x1 < 0) continue;
+            hd = *reinterpret_cast<const RoiBwdHeader*>(base);
+            const f32x4* wyg = reinterpret_cast<const f32x4*>(base + sizeof(RoiBwdHeader));
+            const f32x4* wxg = wyg + (size_t)H * 2;
+            g = dout[((size_t)r * C + c0 + c) * 49 + (lane < 49 ? lane : 48)];
+            wxa = wxg[fxc * 2];
+            wxb = wxg[fxc * 2 + 1];
+            wy0 = wyg[lane < nwy ? lane : 0];
+            wy1 = wyg[lane + 64 < nwy ? lane + 64 : 0];
+        };
+        RoiBwdHeader hd, hdn;
+        float g, gn;
+        f32x4 wxa, wxb, wy0, wy1, wxan, wxbn, wy0n, wy1n;
+        fetch(r0, hd, g, wxa, wxb, wy0, wy1);
+        for (int r = r0; r < r1; ++r) {
+            if (r + 1 < r1) fetch(r + 1, hdn, gn, wxan, wxbn, wy0n, wy1n);
             const int lo = (wave & 1) * 64;
-            if (hd.x1 < lo || hd.x0 > lo + 63) continue;         // no column of this wave inside the ROI (uniform)
-            const float* wyg = reinterpret_cast<const float*>(base + sizeof(RoiBwdHeader));
-            const float* wxg = wyg + (size_t)H * 8;
-            const int ny = hd.y1 - hd.y0 + 1;
-            // stage Wy rows (ny x 8 floats) in this wave's LDS strip
-            for (int i = lane; i < ny * 2; i += 64)
-                reinterpret_cast<f32x4*>(wyl)[i] = reinterpret_cast<const f32x4*>(wyg)[i];
-            __builtin_amdgcn_wave_barrier();                     // the strip is read by other lanes of this wave
-            const bool act = fx >= hd.x0 && fx <= hd.x1;
-            f32x4 wxa = {0.f, 0.f, 0.f, 0.f}, wxb = {0.f, 0.f, 0.f, 0.f};
-            if (act) {
-                wxa = reinterpret_cast<const f32x4*>(wxg)[(fx - hd.x0) * 2];
-                wxb = reinterpret_cast<const f32x4*>(wxg)[(fx - hd.x0) * 2 + 1];
-            }
-            const float* ob = dout + ((size_t)r * C + c0 + c) * 49;     // wave-uniform: scalar loads
-            float t[7];
+            if (hd.y1 >= 0 && hd.x1 >= 0 && hd.x1 >= lo && hd.x0 <= lo + 63) {      // wave-uniform
+                reinterpret_cast<f32x4*>(wyl)[lane < nwy ? lane : 0] = wy0;
+                if (lane + 64 < nwy) reinterpret_cast<f32x4*>(wyl)[lane + 64] = wy1;
+                __builtin_amdgcn_wave_barrier();                 // the strip is read by other lanes of this wave
+                float t[7];
 #pragma unroll
-            for (int ph = 0; ph < 7; ++ph) {
-                float a = ob[ph * 7 + 0] * wxa[0];
-                a += ob[ph * 7 + 1] * wxa[1];
-                a += ob[ph * 7 + 2] * wxa[2];
-                a += ob[ph * 7 + 3] * wxa[3];
-                a += ob[ph * 7 + 4] * wxb[0];
-                a += ob[ph * 7 + 5] * wxb[1];
-                a += ob[ph * 7 + 6] * wxb[2];
-                t[ph] = a / hd.count;
-            }
-            if (act) {
-                float* cp = col + hd.y0 * W;
-                for (int k = 0; k < ny; ++k) {
-                    const f32x4 wa = *reinterpret_cast<const f32x4*>(wyl + k * 8);
-                    const f32x4 wb = *reinterpret_cast<const f32x4*>(wyl + k * 8 + 4);
-                    float a = wa[0] * t[0];
-                    a += wa[1] * t[1];
-                    a += wa[2] * t[2];
-                    a += wa[3] * t[3];
-                    a += wb[0] * t[4];
-                    a += wb[1] * t[5];
-                    a += wb[2] * t[6];
-                    cp[k * W] += a;
+                for (int ph = 0; ph < 7; ++ph) {
+                    float a = rdl(g, ph * 7 + 0) * wxa[0];
+                    a += rdl(g, ph * 7 + 1) * wxa[1];
+                    a += rdl(g, ph * 7 + 2) * wxa[2];
+                    a += rdl(g, ph * 7 + 3) * wxa[3];
+                    a += rdl(g, ph * 7 + 4) * wxb[0];
+                    a += rdl(g, ph * 7 + 5) * wxb[1];
+                    a += rdl(g, ph * 7 + 6) * wxb[2];
+                    t[ph] = a / hd.count;
                 }
+                if (fx >= hd.x0 && fx <= hd.x1) {
+                    for (int fy = hd.y0; fy <= hd.y1; ++fy) {
+                        const f32x4 wa = *reinterpret_cast<const f32x4*>(wyl + fy * 8);
+                        const f32x4 wb = *reinterpret_cast<const f32x4*>(wyl + fy * 8 + 4);
+                        float a = wa[0] * t[0];
+                        a += wa[1] * t[1];
+                        a += wa[2] * t[2];
+                        a += wa[3] * t[3];
+                        a += wb[0] * t[4];
+                        a += wb[1] * t[5];
+                        a += wb[2] * t[6];
+                        col[fy * W] += a;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                 // next ROI overwrites the strip
             }
-            __builtin_amdgcn_wave_barrier();                     // next ROI overwrites the strip
+            hd = hdn; g = gn; wxa = wxan; wxb = wxbn; wy0 = wy0n; wy1 = wy1n;
         }
     }
     __syncthreads();
@@ -577,7 +587,7 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
     static int impl = -1;                 // PTMI_ROI_BWD_IMPL=1: the barrier-per-ROI kernel
     if (impl < 0) { const char* e = getenv("PTMI_ROI_BWD_IMPL"); impl = (e && e[0] == '1') ? 1 : 2; }
     const size_t stage = (size_t)(RB2_THREADS / 64) * h * 8 * sizeof(float);
-    if (impl == 2 && ws && w <= RB2_XP && 4 * plane_bytes + stage <= 79 * 1024) {
+    if (impl == 2 && ws && w <= RB2_XP && h <= 64 && 4 * plane_bytes + stage <= 79 * 1024) {
         hipLaunchKernelGGL(roi_bwd_tables_kernel, dim3(r), dim3(64), (size_t)(h + w) * 8 * sizeof(float), st, rois, ws, h,
                            w, scale);
         PTMI_LAUNCH_CHECK("roi_align_bwd_tables");
