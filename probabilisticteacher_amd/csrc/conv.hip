@@ -581,7 +581,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         }
         wp[i] = v;
     }
-    // 64-float "zero page" after the slabs: the LDS-DMA kernel points halo / channel-padding lanes here
+    // 64-float "zero page" after the slabs: the register-streamed stem kernel points halo / channel-padding lanes here
     if (blockIdx.x == 0 && threadIdx.x < 64) wp[total + threadIdx.x] = 0.f;
 }
 
@@ -1129,7 +1129,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     PTMI_CHECK_ARG(blocks < (1ll << 31), "conv3x3_fwd: grid too large");
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)s;
-    // register-streamed kernel: everywhere with PTMI_CONV_IMPL=3 (A/B experiments: slower than LDS-DMA on the big
+    // register-streamed kernel: everywhere with PTMI_CONV_IMPL=3 (A/B experiments: slower than the buffer-DMA pipeline on the big
     // layers, 66-80 vs 115-131 TF/s) and by default for the 3-channel stem, whose K = 36 loop is too short to
     // amortise the LDS pipeline's prologue (25 vs 18 TF/s; that layer is HBM-write bound)
     if (CK == 4 && (conv_impl() == 3 || (conv_impl() == 4 && cin <= 4 && stem_direct())) && epilogue != 4) {
