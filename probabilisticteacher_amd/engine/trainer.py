@@ -36,6 +36,7 @@ class PTrainer:
         broadcast_(self.teacher.flat)
         self.momentum_buf = torch.zeros_like(self.student.trainable())
         self._first_step = True
+        self.joint_student_pass = True      # one backbone pass for the two student branches when they share a canvas
         self.ensem_ts_model = EnsembleTSModel(self.model_teacher, self.model)
         self.iter = self.start_iter = 0
         self.max_iter = cfg.SOLVER.MAX_ITER
@@ -150,9 +151,14 @@ class PTrainer:
             unlabel_data_q = self.resize(unlabel_data_q)
             label_data_q = self.resize(label_data_q)
             record_dict = {}
-            rec_sup, _, _, _ = self.model(label_data_q + label_data_k, branch="supervised")
+            sup_batch = label_data_q + label_data_k
+            if self.joint_student_pass and self.model.can_run_jointly(sup_batch, unlabel_data_q):
+                # one backbone pass for both student branches (same canvas): fewer, fuller launches
+                rec_sup, rec_unsup = self.model.forward_joint(sup_batch, unlabel_data_q, danchor=True)
+            else:
+                rec_sup, _, _, _ = self.model(sup_batch, branch="supervised")
+                rec_unsup, _, _, _ = self.model(unlabel_data_q, branch="unsupervised", danchor=True)
             record_dict.update({k + "_sup": v for k, v in rec_sup.items()})
-            rec_unsup, _, _, _ = self.model(unlabel_data_q, branch="unsupervised", danchor=True)
             record_dict.update({k + "_unsup": v for k, v in rec_unsup.items()})
             losses = 0
             for k, v in record_dict.items():

@@ -49,6 +49,44 @@ class GuassianGeneralizedRCNN(nn.Module):
             out.append({"instances": detector_postprocess(res, rec.get("height", size[0]), rec.get("width", size[1]))})
         return out
 
+    @staticmethod
+    def _padded_size(batched_inputs):
+        return (max(int(x["image"].shape[-2]) for x in batched_inputs), max(int(x["image"].shape[-1]) for x in batched_inputs))
+
+    def can_run_jointly(self, sup_inputs, unsup_inputs) -> bool:
+        """Both batches pad to the same canvas (then the padded region, the feature-map size and the anchor grid of each
+        branch are what they would be in separate passes)."""
+        return (self.training and len(sup_inputs) > 0 and len(unsup_inputs) > 0 and
+                self._padded_size(sup_inputs) == self._padded_size(unsup_inputs))
+
+    def forward_joint(self, sup_inputs, unsup_inputs, danchor=True):
+        """`model(sup, branch="supervised")` and `model(unsup, branch="unsupervised", danchor=...)` (trainer.py:341,
+        353-355) with ONE backbone + RPN-head pass over the concatenated images: the convolutions are per-image, so
+        each branch sees exactly the activations of its separate pass; what changes is launch granularity (48 images
+        per conv / wgrad launch instead of 32 + 16: fewer, fuller launches) and the summation order inside the weight
+        gradients.  Returns (losses_sup, losses_unsup)."""
+        assert self.can_run_jointly(sup_inputs, unsup_inputs)
+        ns = len(sup_inputs)
+        images = self.preprocess_image(list(sup_inputs) + list(unsup_inputs))
+        features = self.backbone(images.tensor)
+        feats = [features[f] for f in self.proposal_generator.in_features]
+        obj, deltas = self.proposal_generator.rpn_head(feats)
+        out = []
+        for sl, inputs, branch, da in ((slice(0, ns), sup_inputs, "supervised", False),
+                                       (slice(ns, None), unsup_inputs, "unsupervised", danchor)):
+            img = ImageList(images.tensor[sl], images.image_sizes[sl])
+            feat = {k: v[sl] for k, v in features.items()}
+            head = ([o[sl] for o in obj], [d[sl] for d in deltas])
+            gt = [x["instances"].to(self.device) for x in inputs]
+            proposals, l_rpn = self.proposal_generator(img, feat, gt, branch=branch if branch == "unsupervised" else "",
+                                                       danchor=da, head_out=head)
+            _, l_det = self.roi_heads(img, feat, proposals, gt, branch=branch)
+            losses = {}
+            losses.update(l_det)
+            losses.update(l_rpn)
+            out.append(losses)
+        return out[0], out[1]
+
     def forward(self, batched_inputs, branch="supervised", danchor=False):
         if not self.training:
             return self.inference(batched_inputs)

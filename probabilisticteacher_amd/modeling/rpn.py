@@ -121,13 +121,15 @@ class GuassianRPN(nn.Module):
 
     # ------------------------------------------------------------------ forward (rpn.py:80-154)
     def forward(self, images, features, gt_instances: Optional[List[FreeInstances]] = None, compute_loss=True,
-                branch="", danchor=False):
+                branch="", danchor=False, head_out=None):
+        """`head_out` = (objectness, deltas) already computed by `self.rpn_head` on these features (the joint
+        student pass runs the head once for both branches)."""
         feats = [features[f] for f in self.in_features]
         assert len(feats) == 1, "single-level RPN (vgg_block5)"
         anchors = self.anchor_generator(feats)[0].tensor
         if not danchor:
             anchors = anchors.detach()      # grad_zero (rpn.py:91-94): the anchor table gets an all-zero gradient
-        obj, deltas = self.rpn_head(feats)
+        obj, deltas = head_out if head_out is not None else self.rpn_head(feats)
         n, a, h, w = obj[0].shape
         # (N,A,H,W) -> (N,H*W*A);  (N,A*8,H,W) -> (N,H*W*A,8)   (rpn.py:97-113)
         logits = obj[0].permute(0, 2, 3, 1).reshape(n, -1)

@@ -354,3 +354,62 @@ def test_supervised_and_unsup_branches_with_keyed_sampling_match_oracle():
             assert torch.isnan(gu[k]), k
         else:
             close(gu[k].detach().cpu(), ru[k].detach(), 5e-4, 1e-6, "unsup " + k)
+
+
+def test_joint_student_pass_equals_separate_passes():
+    """forward_joint (one backbone / RPN-head pass over supervised + unsupervised images) against the two separate
+    `model(...)` calls of trainer.py:341,353-355 on the same inputs and the same sampler keys: identical losses and
+    matching gradients (the weight gradients only differ in summation order)."""
+    from probabilisticteacher_amd import modeling
+    from probabilisticteacher_amd.engine.flat import FlatParams
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    K = 8
+    cfg = _cfg(K, "DifferentiableAnchorGenerator", (0.5, 0.5))
+    ocfg = opt.Cfg(num_classes=K, anchor_generator="DifferentiableAnchorGenerator")
+    params = opt.golden_params(ocfg, 13)
+    model = modeling.build_model(cfg).train()
+    _load_params(model, params)
+    flat = FlatParams(model)
+    g = torch.Generator().manual_seed(8)
+    sup, un = [], []
+    for i in range(3):
+        img = torch.randint(0, 256, (3, 112, 144), generator=g, dtype=torch.uint8)
+        m = 1 + i
+        xy = torch.rand(m, 2, generator=g) * torch.tensor([80.0, 60.0])
+        a = FreeInstances((112, 144))
+        a.gt_boxes, a.gt_classes = Boxes(torch.cat([xy, xy + 25 + torch.rand(m, 2, generator=g) * 30], 1)), torch.randint(0, K, (m,), generator=g)
+        sup.append({"image": img, "instances": a})
+    for i in range(2):
+        img = torch.randint(0, 256, (3, 112, 144), generator=g, dtype=torch.uint8)
+        a = FreeInstances((112, 144))
+        a.pseudo_boxes = Boxes(torch.tensor([[20.0, 30.0, 90.0, 100.0], [60.0, 10.0, 140.0, 90.0]])[: 2 - i])
+        a.scores_logists = torch.randn(2 - i, K + 1, generator=g)
+        a.boxes_sigma = torch.randn(2 - i, 4, generator=g)
+        un.append({"image": img, "instances": a})
+    assert model.can_run_jointly(sup, un)
+
+    def run(joint):
+        kp = opt.KeyedPerm(5)
+        sampling.set_key_fn(kp.draw)
+        flat.zero_grad()
+        try:
+            if joint:
+                ls, lu = model.forward_joint(sup, un, danchor=True)
+            else:
+                ls, _, _, _ = model(sup, branch="supervised")
+                lu, _, _, _ = model(un, branch="unsupervised", danchor=True)
+        finally:
+            sampling.set_key_fn(None)
+        (sum(ls.values()) + sum(lu.values())).backward()
+        return ({k: float(v) for k, v in ls.items()}, {k: float(v) for k, v in lu.items()}, flat.grad.clone())
+    s1, u1, g1 = run(False)
+    s2, u2, g2 = run(True)
+    for a, b in ((s1, s2), (u1, u2)):
+        assert a.keys() == b.keys()
+        for k in a:
+            close(b[k], a[k], 1e-6, 1e-7, "joint vs separate " + k)
+    close(g2.cpu(), g1.cpu(), 1e-4, 1e-5 * float(g1.abs().max()), "joint vs separate gradients")
+    for rec in un:
+        rec["image"] = torch.randint(0, 256, (3, 96, 144), generator=g, dtype=torch.uint8)
+    assert not model.can_run_jointly(sup, un), "different canvases must fall back to separate passes"
