@@ -68,6 +68,74 @@ def allreduce_mean_(flat_grad: torch.Tensor, world_size: int, chunk_elems: int =
     return flat_grad
 
 
+class BucketedGradReducer:
+    """DDP's overlapped gradient exchange on the flat buffer: the flat gradient is cut into contiguous buckets, walking
+    from its END (the box head, whose gradients are produced first in backward, lies last), and each bucket's
+    all-reduce (RCCL over xGMI, async on the collective stream) is launched from a post-accumulate-grad hook as soon as
+    every parameter in it has its gradient -- while the backbone's dgrad / wgrad kernels are still running.
+
+    Buckets are always launched in bucket order (a ready bucket waits for its predecessors), so every rank issues the
+    same sequence of collectives even if autograd visits parameters in a different order; `finish()` launches what is
+    left (parameters that received no gradient this step keep their zeros), waits, and divides by the world size."""
+
+    def __init__(self, fp: FlatParams, world_size: int, bucket_elems: int = 16 * 1024 * 1024, group=None):
+        self.fp, self.world, self.group = fp, world_size, group
+        grad = fp.attach_grads()
+        names = [n for n, p in fp.params.items() if p.requires_grad]
+        self.buckets: List[Tuple[int, int]] = []         # (start, end) in elements, bucket 0 = tail of the buffer
+        self.bucket_of: Dict[str, int] = {}
+        end = fp.n_trainable
+        members: List[str] = []
+        for n in reversed(names):
+            off, k = fp.index[n]
+            members.append(n)
+            if end - off >= bucket_elems or off == 0:
+                for m in members:
+                    self.bucket_of[m] = len(self.buckets)
+                self.buckets.append((off, end))
+                end, members = off, []
+        self.size = [sum(1 for b in self.bucket_of.values() if b == i) for i in range(len(self.buckets))]
+        self._grad = grad
+        self._hooks = []
+        if world_size > 1:
+            for n in names:
+                p = fp.params[n]
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[n])))
+        self.reset()
+
+    def reset(self):
+        self.pending = list(self.size)
+        self.next = 0
+        self.handles = []
+
+    def _make_hook(self, b: int):
+        def hook(_param):
+            self.pending[b] -= 1
+            self._launch_ready()
+        return hook
+
+    def _launch(self, b: int):
+        s, e = self.buckets[b]
+        self.handles.append(dist.all_reduce(self._grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _launch_ready(self):
+        while self.next < len(self.buckets) and self.pending[self.next] <= 0:
+            self._launch(self.next)
+            self.next += 1
+
+    def finish(self) -> torch.Tensor:
+        """Call after backward(): launches the remaining buckets in order, waits for all, averages."""
+        if self.world > 1:
+            while self.next < len(self.buckets):
+                self._launch(self.next)
+                self.next += 1
+            for h in self.handles:
+                h.wait()
+            self._grad.div_(self.world)
+        self.reset()
+        return self._grad
+
+
 def broadcast_(flat: torch.Tensor, src: int = 0, group=None):
     """trainer.py:495 `_sync_params_and_buffers`: rank 0's parameters to everyone, one collective."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

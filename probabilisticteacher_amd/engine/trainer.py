@@ -16,7 +16,7 @@ import torch.distributed as dist
 from .. import ops
 from ..modeling import EnsembleTSModel, build_model
 from ..structures import Boxes, FreeInstances
-from .flat import FlatParams, allreduce_mean_, broadcast_, lr_at
+from .flat import BucketedGradReducer, FlatParams, broadcast_, lr_at
 
 
 class PTrainer:
@@ -35,6 +35,8 @@ class PTrainer:
         broadcast_(self.student.flat)                  # trainer.py:495 _sync_params_and_buffers
         broadcast_(self.teacher.flat)
         self.momentum_buf = torch.zeros_like(self.student.trainable())
+        # gradient exchange overlapped with backward: 16 MB buckets from the tail of the flat buffer (box head first)
+        self.reducer = BucketedGradReducer(self.student, self.world_size, bucket_elems=4 * 1024 * 1024)
         self._first_step = True
         self.joint_student_pass = True      # one backbone pass for the two student branches when they share a canvas
         self.ensem_ts_model = EnsembleTSModel(self.model_teacher, self.model)
@@ -173,7 +175,7 @@ class PTrainer:
                     raise NotImplementedError
 
         losses.backward()
-        allreduce_mean_(self.student.grad, self.world_size)            # DDP gradient average
+        self.reducer.finish()                  # DDP gradient average (buckets were launched during backward)
         ss = self._clip_and_step(10.0)
         self._write_metrics(record_dict, data_time, ss)
         self.iter += 1

@@ -66,3 +66,67 @@ def test_flat_allreduce_matches_single_rank_big_batch():
     ((model(x) - y) ** 2).mean().backward()
     assert flat.n_trainable == nt0
     assert torch.allclose(flat.grad, g0, rtol=1e-5, atol=1e-7)
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.unused = torch.nn.Parameter(torch.ones(5))           # trainable, never gets a gradient; FIRST in the layout
+        self.body = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                                        torch.nn.Linear(16, 3))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+def _mlp():
+    return _Net()
+
+
+def _worker_bucketed(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from probabilisticteacher_amd.engine.flat import BucketedGradReducer, FlatParams, allreduce_mean_, broadcast_
+    torch.manual_seed(3 + rank)
+    model, ref = _mlp(), _mlp()
+    flat, rflat = FlatParams(model), FlatParams(ref)
+    broadcast_(flat.flat)
+    rflat.flat.copy_(flat.flat)
+    red = BucketedGradReducer(flat, world, bucket_elems=100)      # several buckets, tail of the buffer first
+    g = torch.Generator().manual_seed(20 + rank)                  # rank-local data
+    res = []
+    for step in range(2):                                         # two steps: the reducer re-arms itself
+        x, y = torch.randn(4, 6, generator=g), torch.randn(4, 3, generator=g)
+        flat.zero_grad()
+        ((model(x) - y) ** 2).mean().backward()                   # hooks launch ready buckets during backward
+        launched = red.next
+        got = red.finish().clone()
+        rflat.zero_grad()
+        ((ref(x) - y) ** 2).mean().backward()
+        want = allreduce_mean_(rflat.grad, world).clone()
+        res.append((got, want, launched))
+    q.put((rank, res, list(red.buckets), red.bucket_of["unused"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_reducer_overlaps_and_matches_plain_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bucketed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res, buckets, unused_bucket in out:
+        assert len(buckets) >= 3 and buckets[0][1] == max(b[1] for b in buckets), "bucket 0 is the tail of the buffer"
+        assert sorted(buckets)[0][0] == 0 and all(a[0] == b[1] for a, b in zip(buckets[:-1], buckets[1:])), "contiguous cover"
+        for got, want, launched in res:
+            assert torch.allclose(got, want, rtol=1e-6, atol=1e-8), "bucketed exchange == plain mean all-reduce"
+            # every bucket before the one holding the gradient-less parameter went out DURING backward
+            assert launched == unused_bucket == len(buckets) - 1 and launched >= 2, (launched, unused_bucket)
+    assert torch.equal(out[0][1][1][0], out[1][1][1][0]), "both ranks hold the same averaged gradient"
