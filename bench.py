@@ -141,15 +141,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # memory-pool warm-up: one big segment for the caching allocator, so that the steps split cached blocks instead of
+    # calling hipMalloc (the pool otherwise keeps growing for a few steps as ROI counts vary)
+    total_mem = torch.cuda.get_device_properties(dev).total_memory
+    pool = torch.empty(min(64 << 30, total_mem // 4), dtype=torch.uint8, device=dev)
+    del pool
     for i in range(args.warmup):
         trainer.run_step(batches[i % 2])
     sync()
     ops.profile_start()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
+    step_ms = []
     for i in range(args.steps):
-        trainer.run_step(batches[i % 2])
+        ts = time.perf_counter()
+        trainer.run_step(batches[i % 2])          # (ends with the metrics read-back, i.e. synchronised)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
     sync()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
+    if rank == 0:
+        print(f"[bench] per-step ms {[round(v, 1) for v in step_ms]}; device mallocs in the timed region: "
+              f"{ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)}, reserved "
+              f"{ms1.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB", file=sys.stderr)
     prof = ops.profile_stop()
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
