@@ -136,6 +136,24 @@ int ptmi_iou_match(const float* gt, const float* boxes, int m, int64_t nb, const
                    const int* labels_host, int n_thr, int allow_low_quality, int64_t* matched_idx,
                    int8_t* matched_label, float* matched_iou, float* ws, ptmi_stream_t s);
 
+/* The same for a whole batch in one launch per pass.  gt_all: the images' gt boxes concatenated, gt_off (nimg+1) int32
+ * DEVICE row offsets; boxes: either concatenated per image with box_off (nimg+1) int32 DEVICE offsets (outputs in the
+ * same row order), or box_off == NULL: the same max_boxes boxes for every image (RPN anchors; outputs (nimg, max_boxes)).
+ * max_boxes = largest per-image box count; matched_idx is the gt index WITHIN the image; ws: total_gt floats. */
+int ptmi_iou_match_batched(const float* gt_all, const int32_t* gt_off, const float* boxes, const int32_t* box_off,
+                           int nimg, int64_t max_boxes, int64_t total_gt, const float* thresholds_host,
+                           const int* labels_host, int n_thr, int allow_low_quality, int64_t* matched_idx,
+                           int8_t* matched_label, float* matched_iou, float* ws, ptmi_stream_t s);
+/* D2 subsample_labels (rpn.py:433 via RPN._subsample_labels; D2 StandardROIHeads._sample_proposals) for
+ * a batch of label vectors without host syncs: cls_all int64 (concatenated; -1 ignore, bg_label background, anything
+ * else foreground), keys_all i.i.d. uniform keys, offsets (nimg+1) int32 DEVICE.  Per image: n_fg = min(#fg,
+ * num_pos_max), n_bg = min(#bg, num_samples - n_fg); out_fg (nimg, num_pos_max) / out_bg (nimg, num_samples) get the
+ * local indices of the n_fg / n_bg candidates with the smallest keys in ascending key order (== the prefix of the
+ * permutation argsort(keys[candidates])); counts (nimg, 2) int32 = (n_fg, n_bg).  max_count <= 12288. */
+int ptmi_sample_by_keys(const int64_t* cls_all, const float* keys_all, const int32_t* offsets, int nimg,
+                        int64_t max_count, int num_samples, int num_pos_max, int bg_label, int64_t* out_fg,
+                        int64_t* out_bg, int32_t* counts, ptmi_stream_t s);
+
 /* ------------------------------------------------------------------ sort + proposals (N10)
  * replaces torch.sort(descending) at pt/modeling/proposal_generator/proposal_utils.py:87 and the
  * sort inside torchvision nms.  Stable: ties keep ascending original index.

@@ -123,9 +123,9 @@ __device__ __forceinline__ float iou_pair(const float4 g, float garea, const flo
 
 constexpr int MAX_GT_LDS = 2048;
 
-__global__ __launch_bounds__(256) void iou_match_pass1(const float* __restrict__ gt, const float* __restrict__ boxes,
-                                                       int m, int64_t nb, int64_t* __restrict__ midx,
-                                                       float* __restrict__ miou, int* __restrict__ best_bits)
+__device__ __forceinline__ void iou_match_pass1_body(const float* __restrict__ gt, const float* __restrict__ boxes,
+                                                     int m, int64_t nb, int64_t* __restrict__ midx,
+                                                     float* __restrict__ miou, int* __restrict__ best_bits)
 {
     __shared__ float4 sg[MAX_GT_LDS / 8];
     __shared__ float sa[MAX_GT_LDS / 8];
@@ -175,11 +175,18 @@ __global__ __launch_bounds__(256) void iou_match_pass1(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void iou_match_pass2(const float* __restrict__ gt, const float* __restrict__ boxes,
-                                                       int m, int64_t nb, const float* __restrict__ miou,
-                                                       const int* __restrict__ best_bits, float t0, float t1, int l0,
-                                                       int l1, int l2, int n_thr, int lowq,
-                                                       int8_t* __restrict__ mlabel)
+__global__ __launch_bounds__(256) void iou_match_pass1(const float* __restrict__ gt, const float* __restrict__ boxes,
+                                                       int m, int64_t nb, int64_t* __restrict__ midx,
+                                                       float* __restrict__ miou, int* __restrict__ best_bits)
+{
+    iou_match_pass1_body(gt, boxes, m, nb, midx, miou, best_bits);
+}
+
+__device__ __forceinline__ void iou_match_pass2_body(const float* __restrict__ gt, const float* __restrict__ boxes,
+                                                     int m, int64_t nb, const float* __restrict__ miou,
+                                                     const int* __restrict__ best_bits, float t0, float t1, int l0,
+                                                     int l1, int l2, int n_thr, int lowq,
+                                                     int8_t* __restrict__ mlabel)
 {
     __shared__ float4 sg[256];
     __shared__ float sa[256];
@@ -214,6 +221,99 @@ __global__ __launch_bounds__(256) void iou_match_pass2(const float* __restrict__
         if (hit) lab = 1;
     }
     if (j < nb) mlabel[j] = (int8_t)lab;
+}
+
+__global__ __launch_bounds__(256) void iou_match_pass2(const float* __restrict__ gt, const float* __restrict__ boxes,
+                                                       int m, int64_t nb, const float* __restrict__ miou,
+                                                       const int* __restrict__ best_bits, float t0, float t1, int l0,
+                                                       int l1, int l2, int n_thr, int lowq,
+                                                       int8_t* __restrict__ mlabel)
+{
+    iou_match_pass2_body(gt, boxes, m, nb, miou, best_bits, t0, t1, l0, l1, l2, n_thr, lowq, mlabel);
+}
+
+// Batched over images (blockIdx.y): gt rows gt_off[i] .. gt_off[i+1] against box rows box_off[i] .. box_off[i+1], or
+// against the same `nb_shared` boxes for every image when box_off is null (RPN anchors; outputs at i * nb_shared).
+// One launch per pass for the whole batch instead of two per image.
+__global__ __launch_bounds__(256) void iou_match_pass1_batched(const float* __restrict__ gt, const int32_t* __restrict__ gt_off,
+                                                               const float* __restrict__ boxes,
+                                                               const int32_t* __restrict__ box_off, int64_t nb_shared,
+                                                               int64_t* __restrict__ midx, float* __restrict__ miou,
+                                                               int8_t* __restrict__ mlabel, int* __restrict__ best_bits,
+                                                               int label_nomatch)
+{
+    const int img = blockIdx.y;
+    const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
+    const int64_t b0 = box_off ? box_off[img] : 0, nb = box_off ? box_off[img + 1] - b0 : nb_shared;
+    const int64_t o0 = box_off ? b0 : (int64_t)img * nb_shared;
+    if ((int64_t)blockIdx.x * 256 >= nb) return;
+    if (m == 0) {        // Matcher on an empty (0,N) matrix: matches 0, labels = labels[0] (A.3)
+        const int64_t j = blockIdx.x * 256ll + threadIdx.x;
+        if (j < nb) { midx[o0 + j] = 0; miou[o0 + j] = 0.f; mlabel[o0 + j] = (int8_t)label_nomatch; }
+        return;
+    }
+    iou_match_pass1_body(gt + 4 * (size_t)g0, boxes + 4 * (size_t)b0, m, nb, midx + o0, miou + o0, best_bits + g0);
+}
+
+__global__ __launch_bounds__(256) void iou_match_pass2_batched(const float* __restrict__ gt, const int32_t* __restrict__ gt_off,
+                                                               const float* __restrict__ boxes,
+                                                               const int32_t* __restrict__ box_off, int64_t nb_shared,
+                                                               const float* __restrict__ miou, const int* __restrict__ best_bits,
+                                                               float t0, float t1, int l0, int l1, int l2, int n_thr, int lowq,
+                                                               int8_t* __restrict__ mlabel)
+{
+    const int img = blockIdx.y;
+    const int g0 = gt_off[img], m = gt_off[img + 1] - g0;
+    const int64_t b0 = box_off ? box_off[img] : 0, nb = box_off ? box_off[img + 1] - b0 : nb_shared;
+    const int64_t o0 = box_off ? b0 : (int64_t)img * nb_shared;
+    if ((int64_t)blockIdx.x * 256 >= nb || m == 0) return;
+    iou_match_pass2_body(gt + 4 * (size_t)g0, boxes + 4 * (size_t)b0, m, nb, miou + o0, best_bits + g0, t0, t1, l0, l1, l2,
+                         n_thr, lowq, mlabel + o0);
+}
+
+// D2 subsample_labels for a batch of label vectors without host round trips.  Element j of image i
+// carries a random key; the sample is the (at most) n_pos positives and n_neg negatives with the smallest keys --
+// the first entries of the permutation argsort(keys[candidates]) -- written in ascending key order.  One workgroup
+// per image ranks its candidates with an O(P^2) count over LDS (P <= 12 288: a few thousand proposals).
+constexpr int SAMPLE_MAXP = 12288;
+
+__global__ __launch_bounds__(256) void sample_by_keys_kernel(const int64_t* __restrict__ cls, const float* __restrict__ keys,
+                                                             const int32_t* __restrict__ off, int num_samples,
+                                                             int num_pos_max, int bg_label, int kf_stride, int kb_stride,
+                                                             int64_t* __restrict__ out_fg, int64_t* __restrict__ out_bg,
+                                                             int32_t* __restrict__ counts)
+{
+    extern __shared__ float skey[];                        // P keys, then P type bytes
+    __shared__ int scnt[2];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int p0 = off[img], P = off[img + 1] - p0;
+    unsigned char* stype = reinterpret_cast<unsigned char*>(skey + P);
+    if (tid < 2) scnt[tid] = 0;
+    __syncthreads();
+    int cf = 0, cb = 0;
+    for (int i = tid; i < P; i += 256) {
+        const int64_t c = cls[p0 + i];
+        const unsigned char t = (c == bg_label) ? 2 : ((c != -1) ? 1 : 0);
+        stype[i] = t;
+        skey[i] = keys[p0 + i];
+        cf += t == 1;
+        cb += t == 2;
+    }
+    atomicAdd(&scnt[0], cf);
+    atomicAdd(&scnt[1], cb);
+    __syncthreads();
+    const int n_f = min(scnt[0], num_pos_max);
+    const int n_b = min(scnt[1], num_samples - n_f);
+    if (tid == 0) { counts[2 * img] = n_f; counts[2 * img + 1] = n_b; }
+    for (int i = tid; i < P; i += 256) {
+        const unsigned char t = stype[i];
+        if (t == 0) continue;
+        const float k = skey[i];
+        int rank = 0;
+        for (int j = 0; j < P; ++j) rank += (stype[j] == t) && (skey[j] < k || (skey[j] == k && j < i));
+        if (t == 1) { if (rank < n_f) out_fg[(size_t)img * kf_stride + rank] = i; }
+        else if (rank < n_b) out_bg[(size_t)img * kb_stride + rank] = i;
+    }
 }
 
 __global__ void fill_nomatch_kernel(int64_t* __restrict__ midx, int8_t* __restrict__ mlabel, float* __restrict__ miou,
@@ -346,6 +446,50 @@ int ptmi_iou_match(const float* gt, const float* boxes, int m, int64_t nb, const
                        reinterpret_cast<const int*>(ws), t0, t1, labels[0], labels[1], n_thr == 2 ? labels[2] : 0,
                        n_thr, allow_low_quality, matched_label);
     PTMI_LAUNCH_CHECK("iou_match_pass2");
+    return 0;
+}
+
+int ptmi_iou_match_batched(const float* gt_all, const int32_t* gt_off, const float* boxes, const int32_t* box_off,
+                           int nimg, int64_t max_boxes, int64_t total_gt, const float* thresholds_host,
+                           const int* labels_host, int n_thr, int allow_low_quality, int64_t* matched_idx,
+                           int8_t* matched_label, float* matched_iou, float* ws, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(gt_off && boxes && thresholds_host && labels_host && matched_idx && matched_label && matched_iou &&
+                       nimg > 0 && max_boxes >= 0 && total_gt >= 0,
+                   "iou_match_batched: bad args");
+    PTMI_CHECK_ARG(n_thr == 1 || n_thr == 2, "iou_match_batched: n_thr must be 1 or 2");
+    PTMI_CHECK_ARG(total_gt == 0 || (gt_all && ws), "iou_match_batched: gt/ws missing");
+    if (max_boxes == 0) return 0;
+    hipStream_t st = (hipStream_t)s;
+    if (total_gt > 0) {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(float) * (size_t)total_gt, st);   // bits of +0.0f
+        if (e != hipSuccess) { ptmi_set_error("iou_match_batched: memset failed"); return -2; }
+    }
+    const dim3 grid((unsigned)((max_boxes + 255) / 256), (unsigned)nimg);
+    hipLaunchKernelGGL(iou_match_pass1_batched, grid, dim3(256), 0, st, gt_all, gt_off, boxes, box_off, max_boxes,
+                       matched_idx, matched_iou, matched_label, reinterpret_cast<int*>(ws), labels_host[0]);
+    PTMI_LAUNCH_CHECK("iou_match_pass1_batched");
+    const float t0 = thresholds_host[0], t1 = n_thr == 2 ? thresholds_host[1] : 0.f;
+    hipLaunchKernelGGL(iou_match_pass2_batched, grid, dim3(256), 0, st, gt_all, gt_off, boxes, box_off, max_boxes,
+                       matched_iou, reinterpret_cast<const int*>(ws), t0, t1, labels_host[0], labels_host[1],
+                       n_thr == 2 ? labels_host[2] : 0, n_thr, allow_low_quality, matched_label);
+    PTMI_LAUNCH_CHECK("iou_match_pass2_batched");
+    return 0;
+}
+
+int ptmi_sample_by_keys(const int64_t* cls_all, const float* keys_all, const int32_t* offsets, int nimg,
+                        int64_t max_count, int num_samples, int num_pos_max, int bg_label, int64_t* out_fg,
+                        int64_t* out_bg, int32_t* counts, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(cls_all && keys_all && offsets && out_fg && out_bg && counts && nimg > 0 && num_samples > 0 &&
+                       num_pos_max >= 0 && num_pos_max <= num_samples,
+                   "sample_by_keys: bad args");
+    PTMI_CHECK_ARG(max_count >= 0 && max_count <= SAMPLE_MAXP, "sample_by_keys: %lld candidates per image exceed %d",
+                   (long long)max_count, SAMPLE_MAXP);
+    const int kf = num_pos_max > 0 ? num_pos_max : 1;
+    hipLaunchKernelGGL(sample_by_keys_kernel, dim3(nimg), dim3(256), (size_t)max_count * 5 + 16, (hipStream_t)s, cls_all,
+                       keys_all, offsets, num_samples, num_pos_max, bg_label, kf, num_samples, out_fg, out_bg, counts);
+    PTMI_LAUNCH_CHECK("sample_by_keys");
     return 0;
 }
 

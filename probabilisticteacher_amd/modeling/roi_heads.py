@@ -244,68 +244,122 @@ class GuassianROIHead(nn.Module):
         roi_heads.py:257-291 for the unsupervised branch."""
         K = self.num_classes
         out = []
+        dev = proposals[0].proposal_boxes.tensor.device
+        n = len(proposals)
         if branch == "unsupervised":
-            # matched-label-1 proposals only (roi_heads.py:257-291); one count read + one nonzero for the whole batch
-            # instead of a host sync per image
-            ms, offs, o = [], [], 0
-            for prop, tgt in zip(proposals, targets):
-                midx, mlab, _ = ops.iou_match(tgt.pseudo_boxes.tensor, prop.proposal_boxes.tensor, self.iou_thresholds,
-                                              self.iou_labels, False)
-                ms.append((midx, mlab))
-                offs.append(o)
-                o += len(prop.proposal_boxes)
-            hit = torch.cat([m[1] for m in ms]) == 1
-            counts = torch.stack([(m[1] == 1).sum() for m in ms]).cpu().tolist()
+            # matched-label-1 proposals only (roi_heads.py:257-291): one IoU-match launch pair, one count read and one
+            # nonzero for the whole batch instead of a kernel chain + host sync per image
+            pcounts = [len(p.proposal_boxes) for p in proposals]
+            gcounts = [len(t.pseudo_boxes) for t in targets]
+            pb_all = torch.cat([t.pseudo_boxes.tensor for t in targets], 0)
+            boxes_all = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
+            midx, mlab, _, gt_off, box_off = ops.iou_match_batched(pb_all, gcounts, boxes_all, pcounts, self.iou_thresholds,
+                                                                   self.iou_labels, False)
+            hit = mlab == 1
+            img_of = torch.repeat_interleave(torch.arange(n, device=dev), box_off[1:] - box_off[:-1],
+                                             output_size=boxes_all.shape[0])
+            counts = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, img_of, hit.long()).cpu().tolist()
             flat = torch.nonzero(hit).squeeze(1)
+            glob = midx[flat] + gt_off[img_of[flat]].long()                 # rows of the concatenated pseudo labels
+            sel_boxes = boxes_all[flat]
+            has_sigma = targets[0].has("boxes_sigma")
+            if pb_all.shape[0] > 0:
+                sel_pb = pb_all[glob]
+                sel_soft = torch.cat([t.scores_logists for t in targets], 0)[glob]
+                sel_sig = torch.cat([t.boxes_sigma for t in targets], 0)[glob] if has_sigma else None
             c0 = 0
-            for (midx, _), prop, tgt, off, cnt in zip(ms, proposals, targets, offs, counts):
-                sel = flat[c0:c0 + cnt] - off
-                c0 += cnt
-                pb = tgt.pseudo_boxes.tensor
+            for prop, tgt, cnt, gc in zip(proposals, targets, counts, gcounts):
                 r = FreeInstances(prop.image_size)
-                r.proposal_boxes = Boxes(prop.proposal_boxes.tensor[sel])
-                if pb.shape[0] == 0:
+                r.proposal_boxes = Boxes(sel_boxes[c0:c0 + cnt])
+                if gc == 0:
                     r.pseudo_boxes, r.soft_label = tgt.pseudo_boxes, tgt.scores_logists
-                    if tgt.has("boxes_sigma"):
+                    if has_sigma:
                         r.boxes_sigma = tgt.boxes_sigma
                 else:
-                    m = midx[sel]
-                    r.pseudo_boxes, r.soft_label = Boxes(pb[m]), tgt.scores_logists[m]
-                    if tgt.has("boxes_sigma"):
-                        r.boxes_sigma = tgt.boxes_sigma[m]
+                    r.pseudo_boxes, r.soft_label = Boxes(sel_pb[c0:c0 + cnt]), sel_soft[c0:c0 + cnt]
+                    if has_sigma:
+                        r.boxes_sigma = sel_sig[c0:c0 + cnt]
+                c0 += cnt
                 out.append(r)
             return out
-        legacy = sampling.legacy_path()                # parity tests that inject the reference's permutations
-        pend = []
-        for prop, tgt in zip(proposals, targets):
-            gtb = tgt.gt_boxes.tensor
-            boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
-            if self.proposal_append_gt:
-                boxes = torch.cat([boxes, gtb], 0)
-                logits = torch.cat([logits, GT_LOGIT * torch.ones(len(gtb), device=boxes.device)], 0)
-            midx, mlab, _ = ops.iou_match(gtb, boxes.contiguous(), self.iou_thresholds, self.iou_labels, False)
-            if tgt.gt_classes.numel() > 0:
-                cls = tgt.gt_classes[midx]
-                cls = torch.where(mlab == 0, torch.full_like(cls, K), cls)
-                cls = torch.where(mlab == -1, torch.full_like(cls, -1), cls)
-            else:
-                cls = torch.zeros_like(midx) + K
-            if legacy:
+        if sampling.legacy_path():                     # parity tests that inject the reference's permutations
+            for prop, tgt in zip(proposals, targets):
+                gtb = tgt.gt_boxes.tensor
+                boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
+                if self.proposal_append_gt:
+                    boxes = torch.cat([boxes, gtb], 0)
+                    logits = torch.cat([logits, GT_LOGIT * torch.ones(len(gtb), device=boxes.device)], 0)
+                midx, mlab, _ = ops.iou_match(gtb, boxes.contiguous(), self.iou_thresholds, self.iou_labels, False)
+                if tgt.gt_classes.numel() > 0:
+                    cls = tgt.gt_classes[midx]
+                    cls = torch.where(mlab == 0, torch.full_like(cls, K), cls)
+                    cls = torch.where(mlab == -1, torch.full_like(cls, -1), cls)
+                else:
+                    cls = torch.zeros_like(midx) + K
                 fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, K)
-                pend.append((prop, gtb, boxes, logits, midx, cls, torch.cat([fg, bg], 0)))
-            else:
-                pend.append((prop, gtb, boxes, logits, midx, cls) +
-                            sampling.keyed_sample(cls, self.batch_size_per_image, self.positive_fraction, K))
-        if not legacy:
-            # ONE device->host read for the sample sizes of the whole batch
-            cnt = torch.stack([torch.stack((p[7], p[9])) for p in pend]).cpu().tolist()
-            pend = [p[:6] + (torch.cat([p[6][:nf], p[8][:nb]], 0),) for p, (nf, nb) in zip(pend, cnt)]
-        for prop, gtb, boxes, logits, midx, cls, sel in pend:
+                sel = torch.cat([fg, bg], 0)
+                r = FreeInstances(prop.image_size)
+                r.proposal_boxes = Boxes(boxes[sel])
+                r.objectness_logits = logits[sel]
+                r.gt_classes = cls[sel]
+                r.gt_boxes = Boxes(gtb[midx[sel]]) if len(gtb) > 0 else Boxes(gtb.new_zeros((len(sel), 4)))
+                out.append(r)
+            return out
+        # ---- production path: the whole batch at once.  Proposals (+ appended ground truth) of all images are
+        # concatenated; labels come from one batched IoU match, the 512-per-image sample from one sampling launch
+        # (random keys, see sampling.py); ONE device->host read (the sample sizes) for the batch.
+        gcounts = [len(t.gt_boxes) for t in targets]
+        gt_all = torch.cat([t.gt_boxes.tensor for t in targets], 0)
+        total_gt = gt_all.shape[0]
+        parts_b, parts_l, bcounts = [], [], []
+        gt_logit = torch.full((total_gt,), GT_LOGIT, device=dev)
+        g0 = 0
+        for prop, tgt, gc in zip(proposals, targets, gcounts):
+            parts_b.append(prop.proposal_boxes.tensor)
+            parts_l.append(prop.objectness_logits)
+            cnt = len(prop.proposal_boxes)
+            if self.proposal_append_gt:
+                parts_b.append(tgt.gt_boxes.tensor)
+                parts_l.append(gt_logit[g0:g0 + gc])
+                cnt += gc
+            g0 += gc
+            bcounts.append(cnt)
+        boxes_all = torch.cat(parts_b, 0)
+        logits_all = torch.cat(parts_l, 0)
+        midx, mlab, _, gt_off, box_off = ops.iou_match_batched(gt_all, gcounts, boxes_all, bcounts, self.iou_thresholds,
+                                                               self.iou_labels, False)
+        total = boxes_all.shape[0]
+        img_of = torch.repeat_interleave(torch.arange(n, device=dev), box_off[1:] - box_off[:-1], output_size=total)
+        if total_gt > 0:
+            gidx = (midx + gt_off[img_of].long()).clamp_(max=total_gt - 1)          # images without gt: masked below
+            cls = torch.cat([t.gt_classes for t in targets], 0)[gidx]
+            cls = torch.where(mlab == 0, torch.full_like(cls, K), cls)              # also covers images without gt
+            cls = torch.where(mlab == -1, torch.full_like(cls, -1), cls)
+        else:
+            gidx = None
+            cls = torch.full((total,), K, dtype=torch.int64, device=dev)
+        keys = sampling.segment_keys(bcounts, dev)
+        npos = int(self.batch_size_per_image * self.positive_fraction)
+        fg, bg, cnt = ops.sample_by_keys(cls, keys, box_off, max(bcounts), self.batch_size_per_image, npos, K)
+        cnt_h = cnt.cpu().tolist()                                                   # the one sync
+        fg = fg + box_off[:-1].long().unsqueeze(1)
+        bg = bg + box_off[:-1].long().unsqueeze(1)
+        sel = torch.cat([t for i, (nf, nb) in enumerate(cnt_h) for t in (fg[i, :nf], bg[i, :nb])], 0)
+        sel_boxes, sel_logits, sel_cls = boxes_all[sel], logits_all[sel], cls[sel]
+        if total_gt > 0:
+            has_gt = torch.tensor([float(gc > 0) for gc in gcounts]).pin_memory().to(dev, non_blocking=True)
+            sel_gt = gt_all[gidx[sel]] * has_gt[img_of[sel]].unsqueeze(1)            # zeros for images without gt
+        else:
+            sel_gt = boxes_all.new_zeros((sel.shape[0], 4))
+        c0 = 0
+        for prop, (nf, nb) in zip(proposals, cnt_h):
+            k = nf + nb
             r = FreeInstances(prop.image_size)
-            r.proposal_boxes = Boxes(boxes[sel])
-            r.objectness_logits = logits[sel]
-            r.gt_classes = cls[sel]
-            r.gt_boxes = Boxes(gtb[midx[sel]]) if len(gtb) > 0 else Boxes(gtb.new_zeros((len(sel), 4)))
+            r.proposal_boxes = Boxes(sel_boxes[c0:c0 + k])
+            r.objectness_logits = sel_logits[c0:c0 + k]
+            r.gt_classes = sel_cls[c0:c0 + k]
+            r.gt_boxes = Boxes(sel_gt[c0:c0 + k])
+            c0 += k
             out.append(r)
         return out
 

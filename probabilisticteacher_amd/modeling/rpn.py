@@ -160,24 +160,32 @@ class GuassianRPN(nn.Module):
     def _losses_sup(self, anchors, logits, d8, gt_instances):
         n, r = logits.shape
         anc = anchors.detach()
-        labels, matched = [], []
         with torch.no_grad():
-            legacy = sampling.legacy_path()            # parity tests that inject the reference's permutations
-            for inst in gt_instances:
-                gt = inst.gt_boxes.tensor
-                midx, lab, _ = ops.iou_match(gt, anc, self.iou_thresholds, self.iou_labels, True)
-                if legacy:
+            if sampling.legacy_path():                 # parity tests that inject the reference's permutations
+                labels, matched = [], []
+                for inst in gt_instances:
+                    gt = inst.gt_boxes.tensor
+                    midx, lab, _ = ops.iou_match(gt, anc, self.iou_thresholds, self.iou_labels, True)
                     pos, neg = subsample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0)
                     lab.fill_(-1)
                     lab[pos] = 1
                     lab[neg] = 0
-                labels.append(lab)
-                matched.append(torch.zeros_like(anc) if len(gt) == 0 else gt[midx])
-            lab_all = torch.stack(labels)                              # (N,R) int8
-            if not legacy:                                             # whole batch, no per-image host syncs
+                    labels.append(lab)
+                    matched.append(torch.zeros_like(anc) if len(gt) == 0 else gt[midx])
+                lab_all = torch.stack(labels)                          # (N,R) int8
+                flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
+                gt_rows = torch.stack(matched).view(-1, 4)[flat_pos]
+            else:
+                # whole batch: one IoU-match launch pair, one sync-free relabel, one nonzero
+                counts = [len(inst.gt_boxes) for inst in gt_instances]
+                gt_all = torch.cat([inst.gt_boxes.tensor for inst in gt_instances], 0)
+                midx, lab_all, _, gt_off, _ = ops.iou_match_batched(gt_all, counts, anc, None, self.iou_thresholds,
+                                                                    self.iou_labels, True)
                 lab_all = sampling.keyed_relabel(lab_all, self.batch_size_per_image, self.positive_fraction, 0)
-            flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
-            gt_rows = torch.stack(matched).view(-1, 4)[flat_pos]
+                flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
+                img = torch.div(flat_pos, r, rounding_mode="floor")
+                # (positives only exist for images with ground truth, so the gather index is always in range)
+                gt_rows = gt_all[midx.view(-1)[flat_pos] + gt_off[img].long()]
         inv = 1.0 / (self.batch_size_per_image * n)
         loss_cls = ops.bce_logits_sum(logits.contiguous(), lab_all, inv)
         d_rows = d8.reshape(-1, 8)[flat_pos]
@@ -195,20 +203,17 @@ class GuassianRPN(nn.Module):
         with torch.no_grad():
             # one IoU match per image (different pseudo-box counts), then ONE nonzero for the whole batch: the
             # positives of image i select rows of the concatenated pseudo-label tensors through per-image offsets
-            labs, midxs, offs, o = [], [], [], 0
-            for inst in pseudo:
-                midx, lab, _ = ops.iou_match(inst.pseudo_boxes.tensor, anc, self.iou_thresholds, self.iou_labels, True)
-                labs.append(lab)
-                midxs.append(midx)
-                offs.append(o)
-                o += len(inst.pseudo_boxes)
-            flat = torch.nonzero(torch.stack(labs).view(-1) == 1).squeeze(1)      # positives only, no subsampling
+            counts = [len(inst.pseudo_boxes) for inst in pseudo]
+            pb_all = torch.cat([inst.pseudo_boxes.tensor for inst in pseudo], 0)
+            midx, lab_all, _, gt_off, _ = ops.iou_match_batched(pb_all, counts, anc, None, self.iou_thresholds,
+                                                                self.iou_labels, True)
+            flat = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)                 # positives only, no subsampling
             img = torch.div(flat, r, rounding_mode="floor")
-            sel = torch.stack(midxs).view(-1)[flat] + torch.tensor(offs, device=flat.device)[img]
+            sel = midx.view(-1)[flat] + gt_off[img].long()
             all_logits = torch.cat([inst.scores_logists for inst in pseudo], 0)
             T = all_logits[sel].contiguous()
             sig_all = torch.cat([(inst.boxes_sigma if has_box else inst.scores_logists) for inst in pseudo], 0)[sel]
-            tgt_all = torch.cat([inst.pseudo_boxes.tensor for inst in pseudo], 0)[sel]
+            tgt_all = pb_all[sel]
         inv = 1.0 / (self.batch_size_per_image * n)
         x = logits.reshape(-1)[flat]
         loss_cls, fg = ops.rpn_soft_obj_loss(T, x, U.TAU[0], U.EFL_LAMBDA[0], bool(U.EFL), inv)

@@ -39,6 +39,14 @@ def _keys(shape, device) -> torch.Tensor:
     return torch.rand(shape, device=device)
 
 
+def segment_keys(sizes, device) -> torch.Tensor:
+    """One key per element of the concatenated label vectors; with an injected key source the keys are drawn image
+    by image (the order the oracle's KeyedPerm replays them)."""
+    if _KEY_FN is not None:
+        return torch.cat([_KEY_FN((int(n),)) for n in sizes]).to(device) if len(sizes) else torch.zeros(0, device=device)
+    return torch.rand(int(sum(sizes)), device=device)
+
+
 def keyed_topk(mask: torch.Tensor, keys: torch.Tensor, k: int):
     """The (at most k) candidates of `mask` with the smallest keys, along the last dim, in ascending key order:
     (indices (..., k'), valid (..., k') bool) with the valid entries first.  No host sync."""

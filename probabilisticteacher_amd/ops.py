@@ -500,6 +500,59 @@ def iou_match(gt: torch.Tensor, boxes: torch.Tensor, thresholds: Sequence[float]
     return midx, mlab, miou
 
 
+def dev_i32(values, device) -> torch.Tensor:
+    """Small host list -> int32 device tensor without a stream synchronisation (pinned staging, async copy)."""
+    return torch.tensor(values, dtype=torch.int32).pin_memory().to(device, non_blocking=True)
+
+
+def iou_match_batched(gt_all: torch.Tensor, gt_counts: Sequence[int], boxes: torch.Tensor, box_counts, thresholds,
+                      labels, allow_low_quality: bool):
+    """ptmi_iou_match for a whole batch in one launch per pass.  gt_all: the images' gt boxes concatenated
+    (gt_counts[i] rows each).  boxes: concatenated per image (box_counts[i] rows each) or, with box_counts=None, ONE
+    box set shared by all images (outputs (N, nb)).  Returns (matched_idx within the image, label int8, iou)."""
+    boxes = _chk(boxes.contiguous())
+    gt_all = _chk(gt_all.contiguous())
+    dev = boxes.device
+    n = len(gt_counts)
+    goff = [0]
+    for c in gt_counts:
+        goff.append(goff[-1] + int(c))
+    gt_off = dev_i32(goff, dev)
+    if box_counts is None:
+        nb, box_off, shape = boxes.shape[0], None, (n, boxes.shape[0])
+    else:
+        boff = [0]
+        for c in box_counts:
+            boff.append(boff[-1] + int(c))
+        nb, box_off, shape = max(box_counts) if len(box_counts) else 0, dev_i32(boff, dev), (boff[-1],)
+    midx = torch.empty(shape, dtype=torch.int64, device=dev)
+    mlab = torch.empty(shape, dtype=torch.int8, device=dev)
+    miou = torch.empty(shape, dtype=F32, device=dev)
+    ws = _ws("ioumb", max(goff[-1], 1) * 4, dev)
+    thr = (ctypes.c_float * len(thresholds))(*[float(t) for t in thresholds])
+    lab = (ctypes.c_int * len(labels))(*[int(l) for l in labels])
+    if midx.numel():
+        _lib.call("ptmi_iou_match_batched", _ptr(gt_all), _ptr(gt_off), _ptr(boxes), _ptr(box_off), n, nb, goff[-1], thr,
+                  lab, len(thresholds), int(allow_low_quality), _ptr(midx), _ptr(mlab), _ptr(miou), _ptr(ws), _stream())
+    return midx, mlab, miou, gt_off, box_off
+
+
+def sample_by_keys(cls_all: torch.Tensor, keys_all: torch.Tensor, offsets: torch.Tensor, max_count: int,
+                   num_samples: int, num_pos_max: int, bg_label: int):
+    """D2 subsample_labels for a batch without host syncs (ptmi_sample_by_keys): (fg (N,num_pos_max) int64, bg
+    (N,num_samples) int64, counts (N,2) int32); entries beyond the counts are unspecified."""
+    cls_all = _chk(cls_all.contiguous(), torch.int64)
+    keys_all = _chk(keys_all.contiguous())
+    n = offsets.numel() - 1
+    dev = cls_all.device
+    fg = torch.empty((n, max(num_pos_max, 1)), dtype=torch.int64, device=dev)
+    bg = torch.empty((n, num_samples), dtype=torch.int64, device=dev)
+    cnt = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    _lib.call("ptmi_sample_by_keys", _ptr(cls_all), _ptr(keys_all), _ptr(_chk(offsets, torch.int32)), n, int(max_count),
+              num_samples, num_pos_max, bg_label, _ptr(fg), _ptr(bg), _ptr(cnt), _stream())
+    return fg, bg, cnt
+
+
 # ============================================================================ sort / proposals / NMS
 def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Stable descending sort inside each segment.  Returns (sorted keys, index within segment int32)."""

@@ -560,3 +560,57 @@ def test_conv3x3_random_shapes(ops):
         close(xd.grad, xr.grad, 1e-4, 2e-4, "dgrad " + tag)
         close(wd.grad, wr.grad, 1e-4, 1e-3, "wgrad " + tag)
         close(bd.grad, br.grad, 1e-4, 1e-3, "bias grad " + tag)
+
+
+# ------------------------------------------------------------------------------------------ batched matching / sampling
+def test_iou_match_batched_equals_per_image(ops):
+    """ptmi_iou_match_batched (one launch pair per batch) against ptmi_iou_match image by image: indices, labels and
+    IoU values bit for bit, with per-image box sets, a shared box set (RPN anchors) and images without ground truth."""
+    gen = g(77)
+    n = 4
+    gts = [_rand_boxes(gen, m, 300, 400) for m in (5, 0, 1, 17)]
+    props = [_rand_boxes(gen, p, 300, 400) for p in (700, 33, 0, 1200)]
+    gt_all = torch.cat(gts).to(DEV)
+    boxes_all = torch.cat(props).to(DEV)
+    for lowq, thr, labs in ((False, (0.5,), (0, 1)), (True, (0.3, 0.7), (0, -1, 1))):
+        midx, mlab, miou, _, _ = ops.iou_match_batched(gt_all, [len(x) for x in gts], boxes_all, [len(x) for x in props],
+                                                       thr, labs, lowq)
+        o = 0
+        for gt, pb in zip(gts, props):
+            if len(pb):
+                ri, rl, ru = ops.iou_match(gt.to(DEV), pb.to(DEV), thr, labs, lowq)
+                assert torch.equal(midx[o:o + len(pb)], ri) and torch.equal(mlab[o:o + len(pb)], rl)
+                assert torch.equal(miou[o:o + len(pb)], ru)
+            o += len(pb)
+        anchors = _rand_boxes(gen, 3000, 300, 400).to(DEV)
+        midx, mlab, miou, _, _ = ops.iou_match_batched(gt_all, [len(x) for x in gts], anchors, None, thr, labs, lowq)
+        assert midx.shape == (n, 3000)
+        for i, gt in enumerate(gts):
+            ri, rl, ru = ops.iou_match(gt.to(DEV), anchors, thr, labs, lowq)
+            assert torch.equal(midx[i], ri) and torch.equal(mlab[i], rl) and torch.equal(miou[i], ru)
+
+
+def test_sample_by_keys_equals_reference_subsample_labels(ops):
+    """ptmi_sample_by_keys against D2's subsample_labels driven by the same keys (oracle KeyedPerm): sample sizes, members
+    and order, for images with many / few / no foreground candidates and fewer background candidates than requested."""
+    gen = g(78)
+    K = 8
+    sizes, n_fgs = (2007, 640, 100, 1), (300, 12, 0, 1)
+    cls_list = []
+    for p_count, n_fg in zip(sizes, n_fgs):
+        cls = torch.full((p_count,), K, dtype=torch.int64)
+        cls[torch.randperm(p_count, generator=gen)[:n_fg]] = torch.randint(0, K, (n_fg,), generator=gen)
+        cls[torch.randperm(p_count, generator=gen)[:p_count // 10]] = -1
+        cls_list.append(cls)
+    kp = opt.KeyedPerm(9)
+    keys = torch.cat([kp.draw((s,)) for s in sizes])
+    keys[5] = keys[9]                                        # a tie: broken by index, like a stable argsort
+    kp.pending[0][5] = kp.pending[0][9]
+    off = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32, device=DEV)
+    fg, bg, cnt = ops.sample_by_keys(torch.cat(cls_list).to(DEV), keys.to(DEV), off, max(sizes), 512, 128, K)
+    cnt = cnt.cpu().tolist()
+    kp.start_replay()
+    for i, cls in enumerate(cls_list):
+        rf, rb = d2.subsample_labels(cls, 512, 0.25, K, kp)
+        assert cnt[i] == [len(rf), len(rb)], (i, cnt[i], len(rf), len(rb))
+        assert torch.equal(fg[i, :cnt[i][0]].cpu(), rf) and torch.equal(bg[i, :cnt[i][1]].cpu(), rb), i
