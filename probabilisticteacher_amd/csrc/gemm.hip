@@ -231,7 +231,7 @@ struct OpTile {
             const float* p = T + (r0 + (lane & 31)) * Cfg::KF_PITCH + (lane >> 5) * Cfg::HK;
 #pragma unroll
             for (int t = 0; t < Cfg::HK / 4; ++t) {
-                const f32x4 v = *(const volatile ptmi_lds_f32x4_t*)(p + 4 * t);
+                const f32x4 v = *(const ptmi_lds_f32x4_t*)(p + 4 * t);
                 f[4 * t] = v[0]; f[4 * t + 1] = v[1]; f[4 * t + 2] = v[2]; f[4 * t + 3] = v[3];
             }
         } else {
