@@ -120,10 +120,11 @@ int64_t ptmi_nms_ws_bytes(int64_t max_count, int nimg)
 int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, int nimg, int64_t max_count, float thr,
                      int max_keep, int32_t* keep_out, int32_t* keep_count, void* ws, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(boxes && seg_offsets && keep_out && keep_count && ws && nimg > 0 && max_count >= 0 && max_keep > 0,
+    PTMI_CHECK_ARG(seg_offsets && keep_out && keep_count && nimg > 0 && max_count >= 0 && max_keep > 0,
                    "nms_batched: bad args");
+    PTMI_CHECK_ARG(max_count == 0 || (boxes && ws), "nms_batched: boxes / workspace missing");
     hipStream_t st = (hipStream_t)s;
-    if (max_count == 0) {
+    if (max_count == 0) {        // no candidate in any image (boxes and ws may be null)
         hipError_t e = hipMemsetAsync(keep_count, 0, sizeof(int32_t) * (size_t)nimg, st);
         if (e != hipSuccess) { ptmi_set_error("nms_batched: memset failed"); return -2; }
         return 0;

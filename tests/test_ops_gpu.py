@@ -301,6 +301,13 @@ def test_nms_bit_exact(ops, counts, thr, max_keep):
         assert torch.equal(keep[i, :k].cpu().long(), ref), f"image {i}: keep lists differ"
 
 
+def test_nms_no_candidates_at_all(ops):
+    """every image of the batch has zero candidates (a teacher without any detection above the score threshold)"""
+    seg = torch.zeros(4, dtype=torch.int32, device=DEV)
+    keep, cnt = ops.nms_batched(torch.zeros((0, 4), device=DEV), seg, 0, 0.5, 100)
+    assert keep.shape == (3, 100) and cnt.cpu().tolist() == [0, 0, 0]
+
+
 def test_nms_matches_bruteforce_small(ops):
     gen = g(3)
     b = _rand_boxes(gen, 200, 100, 100, lo=5.0)
