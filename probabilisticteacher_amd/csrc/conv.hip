@@ -558,6 +558,54 @@ __global__ __launch_bounds__(256, 3) void conv3x3_direct_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------ stem (Cin <= 4), VALU
+// The 3-channel stem has K = 27: 3.7 GF per image against 273 MB of output -- an HBM-write-bound layer whose MFMA
+// formulations (above) spend their time in per-workgroup latency chains (2.3 ms per 16 images = 1.9 TB/s of stores).
+// Here a thread owns ONE pixel and all 64 channels of a channel tile: it gathers its 3x3xCin inputs once, the weights of
+// a (tap, channel) pair are 64 consecutive floats of the packed slab and arrive through the scalar cache (wave-uniform
+// address), and every store instruction writes 64 consecutive pixels of one channel plane (256 B).  64 accumulator
+// VGPRs, no LDS, no barrier, eight waves per SIMD.
+__global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int Cin,
+                                                           int Cout, int H, int W, int coTiles, int relu)
+{
+    constexpr int BM = 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int px = blockIdx.x * 64 + lane, py = blockIdx.y * 4 + wave, n = blockIdx.z;
+    const int HW = H * W;
+    const bool inside = px < W && py < H;
+    const float* xn = x + (size_t)n * Cin * HW;
+    float v[36];                                           // [tap][ci] with ci padded to 4
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int gy = py + tap / 3 - 1, gx = px + tap % 3 - 1;
+        const bool ok = inside && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) v[tap * 4 + ci] = (ok && ci < Cin) ? xn[(size_t)ci * HW + (size_t)gy * W + gx] : 0.f;
+    }
+    float* yn = y + (size_t)n * Cout * HW + (size_t)py * W + px;
+    for (int cot = 0; cot < coTiles; ++cot) {
+        const float* wt = wp + (size_t)cot * 9 * 4 * BM;   // packed [tap][ci][64 channels] (one 4-channel chunk)
+        const int co0 = cot * BM;
+        float acc[BM];
+#pragma unroll
+        for (int c = 0; c < BM; ++c) acc[c] = (co0 + c < Cout) ? bias[co0 + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 36; ++k) {
+            if ((k & 3) >= Cin) continue;                  // padded channel: the slab holds zeros there
+            const float* wr = wt + k * BM;
+#pragma unroll
+            for (int c = 0; c < BM; ++c) acc[c] = fmaf(wr[c], v[k], acc[c]);
+        }
+        if (inside) {
+#pragma unroll
+            for (int c = 0; c < BM; ++c) {
+                if (co0 + c < Cout) yn[(size_t)(co0 + c) * HW] = relu ? fmaxf(acc[c], 0.f) : acc[c];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ weight pack
 __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int wCout,
                                     int wCin, int mode, int BM, int CK, int coTiles, int nChunks)
@@ -1052,11 +1100,13 @@ int wgrad_edge_splits(int n, int cin, int cout, int h, int w)
     return S < 1 ? 1 : S;
 }
 
-bool stem_direct()
+// PTMI_CONV_STEM (A/B knob) for Cin <= 4: 2 = VALU pixel-per-thread kernel (default, Cout <= 64 tiles), 1 = LDS-free
+// MFMA kernel, 0 = the regular buffer-DMA kernel
+int stem_impl()
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("PTMI_CONV_STEM_DIRECT"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v != 0;
+    if (v < 0) { const char* e = getenv("PTMI_CONV_STEM"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
+    return v;
 }
 
 int wgrad_splits(int n, int cin, int cout, int h, int w)
@@ -1132,7 +1182,14 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     // register-streamed kernel: everywhere with PTMI_CONV_IMPL=3 (A/B experiments: slower than the buffer-DMA pipeline on the big
     // layers, 66-80 vs 115-131 TF/s) and by default for the 3-channel stem, whose K = 36 loop is too short to
     // amortise the LDS pipeline's prologue (25 vs 18 TF/s; that layer is HBM-write bound)
-    if (CK == 4 && (conv_impl() == 3 || (conv_impl() == 4 && cin <= 4 && stem_direct())) && epilogue != 4) {
+    if (CK == 4 && BM == 64 && conv_impl() == 4 && cin <= 4 && stem_impl() == 2 && epilogue <= 1) {
+        // (-ffp-contract=off: fmaf() is explicit in the kernel; K = 27 keeps the rounding difference at the 1e-7 level)
+        hipLaunchKernelGGL(conv3x3_stem_kernel, dim3((unsigned)cdiv(w, 64), (unsigned)cdiv(h, 4), (unsigned)n), dim3(256), 0,
+                           st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
+        PTMI_LAUNCH_CHECK("conv3x3_fwd(stem)");
+        return 0;
+    }
+    if (CK == 4 && (conv_impl() == 3 || (conv_impl() == 4 && cin <= 4 && stem_impl() >= 1)) && epilogue != 4) {
         const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
         if (BM == 128)
             hipLaunchKernelGGL((conv3x3_direct_kernel<128>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
