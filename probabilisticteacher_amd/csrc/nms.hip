@@ -66,10 +66,14 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
     __syncthreads();
     int count = 0;
     const int chunks = (n + 63) / 64;
+    u64 diag_next = (lane < n) ? M[(size_t)lane * words] : 0;          // diagonal block of chunk 0
     for (int c = 0; c < chunks && count < max_keep; ++c) {
         const int row = c * 64 + lane;
-        u64 diag = 0;
-        if (row < n) diag = M[(size_t)row * words + c];
+        const u64 diag = diag_next;
+        if (c + 1 < chunks) {                                           // prefetch the next diagonal block: its load
+            const int rn = row + 64;                                    // latency hides behind this chunk's resolve
+            diag_next = (rn < n) ? M[(size_t)rn * words + c + 1] : 0;
+        }
         u64 cur = removed[c];
         if (c == chunks - 1 && (n & 63)) cur |= ~0ull << (n & 63);   // rows past n do not exist
         // resolve the 64x64 diagonal block in order (wave-uniform)
@@ -91,14 +95,21 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
         }
         count += nk;
         if (count >= max_keep) break;
-        // fold the kept rows into the remaining words (lanes stride over words; loads coalesced)
+        // fold the kept rows into the remaining words (lanes stride over words; loads coalesced).  The rows are
+        // visited eight at a time with the loads of a group issued together (zero row index 0 stands in for rows that
+        // were not kept: OR-ing a row twice is harmless, OR-ing an unkept row is not, hence the mask).
         for (int w = c + 1 + lane; w < chunks; w += 64) {
             u64 acc = removed[w];
-            u64 kb = kept;
-            while (kb) {
-                const int i = __ffsll((long long)kb) - 1;
-                kb &= kb - 1;
-                acc |= M[(size_t)(c * 64 + i) * words + w];
+            const u64* Mw = M + (size_t)c * 64 * words + w;
+#pragma unroll 1
+            for (int i0 = 0; i0 < 64; i0 += 8) {
+                const unsigned kb = (unsigned)(kept >> i0) & 0xFFu;
+                if (!kb) continue;
+                u64 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? Mw[(size_t)(i0 + j) * words] : 0ull;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc |= v[j];
             }
             removed[w] = acc;
         }
