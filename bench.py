@@ -51,12 +51,12 @@ def synth_records(gen, n, h, w, K, dev, m=12, labelled=True):
     return recs
 
 
-def cpu_baseline(h, w, K, seed=0):
+def cpu_baseline(h, w, K, seed=0, student_only=False):
     """The CPU oracle (oracle/pt.py, a port of the reference's algorithm on stock torch CPU fp32 ops) timed on this
     box's host cores: ONE full mutual-learning step with 1 labelled + 1 unlabelled image (bounded sample)."""
     from oracle import d2, pt as opt
     torch.set_num_threads(min(os.cpu_count() or 1, 32))      # oneDNN scales poorly past ~32 threads at batch 1
-    cfg = opt.Cfg(num_classes=K, burn_up_step=0)
+    cfg = opt.Cfg(num_classes=K, burn_up_step=10 ** 9 if student_only else 0)
     gen = torch.Generator().manual_seed(seed)
     state = {"student": opt.init_params(cfg, 0), "teacher": opt.init_params(cfg, 0), "bufs": {}, "iter": 0}
 
@@ -70,11 +70,13 @@ def cpu_baseline(h, w, K, seed=0):
         return [r]
     data = (recs(), recs(), recs(), recs())
     t0 = time.perf_counter()
-    opt.run_step(cfg, state, data, {"label": [0.8], "unlabel": [0.7]}, perm_fn=opt.SeededPerm(1))
+    opt.run_step(cfg, state, data, {"label": [0.8, 0.75], "unlabel": [0.7]}, perm_fn=opt.SeededPerm(1))
     dt = time.perf_counter() - t0
     return {"value": 2.0 / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 full teacher+student step (EMA, teacher fwd, 3 student fwd, 3 bwd, clip+SGD) with 1 labelled + "
-                      f"1 unlabelled {w}x{h} image, {dt:.1f} s"}
+            "sample": (f"1 supervised student step (2 fwd, 2 bwd, clip+SGD) on the strong + weak view of 1 labelled {w}x{h} "
+                       f"image, {dt:.1f} s" if student_only else
+                       f"1 full teacher+student step (EMA, teacher fwd, 3 student fwd, 3 bwd, clip+SGD) with 1 labelled + "
+                       f"1 unlabelled {w}x{h} image, {dt:.1f} s")}
 
 
 def pmc_traffic():
@@ -102,6 +104,9 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--student-only", action="store_true",
+                    help="BASELINE configs[1]: supervised student fwd/bwd only (burn-in step) on 2 x per-gpu-batch images; "
+                         "use --per-gpu-batch 4 for the quoted batch of 8")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -122,7 +127,8 @@ def main():
 
     B = args.per_gpu_batch
     cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), [
-        "MODEL.DEVICE", f"cuda:{local_rank}", "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", 0,
+        "MODEL.DEVICE", f"cuda:{local_rank}", "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP",
+        10 ** 9 if args.student_only else 0,
         "SOLVER.IMG_PER_BATCH_LABEL", B * world, "SOLVER.IMG_PER_BATCH_UNLABEL", B * world])
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     torch.manual_seed(0)                                                # identical init on all ranks
@@ -172,15 +178,19 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = world * 2 * B * args.steps / dt
+        value = world * 2 * B * args.steps / dt             # burn-in step: label_q + label_k = 2B images as well
         conv = prof.get("conv3x3_mfma", {"ms": 0.0, "flops": 0.0, "calls": 0})
         ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         out = {
-            "metric": "teacher-student train-step img/s at 1333x800", "value": value, "unit": "img/s",
+            "metric": ("student-only train-step img/s at 1333x800" if args.student_only else
+                       "teacher-student train-step img/s at 1333x800"), "value": value, "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: final_c2f.yaml (K=8) full teacher+student+EMA step, per-GPU "
-                                   f"{B} labelled + {B} unlabelled synthetic {W}x{H} images, BURN_UP_STEP=0, random init",
+            "config": {"workload": (f"BASELINE configs[1]: final_c2f.yaml (K=8) student-only supervised fwd/bwd + clip + SGD, "
+                                    f"per-GPU {2 * B} synthetic {W}x{H} images (strong + weak view of {B} labelled), random init"
+                                    if args.student_only else
+                                    f"BASELINE configs[2]: final_c2f.yaml (K=8) full teacher+student+EMA step, per-GPU "
+                                    f"{B} labelled + {B} unlabelled synthetic {W}x{H} images, BURN_UP_STEP=0, random init"),
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
@@ -191,11 +201,12 @@ def main():
             "kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12)
                             if v["ms"] > 0 and v["flops"] else None, "calls_per_step": v["calls"] / args.steps}
                         for k, v in prof.items()},
-            "step_conv_tflops": 2.696 * 2 * B * world * args.steps / dt if (H, W) == (800, 1333) else None,
+            "step_conv_tflops": ((0.67106 + 0.90253) if args.student_only else 2.696) * 2 * B * world * args.steps / dt
+            if (H, W) == (800, 1333) else None,
             "losses": {k: v for k, v in trainer.last_metrics.items() if k.startswith("loss")},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(H, W, K)
+            out["cpu_baseline"] = cpu_baseline(H, W, K, student_only=args.student_only)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
