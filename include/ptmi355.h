@@ -35,7 +35,7 @@ int ptmi_abi_version(void);
  * and the D2 StandardRPNHead 3x3 conv at pt/modeling/proposal_generator/rpn.py:96.
  * fp32 implicit GEMM on v_mfma_f32_32x32x2_f32.
  *
- * Packed weight layout (built by ptmi_conv3x3_pack_weights; followed by a 64-float zero page): for BM = ptmi_conv3x3_bm(Cout),
+ * Packed weight layout (built by ptmi_conv3x3_pack_weights): for BM = ptmi_conv3x3_bm(Cout),
  * CK = ptmi_conv3x3_ck(Cin):  [ceil(Cout/BM)][ceil(Cin/CK)][9 taps][CK][BM] fp32, zero padded.
  * mode 0 = forward weights  Wp[co][ci][ky][kx]            = W[co][ci][ky][kx]
  * mode 1 = dgrad weights    (roles of co/ci swapped)      = W[ci][co][2-ky][2-kx]

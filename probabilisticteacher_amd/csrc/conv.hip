@@ -6,21 +6,15 @@
 //
 // Design (MI355X-first, not a cuDNN translation):
 //   * implicit GEMM  M = Cout, N = output pixels, K = 9*Cin, NCHW fp32 end to end;
-//   * one 256-thread workgroup = 4 wave64s, each wave owns a 64(co) x 64(px = 2 rows x 32 cols)
-//     accumulator block = 2x2 MFMA 32x32 tiles (64 accumulator VGPRs);
-//   * K is walked in chunks of CK input channels: the (TH+2)x34 input halo patch of CK channels and
-//     the [9][CK][BM] weight slab go through LDS; fragment reads are plain ds_read_b32 with
-//     compile-time offsets -- lanes 0-31 walk 32 consecutive pixels (or 32 consecutive output
-//     channels) and lanes 32-63 the next input channel, which is exactly the f32 MFMA operand
-//     layout (A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) => bank-conflict free, no swizzle needed;
-//   * global->register prefetch of chunk c+1 is issued before the 144 MFMAs of chunk c; with
-//     ~43 KB LDS and <=128 VGPRs three workgroups share a CU so one wave per SIMD is always
-//     inside its MFMA block (the f32 MFMA pipe is saturated by a single wave: 64-cycle issue).
-//   * dgrad reuses the same kernel with flipped/transposed packed weights; the producer's ReLU
-//     mask can be applied in the epilogue (epilogue 3).
-//   * wgrad: M = Cout, N = Cin (x 9 taps as 9 accumulator tiles), K = pixels; split-K over pixel
-//     tiles with a fixed-order second-stage reduction (deterministic).
-#include <stdlib.h>
+//   * forward / dgrad: `conv3x3_buf_kernel` -- 4 or 8 wave64s per workgroup, each wave owns 64 channels x two
+//     4-row x 8-column pixel blocks (four 32x32 accumulator tiles = 64 VGPRs); K is walked in 4-channel chunks,
+//     operands go global -> LDS with `buffer_load_dwordx4 ... lds`, double buffered, one barrier per chunk;
+//   * dgrad reuses the same kernel with flipped/transposed packed weights; the producer's ReLU mask can be applied
+//     in the epilogue (epilogue 3); frozen blocks fuse bias + ReLU + 2x2 max pool (epilogue 4);
+//   * the 3-channel stem is a VALU pixel-per-thread kernel (HBM-write bound);
+//   * wgrad: `conv3x3_wgrad_buf_kernel` -- M = Cout, N = Cin (x 9 taps as 9 accumulator tiles), K = pixels; split-K
+//     over pixel tiles with a fixed-order second-stage reduction (deterministic).
+// Shapes whose per-image byte offsets do not fit 32 bits are rejected with an error (no fallback kernels).
 
 #include "common.h"
 #include <type_traits>
@@ -28,164 +22,9 @@
 namespace {
 
 constexpr int TW = 32;   // output pixels per MFMA column block
-constexpr int PW = 34;   // staged patch width (TW + 2 halo)
-
-template <int BM>
-struct FwdCfg {
-    static constexpr int TH = (BM == 128) ? 4 : 8;   // output rows per workgroup
-    static constexpr int PR = TH + 2;
-    static constexpr int PLANE = PR * PW;
-};
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// ------------------------------------------------------------------------------------ forward
-template <int BM, int CK>
-__global__ __launch_bounds__(256, 3) void conv3x3_mfma_kernel(
-    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
-    int tilesX, int tilesY, int coTiles, int nChunks, int epi)
-{
-    using C = FwdCfg<BM>;
-    constexpr int TH = C::TH, PLANE = C::PLANE;
-    constexpr int WS = 9 * CK * BM;          // weight slab floats
-    constexpr int PS = CK * PLANE;           // patch floats
-    constexpr int WS4 = WS / 4;
-    constexpr int NW4 = (WS4 + 255) / 256;
-    constexpr int NP = (PS + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float lds[WS + PS];
-    float* Ws = lds;
-    float* Ps = lds + WS;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int cot = bid % coTiles;
-    int pt = bid / coTiles;
-    const int tx = pt % tilesX;
-    pt /= tilesX;
-    const int ty = pt % tilesY;
-    const int n = pt / tilesY;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int HW = H * W;
-
-    // per-thread patch element offsets (relative to the chunk's first channel plane)
-    int poff[NP];
-    unsigned pvalid = 0;
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        const int idx = tid + i * 256;
-        poff[i] = 0;
-        if (idx < PS) {
-            const int ci = idx / PLANE, rem = idx - ci * PLANE;
-            const int r = rem / PW, c = rem - r * PW;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                poff[i] = ci * HW + gy * W + gx;
-                pvalid |= 1u << i;
-            }
-        }
-    }
-    const float* xn = x + (size_t)n * Cin * HW;
-    const float4* wbase = reinterpret_cast<const float4*>(wp) + (size_t)cot * nChunks * WS4;
-
-    float4 wreg[NW4];
-    float preg[NP];
-    auto gload = [&](int chunk) {
-        const float4* wsrc = wbase + (size_t)chunk * WS4;
-#pragma unroll
-        for (int i = 0; i < NW4; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < WS4) wreg[i] = wsrc[idx];
-        }
-        const int c0 = chunk * CK;
-        const float* xc = xn + (size_t)c0 * HW;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * 256;
-            float v = 0.f;
-            if (idx < PS && ((pvalid >> i) & 1u) && (c0 + idx / PLANE) < Cin) v = xc[poff[i]];
-            preg[i] = v;
-        }
-    };
-    auto lstore = [&]() {
-        float4* wd = reinterpret_cast<float4*>(Ws);
-#pragma unroll
-        for (int i = 0; i < NW4; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < WS4) wd[idx] = wreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < PS) Ps[idx] = preg[i];
-        }
-    };
-
-    const int wm = (BM == 128) ? (wave >> 1) : 0;
-    const int wn = (BM == 128) ? (wave & 1) : wave;
-    const float* wsl = Ws + wm * 64 + (lane & 31) + (lane >> 5) * BM;
-    const float* psl = Ps + (lane >> 5) * PLANE + (wn * 2) * PW + (lane & 31);
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};   // acc[s co-subtile][q pixel row]
-
-    gload(0);
-    for (int chunk = 0; chunk < nChunks; ++chunk) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (chunk + 1 < nChunks) gload(chunk + 1);
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-            const float* wk = wsl + ky * 3 * CK * BM;
-            const float* pk = psl + ky * PW;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-                for (int j = 0; j < CK / 2; ++j) {
-                    const float a0 = wk[(kx * CK + 2 * j) * BM];
-                    const float a1 = wk[(kx * CK + 2 * j) * BM + 32];
-                    const float b0 = pk[2 * j * PLANE + kx];
-                    const float b1 = pk[2 * j * PLANE + PW + kx];
-                    acc00 = mfma32(a0, b0, acc00);
-                    acc01 = mfma32(a0, b1, acc01);
-                    acc10 = mfma32(a1, b0, acc10);
-                    acc11 = mfma32(a1, b1, acc11);
-                }
-            }
-        }
-    }
-
-    // epilogue: C/D layout col = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (co)
-    const int px = x0 + (lane & 31);
-    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
-    const int yrow = y0 + wn * 2;
-    float* yn = y + (size_t)n * Cout * HW;
-    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
-            if (co >= Cout) continue;
-            const float b = (epi <= 1) ? bias[co] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int yy = yrow + q;
-                if (yy >= H || px >= W) continue;
-                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
-                const size_t o = (size_t)co * HW + (size_t)yy * W + px;
-                if (epi <= 1) {
-                    v += b;
-                    if (epi == 1) v = fmaxf(v, 0.f);
-                } else if (epi == 3) {
-                    v = (mn[o] > 0.f) ? v : 0.f;
-                }
-                yn[o] = v;
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------ forward, buffer-DMA pipeline
@@ -435,129 +274,6 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
     }
 }
 
-// ------------------------------------------------------------------------------------ forward, register-streamed
-// Experimental third pipeline (PTMI_CONV_IMPL=3): no LDS, no barriers.  f32 MFMA is so slow (64 cycles per
-// 32x32x2) that a wave needs only four operand dwords per 256 MFMA cycles, so each wave streams its A (packed
-// weights, two 128-B rows per load) and B (32 consecutive pixels of two input channels per load) fragments
-// straight from L1/L2 into VGPRs with a 6-step software pipeline; the hardware scoreboard (counted vmcnt emitted
-// by the compiler) orders loads against MFMAs.  Waves never synchronise with each other.
-template <int BM, bool BORDER>
-__device__ __forceinline__ void direct_mainloop(const float* __restrict__ wrow, const float* __restrict__ xb0,
-                                                const float* __restrict__ xb1, const float* __restrict__ zero_lane,
-                                                int nChunks, int HW, int W, int Cin, bool row_ok00, bool row_ok01,
-                                                bool row_ok02, bool row_ok03, unsigned long long cm0,
-                                                unsigned long long cm1, unsigned long long cm2, int lane,
-                                                f32x16& acc00, f32x16& acc01, f32x16& acc10, f32x16& acc11)
-{
-    constexpr int D = 6, STEPS = 18;
-    float ra0[D], ra1[D], rb0[D], rb1[D];
-    const int half = lane >> 5;
-    // rows touched by pixel row q with tap ky: index q + ky  in {0,1,2,3} -> row_ok0{q+ky}
-    auto rowok = [&](int qk) { return qk == 0 ? row_ok00 : (qk == 1 ? row_ok01 : (qk == 2 ? row_ok02 : row_ok03)); };
-    auto colok = [&](int kx) { return ((kx == 0 ? cm0 : (kx == 1 ? cm1 : cm2)) >> lane) & 1ull; };
-    auto load = [&](int chunk, int st, int slot) {
-        const int tap = st >> 1, j = st & 1, ky = tap / 3, kx = tap % 3;
-        const float* a = wrow + ((size_t)chunk * STEPS + st) * 2 * BM;
-        ra0[slot] = a[0];
-        ra1[slot] = a[32];
-        const size_t boff = (size_t)(chunk * 4 + 2 * j) * HW + ky * W + kx;
-        if (BORDER) {
-            const bool cok = colok(kx) && (chunk * 4 + 2 * j + half) < Cin;
-            rb0[slot] = *((cok && rowok(0 + ky)) ? xb0 + boff : zero_lane);
-            rb1[slot] = *((cok && rowok(1 + ky)) ? xb1 + boff : zero_lane);
-        } else {
-            rb0[slot] = xb0[boff];
-            rb1[slot] = xb1[boff];
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < D; ++s) load(0, s, s);
-    for (int chunk = 0; chunk < nChunks; ++chunk) {
-        const bool more = chunk + 1 < nChunks;
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const int slot = st % D;
-            acc00 = mfma32(ra0[slot], rb0[slot], acc00);
-            acc01 = mfma32(ra0[slot], rb1[slot], acc01);
-            acc10 = mfma32(ra1[slot], rb0[slot], acc10);
-            acc11 = mfma32(ra1[slot], rb1[slot], acc11);
-            if (st + D < STEPS) load(chunk, st + D, slot);
-            else if (more) load(chunk + 1, st + D - STEPS, slot);
-        }
-    }
-}
-
-template <int BM>
-__global__ __launch_bounds__(256, 3) void conv3x3_direct_kernel(
-    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
-    int tilesX, int tilesY, int coTiles, int nChunks, int epi, const float* __restrict__ zero_page)
-{
-    using C = FwdCfg<BM>;
-    constexpr int TH = C::TH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int cot = bid % coTiles;
-    int pt = bid / coTiles;
-    const int tx = pt % tilesX;
-    pt /= tilesX;
-    const int ty = pt % tilesY;
-    const int n = pt / tilesY;
-    const int x0 = tx * TW, y0 = ty * TH;
-    const int HW = H * W;
-    const int wm = (BM == 128) ? (wave >> 1) : 0;
-    const int wn = (BM == 128) ? (wave & 1) : wave;
-    const int yrow = y0 + wn * 2;
-
-    const float* wrow = wp + (size_t)cot * nChunks * (9 * 4 * BM) + (lane >> 5) * BM + wm * 64 + (lane & 31);
-    const float* xn = x + (size_t)n * Cin * HW + (size_t)(lane >> 5) * HW;
-    // pointers at tap (ky,kx) = (0,0) of pixel rows q = 0,1; only dereferenced where the tap is inside the image
-    const float* xb0 = xn + ((ptrdiff_t)yrow - 1) * W + (x0 - 1) + (lane & 31);
-    const float* xb1 = xb0 + W;
-    const float* zero_lane = zero_page + lane;
-    const bool r0 = (yrow - 1) >= 0 && (yrow - 1) < H, r1 = yrow < H, r2 = (yrow + 1) < H, r3 = (yrow + 2) < H;
-    const int colx = x0 - 1 + (lane & 31);
-    const unsigned long long cm0 = __ballot(colx >= 0 && colx < W), cm1 = __ballot(colx + 1 < W),
-                             cm2 = __ballot(colx + 2 < W);
-    const bool interior = r0 && r3 && x0 >= 1 && (x0 + 33) <= W && (Cin & 3) == 0;
-
-    f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
-    if (interior)
-        direct_mainloop<BM, false>(wrow, xb0, xb1, zero_lane, nChunks, HW, W, Cin, r0, r1, r2, r3, cm0, cm1, cm2, lane,
-                                   acc00, acc01, acc10, acc11);
-    else
-        direct_mainloop<BM, true>(wrow, xb0, xb1, zero_lane, nChunks, HW, W, Cin, r0, r1, r2, r3, cm0, cm1, cm2, lane,
-                                  acc00, acc01, acc10, acc11);
-
-    const int px = x0 + (lane & 31);
-    const int co_base = cot * BM + wm * 64 + 4 * (lane >> 5);
-    float* yn = y + (size_t)n * Cout * HW;
-    const float* mn = (epi == 3) ? mref + (size_t)n * Cout * HW : nullptr;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co_base + s * 32 + (r & 3) + 8 * (r >> 2);
-            if (co >= Cout) continue;
-            const float b = (epi <= 1) ? bias[co] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int yy = yrow + q;
-                if (yy >= H || px >= W) continue;
-                float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
-                const size_t o = (size_t)co * HW + (size_t)yy * W + px;
-                if (epi <= 1) {
-                    v += b;
-                    if (epi == 1) v = fmaxf(v, 0.f);
-                } else if (epi == 3) {
-                    v = (mn[o] > 0.f) ? v : 0.f;
-                }
-                yn[o] = v;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------ stem (Cin <= 4), VALU
 // The 3-channel stem has K = 27: 3.7 GF per image against 273 MB of output -- an HBM-write-bound layer whose MFMA
 // formulations (above) spend their time in per-workgroup latency chains (2.3 ms per 16 images = 1.9 TB/s of stores).
@@ -629,122 +345,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         }
         wp[i] = v;
     }
-    // 64-float "zero page" after the slabs: the register-streamed stem kernel points halo / channel-padding lanes here
-    if (blockIdx.x == 0 && threadIdx.x < 64) wp[total + threadIdx.x] = 0.f;
 }
-
-// ------------------------------------------------------------------------------------ wgrad
-// workgroup: 128 co x 32 ci x 9 taps; wave w owns co sub-tile w (32 co); K = pixels, 32 px / stage.
-constexpr int WG_PIX = 32;           // 1 row x 32 cols per stage
-constexpr int DY_PITCH = 33;
-constexpr int XP_PLANE = 3 * PW;     // 3 rows x 34 = 102
-constexpr int XP_PITCH = XP_PLANE + 1;   // 103 (odd)
-
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N,
-    int Cin, int Cout, int H, int W, int tilesX, int tilesY, int coTiles, int ciTiles, int S)
-{
-    constexpr int DYS = 128 * DY_PITCH;
-    constexpr int XS = 32 * XP_PITCH;
-    constexpr int NDY = 128 * WG_PIX / 256;            // 16
-    constexpr int NX = (32 * XP_PLANE + 255) / 256;    // 13
-    __shared__ float lds[DYS + XS];
-    float* dYs = lds;
-    float* Xs = lds + DYS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int bid = blockIdx.x;
-    const int s = bid % S; bid /= S;
-    const int cit = bid % ciTiles;
-    const int cot = bid / ciTiles;
-    const int HW = H * W;
-    const int co0 = cot * 128, ci0 = cit * 32;
-    const int nTiles = N * tilesY * tilesX;
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = (f32x16){0};
-
-    float dreg[NDY];
-    float xreg[NX];
-    auto gload = [&](int tile) {
-        const int tx = tile % tilesX;
-        int t2 = tile / tilesX;
-        const int ty = t2 % tilesY;
-        const int n = t2 / tilesY;
-        const int x0 = tx * TW, y0 = ty;
-        const float* dyn = dy + (size_t)n * Cout * HW;
-        const float* xn = x + (size_t)n * Cin * HW;
-        const int col = tid & 31;
-#pragma unroll
-        for (int i = 0; i < NDY; ++i) {
-            const int co = co0 + (tid >> 5) + 8 * i;
-            const int gx = x0 + col;
-            float v = 0.f;
-            if (co < Cout && gx < W) v = dyn[(size_t)co * HW + y0 * W + gx];
-            dreg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * 256;
-            float v = 0.f;
-            if (idx < 32 * XP_PLANE) {
-                const int ci = idx / XP_PLANE, rem = idx - ci * XP_PLANE;
-                const int r = rem / PW, c = rem - r * PW;
-                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-                if (ci0 + ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                    v = xn[(size_t)(ci0 + ci) * HW + gy * W + gx];
-            }
-            xreg[i] = v;
-        }
-    };
-    auto lstore = [&]() {
-        const int col = tid & 31;
-#pragma unroll
-        for (int i = 0; i < NDY; ++i) dYs[((tid >> 5) + 8 * i) * DY_PITCH + col] = dreg[i];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            const int idx = tid + i * 256;
-            if (idx < 32 * XP_PLANE) {
-                const int ci = idx / XP_PLANE, rem = idx - ci * XP_PLANE;
-                Xs[ci * XP_PITCH + rem] = xreg[i];
-            }
-        }
-    };
-
-    const float* al = dYs + (wave * 32 + (lane & 31)) * DY_PITCH + (lane >> 5);
-    const float* bl = Xs + (lane & 31) * XP_PITCH + (lane >> 5);
-
-    int tile = s;
-    if (tile < nTiles) gload(tile);
-    for (; tile < nTiles; tile += S) {
-        __syncthreads();
-        lstore();
-        __syncthreads();
-        if (tile + S < nTiles) gload(tile + S);
-#pragma unroll 2
-        for (int kk = 0; kk < 16; ++kk) {
-            const float a = al[2 * kk];
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap % 3;
-                const float b = bl[ky * PW + 2 * kk + kx];
-                acc[tap] = mfma32(a, b, acc[tap]);
-            }
-        }
-    }
-    // partial[s][tap][co][ci]
-    const int ci = ci0 + (lane & 31);
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        float* dst = partial + ((size_t)s * 9 + tap) * Cout * Cin;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[tap][r];
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------ wgrad, buffer-DMA pipeline
 // Third-generation wgrad main loop (default).  Measured with clock64() probes (tools/exp_wgrad_timing.py): in the
 // kernel above a wave spends as long issuing its 16 dword DMAs per stage (address VALU work that has to win issue
@@ -1076,37 +677,16 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
         dz[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
-// PTMI_CONV_IMPL (A/B knob): 4 = buffer-DMA pipelines (default); 3 = LDS-free register-streamed forward everywhere;
-// 1 = register-staged kernels with ds_write (also the fallback for shapes whose offsets do not fit 32 bits)
-int conv_impl()
-{
-    static int impl = -1;
-    if (impl < 0) {
-        const char* e = getenv("PTMI_CONV_IMPL");
-        impl = (e && (e[0] == '1' || e[0] == '3')) ? (e[0] - '0') : 4;
-    }
-    return impl;
-}
-
-// split-K factor of the separate right-edge launch of the buffer-DMA wgrad (0 = no separate launch)
+// split-K factor of the right-edge workgroups of the wgrad launch (0 = the edge tile column is handled by the main ones)
 int wgrad_edge_splits(int n, int cin, int cout, int h, int w)
 {
     const int tilesX = cdiv(w, TW), wv = w - (tilesX - 1) * TW;
-    if (conv_impl() == 1 || (int64_t)128 * h * w >= (1 << 28) || tilesX < 2 || wv > 24) return 0;
+    if (tilesX < 2 || wv > 24) return 0;
     const int base = cdiv(cout, 128) * cdiv(cin, 32);
     const int64_t nTiles = (int64_t)n * h;
     int S = cdiv(512, base);
     if (S > nTiles) S = (int)nTiles;
     return S < 1 ? 1 : S;
-}
-
-// PTMI_CONV_STEM (A/B knob) for Cin <= 4: 2 = VALU pixel-per-thread kernel (default, Cout <= 64 tiles), 1 = LDS-free
-// MFMA kernel, 0 = the regular buffer-DMA kernel
-int stem_impl()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PTMI_CONV_STEM"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }
-    return v;
 }
 
 int wgrad_splits(int n, int cin, int cout, int h, int w)
@@ -1126,21 +706,12 @@ int wgrad_splits(int n, int cin, int cout, int h, int w)
 extern "C" {
 
 int ptmi_conv3x3_bm(int cout) { return cout <= 64 ? 64 : 128; }
-int ptmi_conv3x3_ck(int cin)
-{
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("PTMI_CONV_CK");   // tuning knob: force the channel-chunk depth (4 or 8)
-        forced = (e && (e[0] == '4' || e[0] == '8')) ? (e[0] - '0') : 0;
-    }
-    if (forced) return forced;
-    return (cin <= 4 || conv_impl() != 1) ? 4 : 8;
-}
+int ptmi_conv3x3_ck(int cin) { (void)cin; return 4; }
 
 int64_t ptmi_conv3x3_packed_floats(int cin, int cout)
 {
     const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
-    return (int64_t)cdiv(cout, BM) * cdiv(cin, CK) * 9 * CK * BM + 64;   // + zero page
+    return (int64_t)cdiv(cout, BM) * cdiv(cin, CK) * 9 * CK * BM;
 }
 
 int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode,
@@ -1163,69 +734,42 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_fwd: bad epilogue %d", epilogue);
-    const bool buf_ok = ptmi_conv3x3_ck(cin) == 4 && conv_impl() == 4 && (int64_t)cin * h * w * 4 < (1ll << 32) &&
-                        ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) && (int64_t)n * cdiv(h, 4) < 65536;
-    PTMI_CHECK_ARG(epilogue != 4 || buf_ok, "conv3x3_fwd: the fused pool epilogue needs the buffer-DMA kernel");
+    // the buffer-DMA kernels address one image through 32-bit byte offsets and a 16-bit grid dimension: reject (loudly)
+    // anything larger -- 1333x800 VGG maps use at most 273 MB per image
+    PTMI_CHECK_ARG((int64_t)cin * h * w * 4 < (1ll << 32) && ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) &&
+                   (int64_t)n * cdiv(h, 4) < 65536, "conv3x3_fwd: image too large for 32-bit buffer offsets "
+                   "(n=%d cin=%d cout=%d h=%d w=%d)", n, cin, cout, h, w);
     PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
     const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
-    static int w8 = -1;
-    if (w8 < 0) { const char* e = getenv("PTMI_CONV_W8"); w8 = e ? (e[0] - '0') : 2; }
-    // 8-wave workgroups (8 rows x 32 cols per 128 channels) share one weight slab among twice the pixels
-    const bool use8 = BM == 128 && buf_ok && cin > 4 && (w8 == 1 || (w8 == 2 && h >= 200));   // A/B: +3.5 % at 400x666, -3 .. -14 % on the small maps
+    // 8-wave workgroups (8 rows x 32 cols per 128 channels) share one weight slab among twice the pixels:
+    // A/B +3.5 % at 400x666, -3 .. -14 % on the small maps
+    const bool use8 = BM == 128 && cin > 4 && h >= 200;
     const int TH = (BM == 128 && !use8) ? 4 : 8;
     const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
-    const int64_t blocks = (int64_t)n * tilesX * tilesY * coTiles;
-    PTMI_CHECK_ARG(blocks < (1ll << 31), "conv3x3_fwd: grid too large");
-    dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = (hipStream_t)s;
-    // register-streamed kernel: everywhere with PTMI_CONV_IMPL=3 (A/B experiments: slower than the buffer-DMA pipeline on the big
-    // layers, 66-80 vs 115-131 TF/s) and by default for the 3-channel stem, whose K = 36 loop is too short to
-    // amortise the LDS pipeline's prologue (25 vs 18 TF/s; that layer is HBM-write bound)
-    if (CK == 4 && BM == 64 && conv_impl() == 4 && cin <= 4 && stem_impl() == 2 && epilogue <= 1) {
+    // 3-channel stem: K = 27 is too short to amortise the LDS pipeline's prologue and the layer is HBM-write bound
+    if (BM == 64 && cin <= 4 && epilogue <= 1) {
         // (-ffp-contract=off: fmaf() is explicit in the kernel; K = 27 keeps the rounding difference at the 1e-7 level)
         hipLaunchKernelGGL(conv3x3_stem_kernel, dim3((unsigned)cdiv(w, 64), (unsigned)cdiv(h, 4), (unsigned)n), dim3(256), 0,
                            st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
         PTMI_LAUNCH_CHECK("conv3x3_fwd(stem)");
         return 0;
     }
-    if (CK == 4 && (conv_impl() == 3 || (conv_impl() == 4 && cin <= 4 && stem_impl() >= 1)) && epilogue != 4) {
-        const float* zero_page = wp + (int64_t)coTiles * nChunks * 9 * CK * BM;
-        if (BM == 128)
-            hipLaunchKernelGGL((conv3x3_direct_kernel<128>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
-                               h, w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
-        else
-            hipLaunchKernelGGL((conv3x3_direct_kernel<64>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, cin, cout,
-                               h, w, tilesX, tilesY, coTiles, nChunks, epilogue, zero_page);
-        PTMI_LAUNCH_CHECK("conv3x3_fwd(direct)");
-        return 0;
-    }
-    if (buf_ok) {
-        const dim3 grid3((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
+    const dim3 grid3((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
 #define LBUF(BM_, NW_) hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, \
                                           y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
-        if (BM == 128 && use8) LBUF(128, 8);
-        else if (BM == 128) LBUF(128, 4);
-        else LBUF(64, 4);
+    if (BM == 128 && use8) LBUF(128, 8);
+    else if (BM == 128) LBUF(128, 4);
+    else LBUF(64, 4);
 #undef LBUF
-        PTMI_LAUNCH_CHECK("conv3x3_fwd(buf)");
-        return 0;
-    }
-#define LAUNCH(BM_, CK_)                                                                              \
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<BM_, CK_>), grid, block, 0, st, x, wp, bias, mask_ref, y, n, \
-                       cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
-    if (BM == 128 && CK == 8) LAUNCH(128, 8);
-    else if (BM == 64 && CK == 8) LAUNCH(64, 8);
-    else if (BM == 128 && CK == 4) LAUNCH(128, 4);
-    else LAUNCH(64, 4);
-#undef LAUNCH
-    PTMI_LAUNCH_CHECK("conv3x3_fwd");
+    PTMI_LAUNCH_CHECK("conv3x3_fwd(buf)");
     return 0;
 }
 
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 {
-    // split-K partials (main + right-edge launch) + zero page for the DMA kernel + bias-gradient partials
+    // split-K partials (main + right-edge workgroups) + bias-gradient partials
     return (int64_t)(wgrad_splits(n, cin, cout, h, w) + wgrad_edge_splits(n, cin, cout, h, w)) * 9 * cout * cin + 64 +
            (int64_t)cout * BG_SLOTS;
 }
@@ -1234,22 +778,18 @@ int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, fl
                        int cout, int h, int w, int accumulate, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0, "conv3x3_wgrad: bad args");
+    PTMI_CHECK_ARG((int64_t)128 * h * w < (1 << 28), "conv3x3_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
     const int tilesX = cdiv(w, TW), tilesY = h;
     const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
     int S = wgrad_splits(n, cin, cout, h, w);
     const int Se = wgrad_edge_splits(n, cin, cout, h, w);
     const int64_t bg_off = (int64_t)(S + Se) * 9 * cout * cin;
     hipStream_t st = (hipStream_t)s;
-    if (conv_impl() != 1 && (int64_t)128 * h * w < (1 << 28)) {
-        // Se > 0: the right-edge tile column has few valid pixels and gets the short interleaved stage
-        const int nMain = coTiles * ciTiles * S, nEdge = coTiles * ciTiles * Se;
-        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel, dim3(nMain + nEdge), dim3(512), 0, st, x, dy, ws, n, cin, cout, h, w,
-                           Se > 0 ? tilesX - 1 : tilesX, tilesY, coTiles, ciTiles, S, nMain, Se);
-        S += Se;
-    } else {
-        hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(coTiles * ciTiles * S), dim3(256), 0, st, x, dy, ws, n, cin,
-                           cout, h, w, tilesX, tilesY, coTiles, ciTiles, S);
-    }
+    // Se > 0: the right-edge tile column has few valid pixels and gets the short interleaved stage
+    const int nMain = coTiles * ciTiles * S, nEdge = coTiles * ciTiles * Se;
+    hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel, dim3(nMain + nEdge), dim3(512), 0, st, x, dy, ws, n, cin, cout, h, w,
+                       Se > 0 ? tilesX - 1 : tilesX, tilesY, coTiles, ciTiles, S, nMain, Se);
+    S += Se;
     PTMI_LAUNCH_CHECK("conv3x3_wgrad");
     const int64_t total = (int64_t)cout * cin * 9;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw,

@@ -6,7 +6,6 @@
 // channels with threads laid out along (c, ph, pw) so that the (R, C, 7, 7) output is written with
 // fully coalesced stores.  Backward scatters with hardware fp32 atomics (-munsafe-fp-atomics).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -243,113 +242,17 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
     }
 }
 
-// Backward without any atomics.  ROIAlign is separable: a sample's bilinear weight is wy(sample_y, cell_y) *
-// wx(sample_x, cell_x) and its bin is (ph(sample_y), pw(sample_x)), so for one ROI and one channel
+// Backward without any atomics (7x7 pooling, W <= 128, H <= 64: the hot-path maps).  ROIAlign is separable: a
+// sample's bilinear weight is wy(sample_y, cell_y) * wx(sample_x, cell_x) and its bin is (ph(sample_y),
+// pw(sample_x)), so for one ROI and one channel
 //     dF[fy][fx] += (1/count) * sum_{ph,pw} Wy[fy][ph] * dOut[ph][pw] * Wx[fx][pw]
-// with Wy[fy][ph] = sum of the y-weights that the gh sample rows of bin-row ph put on feature row fy (same for
-// Wx).  A workgroup owns CG channel planes of ONE image in LDS (rois are grouped by image) and walks the image's
-// ROIs: 14 threads build Wy (H x 7) / Wx (W x 7) for the ROI, then thread (c, fx) forms t[ph] = sum_pw
-// dOut[c][ph][pw] * Wx[fx][pw] and adds sum_ph Wy[fy][ph] * t[ph] down its column -- every cell has one owner per
-// ROI, so plain LDS read-modify-write, fixed summation order (deterministic), and each plane is written to HBM once.
-constexpr int RB_THREADS = 512;
-
-__global__ __launch_bounds__(RB_THREADS) void roi_align_bwd_sep_kernel(const float* __restrict__ dout,
-                                                                       const float* __restrict__ rois,
-                                                                       const int32_t* __restrict__ img_off,
-                                                                       float* __restrict__ dfeat, int C, int H, int W,
-                                                                       int P, float scale, int CG)
-{
-    extern __shared__ float smem[];
-    // layout: plane[CG*H*W] | Wy[H*7] | Wx[W*7] | G[CG*49] | rng[4] (as int)
-    const int HW = H * W;
-    float* plane = smem;
-    float* Wy = plane + CG * HW;
-    float* Wx = Wy + H * 7;
-    float* G = Wx + W * 7;
-    int* rng = reinterpret_cast<int*>(G + CG * 49);
-    const int n = blockIdx.y, c0 = blockIdx.x * CG;
-    const int cg = min(CG, C - c0);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < cg * HW; i += RB_THREADS) plane[i] = 0.f;
-    for (int i = tid; i < (H + W) * 7; i += RB_THREADS) Wy[i] = 0.f;      // Wy and Wx are contiguous
-    if (tid < 4) rng[tid] = (tid & 1) ? -1 : (1 << 30);                    // ymin, ymax, xmin, xmax
-    __syncthreads();
-    const int r0 = img_off[n], r1 = img_off[n + 1];
-    for (int r = r0; r < r1; ++r) {
-        const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, P);
-        // ---- phase A: 1-D weight tables (thread ph builds column ph of Wy, thread 7+pw column pw of Wx)
-        if (tid < 2 * 7 && P == 7) {
-            const bool isx = tid >= 7;
-            const int pb = isx ? tid - 7 : tid;
-            const int gn = isx ? g.gw : g.gh, L = isx ? W : H;
-            const float start = isx ? g.sw : g.sh, bsz = isx ? g.bw : g.bh;
-            float* Wt = isx ? Wx : Wy;
-            int lo = 1 << 30, hi = -1;
-            for (int i = 0; i < gn; ++i) {
-                float v = start + (float)pb * bsz + ((float)i + .5f) * bsz / (float)gn;
-                if (v < -1.0f || v > (float)L) continue;
-                if (v <= 0.f) v = 0.f;
-                int l = (int)v, h2;
-                if (l >= L - 1) { h2 = l = L - 1; v = (float)l; } else h2 = l + 1;
-                const float lw = v - (float)l, hw = 1.f - lw;
-                Wt[l * 7 + pb] += hw;
-                Wt[h2 * 7 + pb] += lw;
-                lo = min(lo, l);
-                hi = max(hi, h2);
-            }
-            if (hi >= 0) {
-                atomicMin(&rng[isx ? 2 : 0], lo);
-                atomicMax(&rng[isx ? 3 : 1], hi);
-            }
-        }
-        const float* ob = dout + ((size_t)r * C + c0) * 49;
-        if (tid < cg * 49) G[tid] = ob[tid] / g.count;
-        __syncthreads();
-        const int y0 = rng[0], y1 = rng[1], x0 = rng[2], x1 = rng[3];
-        // ---- phase B: column owners
-        if (y1 >= 0 && x1 >= 0) {
-            const int fw = x1 - x0 + 1;
-            for (int i = tid; i < cg * fw; i += RB_THREADS) {
-                const int c = i / fw, fx = x0 + (i - c * fw);
-                const float* gc = G + c * 49;
-                const float* wx = Wx + fx * 7;
-                float t[7];
-#pragma unroll
-                for (int ph = 0; ph < 7; ++ph) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int pw = 0; pw < 7; ++pw) acc += gc[ph * 7 + pw] * wx[pw];
-                    t[ph] = acc;
-                }
-                float* col = plane + c * HW + fx;
-                for (int fy = y0; fy <= y1; ++fy) {
-                    const float* wy = Wy + fy * 7;
-                    float acc = 0.f;
-#pragma unroll
-                    for (int ph = 0; ph < 7; ++ph) acc += wy[ph] * t[ph];
-                    col[fy * W] += acc;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- reset the tables over the touched ranges
-        if (y1 >= 0)
-            for (int i = tid; i < (y1 - y0 + 1) * 7; i += RB_THREADS) Wy[y0 * 7 + i] = 0.f;
-        if (x1 >= 0)
-            for (int i = tid; i < (x1 - x0 + 1) * 7; i += RB_THREADS) Wx[x0 * 7 + i] = 0.f;
-        if (tid < 4) rng[tid] = (tid & 1) ? -1 : (1 << 30);
-        __syncthreads();
-    }
-    float* dst = dfeat + ((size_t)n * C + c0) * HW;
-    for (int i = tid; i < cg * HW; i += RB_THREADS) dst[i] = plane[i];
-}
-
-// Third-generation backward (default for 7x7 pooling, W <= 128): same separable formulation, but
+// with Wy[fy][ph] = sum of the y-weights that the gh sample rows of bin-row ph put on feature row fy (same for Wx).
 //   * the per-ROI 1-D weight tables (Wy rows y0..y1, Wx rows x0..x1, 8 floats per row) are built ONCE per ROI by
-//     roi_bwd_tables_kernel into a workspace instead of by 14 threads of every channel-group workgroup, and
-//   * every thread owns a FIXED column (channel c = tid / 128, feature column fx = tid % 128) of the LDS planes for
-//     the whole ROI walk, so consecutive ROIs never hand a cell from one thread to another: the ROI loop has no
-//     barrier at all (the kernel above needs three per ROI and keeps ~80 of 512 threads busy).
+//     roi_bwd_tables_kernel into a workspace, and
+//   * a workgroup owns 4 channel planes of ONE image in LDS (rois are grouped by image) and every thread owns a FIXED
+//     column (channel c = tid / 128, feature column fx = tid % 128) of the LDS planes for the whole ROI walk, so
+//     consecutive ROIs never hand a cell from one thread to another: the ROI loop has no barrier at all, the
+//     summation order is fixed (deterministic) and each plane is written to HBM once.
 // Each wave stages the ROI's Wy table in a private LDS strip (broadcast reads in the column loop); lanes 0-48 hold
 // dOut[r][c] (broadcast with v_readlane) and every lane its own Wx row.  The tables are indexed by absolute feature
 // row / column, so none of these loads depends on the ROI header and all of them are issued one ROI ahead.
@@ -576,46 +479,27 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
                    "roi_align_bwd_grouped: bad args");
     hipStream_t st = (hipStream_t)s;
     const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    const size_t budget = 72 * 1024;      // two workgroups per CU
-    const size_t extra = ((size_t)(h + w) * 7 + 4 * 49 + 8) * sizeof(float);
-    if (pooled != 7 || plane_bytes + extra > budget || r == 0) {   // not the hot-path shape: zero + atomic kernel
+    const size_t stage = (size_t)(RB2_THREADS / 64) * h * 8 * sizeof(float);
+    const bool col_ok = pooled == 7 && ws && w <= RB2_XP && h <= 64 && 4 * plane_bytes + stage <= 79 * 1024;
+    if (!col_ok || r == 0) {              // not the hot-path shape (or no ROI at all): zero + atomic scatter kernel
         hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)n * c * plane_bytes, st);
         if (e != hipSuccess) { ptmi_set_error("roi_align_bwd_grouped: memset failed"); return -2; }
         return r == 0 ? 0 : ptmi_roi_align_bwd(dout, rois, dfeat, n, c, h, w, r, pooled, scale, s);
     }
     PTMI_CHECK_ARG(dout && rois, "roi_align_bwd_grouped: null buffer");
-    static int impl = -1;                 // PTMI_ROI_BWD_IMPL=1: the barrier-per-ROI kernel
-    if (impl < 0) { const char* e = getenv("PTMI_ROI_BWD_IMPL"); impl = (e && e[0] == '1') ? 1 : 2; }
-    const size_t stage = (size_t)(RB2_THREADS / 64) * h * 8 * sizeof(float);
-    if (impl == 2 && ws && w <= RB2_XP && h <= 64 && 4 * plane_bytes + stage <= 79 * 1024) {
-        hipLaunchKernelGGL(roi_bwd_tables_kernel, dim3(r), dim3(64), (size_t)(h + w) * 8 * sizeof(float), st, rois, ws, h,
-                           w, scale);
-        PTMI_LAUNCH_CHECK("roi_align_bwd_tables");
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
-            attr2 = true;
-        }
-        const int cg = c < 4 ? c : 4;
-        hipLaunchKernelGGL(roi_align_bwd_col_kernel, dim3(cdiv(c, cg), n), dim3(RB2_THREADS), 4 * plane_bytes + stage, st,
-                           dout, ws, img_offsets, dfeat, c, h, w, cg);
-        PTMI_LAUNCH_CHECK("roi_align_bwd_grouped(col)");
-        return 0;
-    }
-    int cg = (int)((budget - extra) / plane_bytes);
-    if (cg > 4) cg = 4;
-    if (cg > c) cg = c;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_sep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipLaunchKernelGGL(roi_bwd_tables_kernel, dim3(r), dim3(64), (size_t)(h + w) * 8 * sizeof(float), st, rois, ws, h, w,
+                       scale);
+    PTMI_LAUNCH_CHECK("roi_align_bwd_tables");
+    static bool attr2 = false;
+    if (!attr2) {
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
-        attr_set = true;
+        attr2 = true;
     }
-    const size_t lds = (size_t)cg * plane_bytes + ((size_t)(h + w) * 7 + (size_t)cg * 49 + 8) * sizeof(float);
-    hipLaunchKernelGGL(roi_align_bwd_sep_kernel, dim3(cdiv(c, cg), n), dim3(RB_THREADS), lds, st, dout, rois,
-                       img_offsets, dfeat, c, h, w, pooled, scale, cg);
-    PTMI_LAUNCH_CHECK("roi_align_bwd_grouped");
+    const int cg = c < 4 ? c : 4;
+    hipLaunchKernelGGL(roi_align_bwd_col_kernel, dim3(cdiv(c, cg), n), dim3(RB2_THREADS), 4 * plane_bytes + stage, st,
+                       dout, ws, img_offsets, dfeat, c, h, w, cg);
+    PTMI_LAUNCH_CHECK("roi_align_bwd_grouped(col)");
     return 0;
 }
 

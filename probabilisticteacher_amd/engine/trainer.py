@@ -5,7 +5,6 @@ without thresholding, shrink-and-paste `resize`, supervised + unsupervised stude
 gradient clipping, SGD -- but every heavy piece is a HIP kernel and the per-tensor Python loops of the reference
 (EMA, clip, SGD, metrics `.item()`s) are single launches over flat buffers.  What the reference does only to burn
 time (anomaly mode, empty_cache, gc.collect, a third unused model copy) is not replicated."""
-import copy
 import random
 import time
 from typing import Callable, Dict, List, Optional
@@ -146,9 +145,6 @@ class PTrainer:
             with torch.no_grad():
                 _, _, proposals_roih_unsup_k, _ = self.model_teacher(unlabel_data_k, branch="unsup_data_weak")
             pseudo, _ = self.process_pseudo_label(proposals_roih_unsup_k, "roih", "all")
-            self.last_pseudo = pseudo
-            if getattr(self, "pseudo_override", None) is not None:     # test hook, see tests/test_model_gpu.py
-                pseudo = self.pseudo_override
             unlabel_data_q = self.add_label(self.remove_label([dict(d) for d in unlabel_data_q]), pseudo)
             unlabel_data_q = self.resize(unlabel_data_q)
             label_data_q = self.resize(label_data_q)

@@ -16,7 +16,6 @@ from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
 from ..structures import Boxes, FreeInstances
 from .box_regression import Box2BoxTransform
 from . import sampling
-from .sampling import subsample_labels
 
 GT_LOGIT = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))     # proposal_utils.py:207
 
@@ -295,30 +294,7 @@ class GuassianROIHead(nn.Module):
                 c0 += cnt
                 out.append(r)
             return out
-        if sampling.legacy_path():                     # parity tests that inject the reference's permutations
-            for prop, tgt in zip(proposals, targets):
-                gtb = tgt.gt_boxes.tensor
-                boxes, logits = prop.proposal_boxes.tensor, prop.objectness_logits
-                if self.proposal_append_gt:
-                    boxes = torch.cat([boxes, gtb], 0)
-                    logits = torch.cat([logits, GT_LOGIT * torch.ones(len(gtb), device=boxes.device)], 0)
-                midx, mlab, _ = ops.iou_match(gtb, boxes.contiguous(), self.iou_thresholds, self.iou_labels, False)
-                if tgt.gt_classes.numel() > 0:
-                    cls = tgt.gt_classes[midx]
-                    cls = torch.where(mlab == 0, torch.full_like(cls, K), cls)
-                    cls = torch.where(mlab == -1, torch.full_like(cls, -1), cls)
-                else:
-                    cls = torch.zeros_like(midx) + K
-                fg, bg = subsample_labels(cls, self.batch_size_per_image, self.positive_fraction, K)
-                sel = torch.cat([fg, bg], 0)
-                r = FreeInstances(prop.image_size)
-                r.proposal_boxes = Boxes(boxes[sel])
-                r.objectness_logits = logits[sel]
-                r.gt_classes = cls[sel]
-                r.gt_boxes = Boxes(gtb[midx[sel]]) if len(gtb) > 0 else Boxes(gtb.new_zeros((len(sel), 4)))
-                out.append(r)
-            return out
-        # ---- production path: the whole batch at once.  Proposals (+ appended ground truth) of all images are
+        # the whole batch at once.  Proposals (+ appended ground truth) of all images are
         # concatenated; labels come from one batched IoU match, the 512-per-image sample from one sampling launch
         # (random keys, see sampling.py); ONE device->host read (the sample sizes) for the batch.
         gcounts = [len(t.gt_boxes) for t in targets]
@@ -351,7 +327,7 @@ class GuassianROIHead(nn.Module):
         else:
             gidx = None
             cls = torch.full((total,), K, dtype=torch.int64, device=dev)
-        keys = sampling.segment_keys(bcounts, dev)
+        keys = sampling.draw_keys(cls, bcounts, K)
         npos = int(self.batch_size_per_image * self.positive_fraction)
         fg, bg, cnt = ops.sample_by_keys(cls, keys, box_off, max(bcounts), self.batch_size_per_image, npos, K)
         cnt_h = cnt.cpu().tolist()                                                   # the one sync

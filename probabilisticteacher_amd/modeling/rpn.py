@@ -19,7 +19,6 @@ from ..structures import Boxes, FreeInstances
 from .anchor_generator import build_anchor_generator
 from .box_regression import Box2BoxTransform
 from . import sampling
-from .sampling import subsample_labels
 
 
 class _ConvP(nn.Module):
@@ -161,31 +160,16 @@ class GuassianRPN(nn.Module):
         n, r = logits.shape
         anc = anchors.detach()
         with torch.no_grad():
-            if sampling.legacy_path():                 # parity tests that inject the reference's permutations
-                labels, matched = [], []
-                for inst in gt_instances:
-                    gt = inst.gt_boxes.tensor
-                    midx, lab, _ = ops.iou_match(gt, anc, self.iou_thresholds, self.iou_labels, True)
-                    pos, neg = subsample_labels(lab, self.batch_size_per_image, self.positive_fraction, 0)
-                    lab.fill_(-1)
-                    lab[pos] = 1
-                    lab[neg] = 0
-                    labels.append(lab)
-                    matched.append(torch.zeros_like(anc) if len(gt) == 0 else gt[midx])
-                lab_all = torch.stack(labels)                          # (N,R) int8
-                flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
-                gt_rows = torch.stack(matched).view(-1, 4)[flat_pos]
-            else:
-                # whole batch: one IoU-match launch pair, one sync-free relabel, one nonzero
-                counts = [len(inst.gt_boxes) for inst in gt_instances]
-                gt_all = torch.cat([inst.gt_boxes.tensor for inst in gt_instances], 0)
-                midx, lab_all, _, gt_off, _ = ops.iou_match_batched(gt_all, counts, anc, None, self.iou_thresholds,
-                                                                    self.iou_labels, True)
-                lab_all = sampling.keyed_relabel(lab_all, self.batch_size_per_image, self.positive_fraction, 0)
-                flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
-                img = torch.div(flat_pos, r, rounding_mode="floor")
-                # (positives only exist for images with ground truth, so the gather index is always in range)
-                gt_rows = gt_all[midx.view(-1)[flat_pos] + gt_off[img].long()]
+            # whole batch: one IoU-match launch pair, one sync-free relabel, one nonzero
+            counts = [len(inst.gt_boxes) for inst in gt_instances]
+            gt_all = torch.cat([inst.gt_boxes.tensor for inst in gt_instances], 0)
+            midx, lab_all, _, gt_off, _ = ops.iou_match_batched(gt_all, counts, anc, None, self.iou_thresholds,
+                                                                self.iou_labels, True)
+            lab_all = sampling.keyed_relabel(lab_all, self.batch_size_per_image, self.positive_fraction, 0)
+            flat_pos = torch.nonzero(lab_all.view(-1) == 1).squeeze(1)
+            img = torch.div(flat_pos, r, rounding_mode="floor")
+            # (positives only exist for images with ground truth, so the gather index is always in range)
+            gt_rows = gt_all[midx.view(-1)[flat_pos] + gt_off[img].long()]
         inv = 1.0 / (self.batch_size_per_image * n)
         loss_cls = ops.bce_logits_sum(logits.contiguous(), lab_all, inv)
         d_rows = d8.reshape(-1, 8)[flat_pos]
