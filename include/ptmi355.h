@@ -247,9 +247,19 @@ int ptmi_preprocess_image(const uint8_t* img, float* out, int h, int w, int hmax
                           float m0, float m1, float m2, float s0, float s1, float s2,
                           ptmi_stream_t s);
 /* trainer.py:557-590 resize: bilinear (align_corners=False) shrink to (dh,dw), truncated to u8,
- * pasted at (y1,x1) on a canvas filled with int(pixel_mean). */
+ * pasted at (y1,x1) on a canvas filled with int(pixel_mean).  Byte-exact with ATen's CPU kernel as the reference
+ * runs it (generic NCHW path, FMA-contracted; see csrc/misc.hip). */
 int ptmi_shrink_paste(const uint8_t* img, uint8_t* out, int h, int w, int dh, int dw, int y1,
                       int x1, int m0, int m1, int m2, ptmi_stream_t s);
+
+/* Whole-batch variants (one launch instead of one per image; the step prepares 64 + 32 images).  `desc` is a DEVICE
+ * array of 8 int64 words per image: [src u8 pointer, dst u8 pointer, h, w, dh, dw, y1, x1] (dst and dh..x1 are ignored
+ * by preprocess; every pointed-to buffer is owned by the caller and must stay alive until the launch has run).
+ * preprocess: out is (n, 3, hmax, wmax) fp32.  shrink_paste: max_elems = max_i 3*h_i*w_i (sizes the grid). */
+int ptmi_preprocess_batched(const int64_t* desc, float* out, int n, int hmax, int wmax, float m0, float m1,
+                            float m2, float s0, float s1, float s2, ptmi_stream_t s);
+int ptmi_shrink_paste_batched(const int64_t* desc, int n, int64_t max_elems, int m0, int m1, int m2,
+                              ptmi_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -145,3 +145,43 @@ void ptref_roi_align_bwd(const float* gout, const float* rois, float* gfeat, int
         }
     }
 }
+
+/* ATen CPU upsample_bilinear2d (align_corners=False), float NCHW input, as the reference reaches it through
+ * F.interpolate at /root/reference/pt/engine/trainer.py:573-576, followed by the float -> uint8 truncation of the
+ * assignment into the uint8 canvas (:573).  ATen's source is not under /root/reference; this restates the evaluation
+ * order of its generic kernel (upsample_generic_Nd_kernel_impl, the path taken with more than one intra-op thread) as
+ * built with FMA contraction, established empirically against torch 2.10 (tools/exp/aten_bilinear_order.py) and
+ * pinned by tests/golden/trainer_pieces.npz (outputs of the real PTrainer.resize) in tests/test_oracle_golden.py:
+ *     src = max(fma(scale, dst + 0.5, -0.5), 0);  i0 = min(floor(src), in-1);  l1 = clamp(src - i0, 0, 1);  l0 = 1 - l1
+ *     t_r = fma(p[r][x0], lx0, p[r][x1] * lx1);   out = fma(t_y0, ly0, t_y1 * ly1)
+ * fmaf() is explicit (this file is compiled with -ffp-contract=off).  out is (3, dh, dw) uint8. */
+static void ptref_src_index(float scale, int dst, int in_size, int* i0, int* i1, float* l0, float* l1)
+{
+    float src = fmaf(scale, (float)dst + 0.5f, -0.5f);
+    if (src < 0.f) src = 0.f;
+    int i = (int)floorf(src);
+    if (i > in_size - 1) i = in_size - 1;
+    float l = src - (float)i;
+    l = l < 0.f ? 0.f : (l > 1.f ? 1.f : l);
+    *i0 = i; *i1 = i + (i < in_size - 1 ? 1 : 0); *l1 = l; *l0 = 1.f - l;
+}
+
+void ptref_bilinear_shrink_u8(const uint8_t* img, uint8_t* out, int c, int h, int w, int dh, int dw)
+{
+    const float sy = (float)h / (float)dh, sx = (float)w / (float)dw;
+    for (int ch = 0; ch < c; ++ch) {
+        const uint8_t* p = img + (int64_t)ch * h * w;
+        for (int oy = 0; oy < dh; ++oy) {
+            int y0, y1; float ly0, ly1;
+            if (dh == h) { y0 = y1 = oy; ly0 = 1.f; ly1 = 0.f; } else ptref_src_index(sy, oy, h, &y0, &y1, &ly0, &ly1);
+            for (int ox = 0; ox < dw; ++ox) {
+                int x0, x1; float lx0, lx1;
+                if (dw == w) { x0 = x1 = ox; lx0 = 1.f; lx1 = 0.f; } else ptref_src_index(sx, ox, w, &x0, &x1, &lx0, &lx1);
+                const float t0 = fmaf((float)p[(int64_t)y0 * w + x0], lx0, (float)p[(int64_t)y0 * w + x1] * lx1);
+                const float t1 = fmaf((float)p[(int64_t)y1 * w + x0], lx0, (float)p[(int64_t)y1 * w + x1] * lx1);
+                const float r = fmaf(t0, ly0, t1 * ly1);
+                out[((int64_t)ch * dh + oy) * dw + ox] = (uint8_t)r;
+            }
+        }
+    }
+}

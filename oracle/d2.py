@@ -40,8 +40,21 @@ def _lib():
             f.restype = None
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + \
                 [ctypes.c_int] * 6 + [ctypes.c_float]
+        lib.ptref_bilinear_shrink_u8.restype = None
+        lib.ptref_bilinear_shrink_u8.argtypes = [ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 5
         _LIB = lib
     return _LIB
+
+
+def bilinear_shrink_u8(img: torch.Tensor, dh: int, dw: int) -> torch.Tensor:
+    """uint8 (C,H,W) -> uint8 (C,dh,dw): ATen's CPU bilinear (align_corners=False) + truncation, in the evaluation
+    order of its multi-threaded generic kernel (ref_ops.c: ptref_bilinear_shrink_u8) -- independent of this host's
+    torch thread count / CPU capability, unlike F.interpolate itself."""
+    img = img.contiguous()
+    assert img.dtype == torch.uint8 and img.dim() == 3
+    out = torch.empty((img.shape[0], dh, dw), dtype=torch.uint8)
+    _lib().ptref_bilinear_shrink_u8(img.data_ptr(), out.data_ptr(), img.shape[0], img.shape[1], img.shape[2], dh, dw)
+    return out
 
 
 def cat(tensors: List[torch.Tensor], dim: int = 0) -> torch.Tensor:

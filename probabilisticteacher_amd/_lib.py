@@ -64,6 +64,8 @@ SIGNATURES = {
     "ptmi_scale_by_clip": (_i, [_vp, _i64, _vp, _f, _vp]),
     "ptmi_preprocess_image": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp]),
     "ptmi_shrink_paste": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_preprocess_batched": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp]),
+    "ptmi_shrink_paste_batched": (_i, [_vp, _i, _i64, _i, _i, _i, _vp]),
 }
 
 _lib = None

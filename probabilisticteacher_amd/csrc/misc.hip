@@ -59,6 +59,15 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
 }
 
 // ---------------------------------------------------------------------------------- image prep
+__device__ __forceinline__ float prep_pixel(const uint8_t* __restrict__ img, int h, int w, int c, int y, int x, float m0,
+                                            float m1, float m2, float s0, float s1, float s2)
+{
+    if (y >= h || x >= w) return 0.f;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+    const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    return ((float)img[((int64_t)c * h + y) * w + x] - mean) / sd;
+}
+
 __global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int h, int w,
                                   int hmax, int wmax, float m0, float m1, float m2, float s0, float s1, float s2)
 {
@@ -67,20 +76,69 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ img, float* __rest
          i += (int64_t)gridDim.x * blockDim.x) {
         const int x = i % wmax;
         const int64_t t = i / wmax;
-        const int y = t % hmax;
-        const int c = t / hmax;
-        float v = 0.f;
-        if (y < h && x < w) {
-            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
-            const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-            v = ((float)img[((int64_t)c * h + y) * w + x] - mean) / sd;
-        }
-        out[i] = v;
+        out[i] = prep_pixel(img, h, w, (int)(t / hmax), (int)(t % hmax), x, m0, m1, m2, s0, s1, s2);
+    }
+}
+
+// whole batch in one launch: blockIdx.y = image; desc = 8 int64 words per image (include/ptmi355.h)
+__global__ void preprocess_batched_kernel(const int64_t* __restrict__ desc, float* __restrict__ out, int hmax, int wmax,
+                                          float m0, float m1, float m2, float s0, float s1, float s2)
+{
+    const int64_t* d = desc + 8 * (int64_t)blockIdx.y;
+    const uint8_t* img = (const uint8_t*)d[0];
+    const int h = (int)d[2], w = (int)d[3];
+    const int64_t total = 3ll * hmax * wmax;
+    float* o = out + (int64_t)blockIdx.y * total;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = i % wmax;
+        const int64_t t = i / wmax;
+        o[i] = prep_pixel(img, h, w, (int)(t / hmax), (int)(t % hmax), x, m0, m1, m2, s0, s1, s2);
     }
 }
 
 // F.interpolate(bilinear, align_corners=False) from (h,w) to (dh,dw), truncated to uint8, pasted at
 // (y1,x1) on a canvas of int(pixel_mean)   (trainer.py:563-575).
+//
+// Byte-exact with ATen's CPU kernel as the reference runs it (float NCHW input, more than one intra-op thread:
+// upsample_generic_Nd_kernel_impl, built with FMA contraction -- verified against torch 2.10 on AVX-512 for 1e6s of
+// pixels, tools/exp/aten_bilinear_order.py):
+//     src   = max(fma(scale, dst + 0.5, -0.5), 0)            scale = float(in) / float(out)
+//     i0    = min(floor(src), in - 1);  l1 = clamp(src - i0, 0, 1);  l0 = 1 - l1;  i1 = i0 + (i0 < in - 1)
+//     t_r   = fma(p[r][x0], lx0, p[r][x1] * lx1)             (row r = y0, y1)
+//     out   = fma(t_y0, ly0, t_y1 * ly1)
+// (-ffp-contract=off for this library: every fused operation is spelled out.)  With a single intra-op thread and
+// C == 3 ATen takes a different (channels-last) kernel whose rounding differs in ~1e-3 of the bytes; the training
+// process of the reference runs with the default thread count (> 1).
+__device__ __forceinline__ void aten_src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l0, float& l1)
+{
+    float src = fmaf(scale, (float)dst + 0.5f, -0.5f);
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)floorf(src);
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    l1 = fminf(fmaxf(src - (float)i0, 0.f), 1.f);
+    l0 = 1.f - l1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+}
+
+__device__ __forceinline__ uint8_t shrink_pixel(const uint8_t* __restrict__ img, int h, int w, int dh, int dw, int y1,
+                                                int x1, int c, int y, int x, int mean_c, float sy, float sx)
+{
+    const int oy = y - y1, ox = x - x1;
+    if (oy < 0 || oy >= dh || ox < 0 || ox >= dw) return (uint8_t)mean_c;
+    int iy0, iy1, ix0, ix1;
+    float ly0, ly1, lx0, lx1;
+    if (dh == h) { iy0 = iy1 = oy; ly0 = 1.f; ly1 = 0.f; } else aten_src_index(sy, oy, h, iy0, iy1, ly0, ly1);
+    if (dw == w) { ix0 = ix1 = ox; lx0 = 1.f; lx1 = 0.f; } else aten_src_index(sx, ox, w, ix0, ix1, lx0, lx1);
+    const uint8_t* p = img + (int64_t)c * h * w;
+    const float t0 = fmaf((float)p[(int64_t)iy0 * w + ix0], lx0, (float)p[(int64_t)iy0 * w + ix1] * lx1);
+    const float t1 = fmaf((float)p[(int64_t)iy1 * w + ix0], lx0, (float)p[(int64_t)iy1 * w + ix1] * lx1);
+    const float r = fmaf(t0, ly0, t1 * ly1);
+    int v = (int)r;                        // float -> uint8 truncation on assignment into the uint8 canvas
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    return (uint8_t)v;
+}
+
 __global__ void shrink_paste_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, int h, int w,
                                     int dh, int dw, int y1, int x1, int m0, int m1, int m2)
 {
@@ -90,27 +148,25 @@ __global__ void shrink_paste_kernel(const uint8_t* __restrict__ img, uint8_t* __
          i += (int64_t)gridDim.x * blockDim.x) {
         const int x = i % w;
         const int64_t t = i / w;
-        const int y = t % h;
-        const int c = t / h;
-        int v = c == 0 ? m0 : (c == 1 ? m1 : m2);
-        const int oy = y - y1, ox = x - x1;
-        if (oy >= 0 && oy < dh && ox >= 0 && ox < dw) {
-            // ATen area_pixel_compute_source_index(align_corners=False): max(scale*(dst+0.5)-0.5, 0)
-            float fy = sy * ((float)oy + 0.5f) - 0.5f;
-            float fx = sx * ((float)ox + 0.5f) - 0.5f;
-            fy = fy < 0.f ? 0.f : fy;
-            fx = fx < 0.f ? 0.f : fx;
-            const int iy = (int)fy, ix = (int)fx;
-            const int iy1 = iy + (iy < h - 1 ? 1 : 0), ix1 = ix + (ix < w - 1 ? 1 : 0);
-            const float ly = fy - (float)iy, lx = fx - (float)ix;
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            const uint8_t* p = img + (int64_t)c * h * w;
-            const float r = hy * (hx * (float)p[(int64_t)iy * w + ix] + lx * (float)p[(int64_t)iy * w + ix1]) +
-                            ly * (hx * (float)p[(int64_t)iy1 * w + ix] + lx * (float)p[(int64_t)iy1 * w + ix1]);
-            v = (int)r;   // float -> uint8 truncation on assignment into the uint8 canvas
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
-        }
-        out[i] = (uint8_t)v;
+        const int c = (int)(t / h);
+        out[i] = shrink_pixel(img, h, w, dh, dw, y1, x1, c, (int)(t % h), x, c == 0 ? m0 : (c == 1 ? m1 : m2), sy, sx);
+    }
+}
+
+__global__ void shrink_paste_batched_kernel(const int64_t* __restrict__ desc, int m0, int m1, int m2)
+{
+    const int64_t* d = desc + 8 * (int64_t)blockIdx.y;
+    const uint8_t* img = (const uint8_t*)d[0];
+    uint8_t* out = (uint8_t*)d[1];
+    const int h = (int)d[2], w = (int)d[3], dh = (int)d[4], dw = (int)d[5], y1 = (int)d[6], x1 = (int)d[7];
+    const int64_t total = 3ll * h * w;
+    const float sy = (float)h / (float)dh, sx = (float)w / (float)dw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = i % w;
+        const int64_t t = i / w;
+        const int c = (int)(t / h);
+        out[i] = shrink_pixel(img, h, w, dh, dw, y1, x1, c, (int)(t % h), x, c == 0 ? m0 : (c == 1 ? m1 : m2), sy, sx);
     }
 }
 
@@ -236,6 +292,31 @@ int ptmi_shrink_paste(const uint8_t* img, uint8_t* out, int h, int w, int dh, in
     hipLaunchKernelGGL(shrink_paste_kernel, dim3(grid_for(3ll * h * w)), dim3(256), 0, (hipStream_t)s, img, out, h,
                        w, dh, dw, y1, x1, m0, m1, m2);
     PTMI_LAUNCH_CHECK("shrink_paste");
+    return 0;
+}
+
+int ptmi_preprocess_batched(const int64_t* desc, float* out, int n, int hmax, int wmax, float m0, float m1, float m2,
+                            float s0, float s1, float s2, ptmi_stream_t s)
+{
+    if (n == 0) return 0;
+    PTMI_CHECK_ARG(desc && out && n > 0 && n < 65536 && hmax > 0 && wmax > 0, "preprocess_batched: bad args");
+    const int64_t per = 3ll * hmax * wmax;
+    int bx = (int)((per + 1023) / 1024);                      // ~4 elements per thread
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(preprocess_batched_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)s, desc, out, hmax, wmax, m0,
+                       m1, m2, s0, s1, s2);
+    PTMI_LAUNCH_CHECK("preprocess_batched");
+    return 0;
+}
+
+int ptmi_shrink_paste_batched(const int64_t* desc, int n, int64_t max_elems, int m0, int m1, int m2, ptmi_stream_t s)
+{
+    if (n == 0) return 0;
+    PTMI_CHECK_ARG(desc && n > 0 && n < 65536 && max_elems > 0, "shrink_paste_batched: bad args");
+    int bx = (int)((max_elems + 1023) / 1024);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(shrink_paste_batched_kernel, dim3(bx, n), dim3(256), 0, (hipStream_t)s, desc, m0, m1, m2);
+    PTMI_LAUNCH_CHECK("shrink_paste_batched");
     return 0;
 }
 

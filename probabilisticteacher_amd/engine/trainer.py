@@ -81,12 +81,14 @@ class PTrainer:
 
     # ------------------------------------------------------------------ resize (trainer.py:557-590)
     def resize(self, data: List[dict]) -> List[dict]:
-        out = []
+        """One launch for the images of the whole list (ops.shrink_paste_batch); boxes are rescaled with the same
+        three in-place fp32 steps as the reference (`*= ratio`, `+= x1`, `+= y1`)."""
         dev = self.model.device
-        for rec in data:
-            img = rec["image"].to(dev, non_blocking=True)
-            ratio = self._ratio_fn()
-            canvas, x1, y1 = ops.shrink_paste(img, ratio, self._mean_int)
+        images = [rec["image"].to(dev, non_blocking=True) for rec in data]
+        ratios = [self._ratio_fn() for _ in data]
+        canvases, offsets = ops.shrink_paste_batch(images, ratios, self._mean_int)
+        out = []
+        for rec, canvas, ratio, (x1, y1) in zip(data, canvases, ratios, offsets):
             new = dict(rec)
             new["image"] = canvas
             inst = rec["instances"]

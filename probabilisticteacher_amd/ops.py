@@ -783,26 +783,59 @@ def scale_by_clip(g, sumsq_t, clip_norm) -> None:
     _lib.call("ptmi_scale_by_clip", _ptr(_chk(g)), g.numel(), _ptr(sumsq_t), float(clip_norm), _stream())
 
 
+def _image_desc(rows, device) -> torch.Tensor:
+    """rows of 8 ints -> device int64 descriptor table (pinned staging, async copy: no stream synchronisation)."""
+    return torch.tensor(rows, dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+
+
 def preprocess_images(images_u8: List[torch.Tensor], mean: Sequence[float], std: Sequence[float]):
-    """D2 preprocess_image + ImageList.from_tensors: (x-mean)/std, zero pad to the batch max."""
+    """D2 preprocess_image + ImageList.from_tensors: (x-mean)/std, zero pad to the batch max; ONE launch per batch."""
     hmax = max(im.shape[-2] for im in images_u8)
     wmax = max(im.shape[-1] for im in images_u8)
     dev = images_u8[0].device
+    images_u8 = [_chk(im.contiguous(), torch.uint8, "image") for im in images_u8]
     out = torch.empty((len(images_u8), 3, hmax, wmax), dtype=F32, device=dev)
-    for i, im in enumerate(images_u8):
-        im = _chk(im.contiguous(), torch.uint8, "image")
-        _lib.call("ptmi_preprocess_image", _ptr(im), _ptr(out[i]), im.shape[-2], im.shape[-1], hmax, wmax,
-                  float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _stream())
+    desc = _image_desc([[im.data_ptr(), 0, im.shape[-2], im.shape[-1], 0, 0, 0, 0] for im in images_u8], dev)
+    _lib.call("ptmi_preprocess_batched", _ptr(desc), _ptr(out), len(images_u8), hmax, wmax, float(mean[0]), float(mean[1]),
+              float(mean[2]), float(std[0]), float(std[1]), float(std[2]), _stream())
     return out
 
 
+def shrink_paste_geometry(h: int, w: int, ratio: float) -> Tuple[int, int, int, int]:
+    """(dh, dw, x1, y1) of trainer.py:563-566."""
+    dh, dw = int(h * ratio), int(w * ratio)
+    return dh, dw, int((w - dw) / 2), int((h - dh) / 2)
+
+
 def shrink_paste(img_u8: torch.Tensor, ratio: float, mean_int: Sequence[int]) -> Tuple[torch.Tensor, int, int]:
-    """trainer.py:557-590 image part; returns (canvas, x1, y1)."""
+    """trainer.py:557-590 image part for one image; returns (canvas, x1, y1)."""
     img_u8 = _chk(img_u8.contiguous(), torch.uint8, "image")
     h, w = img_u8.shape[-2:]
-    dh, dw = int(h * ratio), int(w * ratio)
-    x1, y1 = int((w - dw) / 2), int((h - dh) / 2)
+    dh, dw, x1, y1 = shrink_paste_geometry(h, w, ratio)
     out = torch.empty_like(img_u8)
     _lib.call("ptmi_shrink_paste", _ptr(img_u8), _ptr(out), h, w, dh, dw, y1, x1, int(mean_int[0]), int(mean_int[1]),
               int(mean_int[2]), _stream())
     return out, x1, y1
+
+
+def shrink_paste_batch(images_u8: List[torch.Tensor], ratios: Sequence[float], mean_int: Sequence[int]):
+    """trainer.py:557-590 image part for a whole batch in ONE launch; returns (canvases, [(x1, y1), ...])."""
+    images_u8 = [_chk(im.contiguous(), torch.uint8, "image") for im in images_u8]
+    if not images_u8:
+        return [], []
+    dev = images_u8[0].device
+    sizes = [3 * im.shape[-2] * im.shape[-1] for im in images_u8]
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    outs, rows, offs, o = [], [], [], 0
+    for im, ratio, sz in zip(images_u8, ratios, sizes):
+        h, w = im.shape[-2:]
+        dh, dw, x1, y1 = shrink_paste_geometry(h, w, ratio)
+        canvas = buf[o:o + sz].view(3, h, w)
+        o += sz
+        outs.append(canvas)
+        offs.append((x1, y1))
+        rows.append([im.data_ptr(), canvas.data_ptr(), h, w, dh, dw, y1, x1])
+    desc = _image_desc(rows, dev)
+    _lib.call("ptmi_shrink_paste_batched", _ptr(desc), len(images_u8), max(sizes), int(mean_int[0]), int(mean_int[1]),
+              int(mean_int[2]), _stream())
+    return outs, offs

@@ -11,8 +11,15 @@ import torch
 import torch.nn.functional as F
 
 from oracle import d2, pt as opt
+from tests.helpers import load, records
 
 pytestmark = pytest.mark.gpu
+
+
+def _raw():
+    """(call, ptr, stream) for tests that drive a C-ABI entry point directly"""
+    from probabilisticteacher_amd import _lib, ops as _ops
+    return _lib.call, _ops._ptr, _ops._stream
 
 
 @pytest.fixture(scope="module")
@@ -474,22 +481,54 @@ def test_ema_clip_sgd(ops):
         close(pd, p - 0.016 * b2, 1e-5, 1e-6, "param")
 
 
+def _paste_ref(cfg, img, ratio):
+    """canvas of trainer.py:563-576 with the shrink computed by the oracle's C restatement of ATen's evaluation order"""
+    h, w = img.shape[-2:]
+    dh, dw = int(h * ratio), int(w * ratio)
+    x1, y1 = int((w - dw) / 2), int((h - dh) / 2)
+    bg = torch.zeros_like(img)
+    bg += torch.tensor(cfg.pixel_mean).view(3, 1, 1).int()
+    bg[:, y1:y1 + dh, x1:x1 + dw] = d2.bilinear_shrink_u8(img, dh, dw)
+    return bg, x1, y1
+
+
 def test_preprocess_and_shrink_paste(ops):
+    """Byte outputs are BIT-EXACT: preprocess vs the oracle; shrink_paste vs (a) the uint8 canvases the REAL reference
+    produced (tests/golden/trainer_pieces.npz), (b) the oracle at toy and BASELINE (1333x800) size, single-image and
+    whole-batch entry points."""
     cfg = opt.Cfg()
+    mean_int = [int(m) for m in cfg.pixel_mean]
     rs = np.random.RandomState(1)
     imgs = [torch.from_numpy(rs.randint(0, 256, (3, 50, 70)).astype(np.uint8)),
             torch.from_numpy(rs.randint(0, 256, (3, 44, 61)).astype(np.uint8))]
     ref = opt.preprocess_image(cfg, [{"image": im} for im in imgs]).tensor
-    got = ops.preprocess_images([im.to(DEV) for im in imgs], cfg.pixel_mean, cfg.pixel_std)
+    got = ops.preprocess_images([im.to(DEV) for im in imgs], cfg.pixel_mean, cfg.pixel_std)      # batched launch
     assert torch.equal(got.cpu(), ref), "preprocess must be bit-exact"
-    inst = opt.FreeInstances((50, 70))
-    inst.gt_boxes = d2.Boxes(torch.tensor([[1.0, 2.0, 30.0, 40.0]]))
-    for ratio in (0.731, 0.5, 0.999):
-        ref_rec = opt.shrink_paste(cfg, {"image": imgs[0], "instances": inst}, ratio)
-        out, x1, y1 = ops.shrink_paste(imgs[0].to(DEV), ratio, [int(m) for m in cfg.pixel_mean])
-        diff = (out.cpu().int() - ref_rec["image"].int()).abs()
-        # truncation of a float that sits within rounding of an integer may flip by 1 (FMA vs no FMA)
-        assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 1e-3, "shrink_paste mismatch"
+    one = torch.empty((3, 50, 70), device=DEV)
+    im0 = imgs[0].to(DEV)
+    call, _p, _stream = _raw()
+    call("ptmi_preprocess_image", _p(im0), _p(one), 50, 70, 50, 70, *[float(v) for v in cfg.pixel_mean],
+         *[float(v) for v in cfg.pixel_std], _stream())
+    assert torch.equal(one.cpu(), ref[0]), "single-image preprocess must be bit-exact"
+    # (a) the real reference's PTrainer.resize outputs
+    z = load("trainer_pieces")
+    recs = records(z, "rz_in", 2)
+    for i, (r, q) in enumerate(zip(recs, z["rz_ratios"])):
+        out, _, _ = ops.shrink_paste(r["image"].to(DEV), float(q), mean_int)
+        assert np.array_equal(out.cpu().numpy(), z[f"rz_out{i}_image"]), "shrink_paste vs the reference's canvas"
+    outs, _ = ops.shrink_paste_batch([r["image"].to(DEV) for r in recs], [float(q) for q in z["rz_ratios"]], mean_int)
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy(), z[f"rz_out{i}_image"]), "batched shrink_paste vs the reference's canvas"
+    # (b) oracle, toy sizes (incl. ratio 1.0: identity copy) and BASELINE size
+    big = torch.from_numpy(rs.randint(0, 256, (3, 800, 1333)).astype(np.uint8))
+    cases = [(imgs[0], r) for r in (0.731, 0.5, 0.999, 1.0)] + [(imgs[1], 0.6180339)] + [(big, r) for r in (0.5, 0.83, 0.99999)]
+    for im, ratio in cases:
+        want, x1r, y1r = _paste_ref(cfg, im, ratio)
+        out, x1, y1 = ops.shrink_paste(im.to(DEV), ratio, mean_int)
+        assert (x1, y1) == (x1r, y1r) and torch.equal(out.cpu(), want), f"shrink_paste {tuple(im.shape)} ratio {ratio}"
+    outs, offs = ops.shrink_paste_batch([im.to(DEV) for im, _ in cases], [r for _, r in cases], mean_int)
+    for (im, ratio), o in zip(cases, outs):
+        assert torch.equal(o.cpu(), _paste_ref(cfg, im, ratio)[0]), f"batched shrink_paste ratio {ratio}"
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 37, 45), (1, 128, 128, 20, 83), (1, 3, 64, 24, 33)])

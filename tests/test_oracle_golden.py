@@ -41,8 +41,24 @@ def test_trainer_pieces_match_reference():
     for i, (r, q) in enumerate(zip(recs, z["rz_ratios"])):
         out = opt.shrink_paste(cfg, r, float(q))
         assert np.array_equal(out["image"].numpy(), z[f"rz_out{i}_image"]), "resize image must be bit-exact"
+        # the C restatement of ATen's evaluation order (what the HIP kernel is checked against at full size, on hosts
+        # whose torch build / thread count may round differently) reproduces the real reference's bytes as well
+        h, w = r["image"].shape[-2:]
+        dh, dw = int(h * float(q)), int(w * float(q))
+        x1, y1 = int((w - dw) / 2), int((h - dh) / 2)
+        assert np.array_equal(d2.bilinear_shrink_u8(r["image"], dh, dw).numpy(),
+                              z[f"rz_out{i}_image"][:, y1:y1 + dh, x1:x1 + dw]), "ptref_bilinear_shrink_u8 vs reference"
         close(out["instances"].gt_boxes.tensor, z[f"rz_out{i}_gt_boxes"], 1e-6, 1e-5, "resize boxes")
     close(out["instances"].pseudo_boxes.tensor, z["rz_out1_pseudo_boxes"], 1e-6, 1e-5, "resize pseudo boxes")
+    # ... and equals F.interpolate itself on this host (multi-threaded generic ATen kernel) at BASELINE size
+    if torch.get_num_threads() > 1:
+        import torch.nn.functional as F
+        img = torch.from_numpy(np.random.RandomState(5).randint(0, 256, (3, 800, 1333)).astype(np.uint8))
+        for ratio in (0.5, 0.731, 0.9999, 1.0):
+            dh, dw = int(800 * ratio), int(1333 * ratio)
+            ref = torch.zeros((3, dh, dw), dtype=torch.uint8)
+            ref[:] = F.interpolate(img.unsqueeze(0).float(), size=(dh, dw), align_corners=False, mode="bilinear")[0]
+            assert torch.equal(d2.bilinear_shrink_u8(img, dh, dw), ref), f"ratio {ratio}"
     # inputs of shrink_paste are not mutated
     assert np.array_equal(recs[0]["instances"].gt_boxes.tensor.numpy(), z["rz_in0_gt_boxes"])
     # EMA
