@@ -163,25 +163,51 @@ int ptmi_segsort_desc(const float* keys_in, float* keys_out, int32_t* idx_out, i
                       int nseg, const int32_t* seg_offsets, void* ws, int64_t ws_bytes,
                       ptmi_stream_t s);
 /* proposal_utils.py:92-138 for one batch: for image i and rank j < k:
- *   box = clip(decoded[i][sorted_idx[i][j]], image_size[i]); valid = finite & w>min & h>min;
+ *   box = clip(decoded[i][sorted_idx[i][j]], image_size[i]); kept = finite & w>min & h>min;
  *   score = sorted_logit[i][j] * (1 - mean4(sigmoid(sigma_logits[i][j])))   <- row j, NOT idx (:94)
- * Outputs dense (n,k,*) plus valid (uint8) and nonfinite flag per image. */
+ * Outputs dense (n,k,*): boxes, keys = score for kept entries / -inf for dropped ones (a stable descending sort of the
+ * keys lists the kept entries in the order batched_nms visits them), the number of kept entries and a nonfinite flag
+ * per image -- no host synchronisation is needed before NMS. */
 int ptmi_rpn_prepare(const float* decoded, const float* sorted_logits, const int32_t* sorted_idx,
                      const float* sigma_logits, const float* image_sizes_hw, float* boxes_out,
-                     float* scores_out, uint8_t* valid_out, int32_t* nonfinite_out, int n,
+                     float* keys_out, int32_t* counts_out, int32_t* nonfinite_out, int n,
                      int64_t r, int k, float min_size, ptmi_stream_t s);
 
 /* ------------------------------------------------------------------ NMS (N11)
  * replaces torchvision nms (detectron2 batched_nms) at proposal_utils.py:140, fast_rcnn.py:104.
  * Batched over `nimg` images: boxes (sum counts,4) ALREADY sorted by descending score per image,
- * seg_offsets (nimg+1) int32.  keep_out (nimg, max_keep) int32 = positions within the image's
- * sorted list, keep_count (nimg) int32.  Suppress iff IoU > thr (strict), IoU evaluated as
- * inter/(area_i+area_j-inter) in fp32 without FMA contraction => bit-exact vs the CPU oracle.
- * ws: ptmi_nms_ws_bytes(max_count, nimg). */
+ * seg_offsets (nimg+1) int32; seg_counts (nimg) int32 or NULL: only the first seg_counts[i] boxes of segment i exist
+ * (fixed-capacity segments whose fill level is known on the device only).  keep_out (nimg, max_keep) int32 =
+ * positions within the image's sorted list, keep_count (nimg) int32.  Suppress iff IoU > thr (strict), IoU evaluated
+ * as inter/(area_i+area_j-inter) in fp32 without FMA contraction => bit-exact vs the CPU oracle.
+ * ws: ptmi_nms_ws_bytes(max_count, nimg), max_count = largest segment capacity. */
 int64_t ptmi_nms_ws_bytes(int64_t max_count, int nimg);
-int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, int nimg, int64_t max_count,
-                     float thr, int max_keep, int32_t* keep_out, int32_t* keep_count, void* ws,
-                     ptmi_stream_t s);
+int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_counts, int nimg,
+                     int64_t max_count, float thr, int max_keep, int32_t* keep_out, int32_t* keep_count,
+                     void* ws, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ teacher ROI inference (N12)
+ * fast_rcnn.py:34-101 (fast_rcnn_inference_single_image up to the NMS call) for all R ROIs of a batch: decode the K
+ * mean quadruples of deltas (R, 8K) on proposal_boxes (R,4) with weights (wx,wy,ww,wh) (:63 drops the sigma
+ * quadruples), finite filter over a ROI's K boxes and K+1 probabilities (:67), clip to the image roi_img[r] (:78),
+ * probs[r][j] > score_thresh (:85), score *= 1 - mean4(sigmoid(sigma logits)) (:101).
+ * Outputs dense over (roi, class): boxes_out (R,K,4) clipped; keys_out (R,K) = rescored score of a candidate, -1
+ * otherwise (scores are > 0: a stable descending sort of an image's keys lists its candidates in batched_nms order);
+ * img_max_out (nimg) = largest candidate coordinate, img_count_out (nimg) = number of candidates;
+ * roi_valid_out (R) u8 = the finite filter's verdict, img_invalid_out (nimg) = ROIs it dropped (the reference indexes
+ * `scores_logists` and the returned ROI indices by position in the FILTERED list, :96,:126). */
+int ptmi_roi_infer_prepare(const float* deltas, const float* proposal_boxes, const float* probs,
+                           const int32_t* roi_img, const float* image_sizes_hw, float* boxes_out,
+                           float* keys_out, uint8_t* roi_valid_out, float* img_max_out,
+                           int32_t* img_count_out, int32_t* img_invalid_out, int64_t r, int k, int nimg,
+                           float wx, float wy, float ww, float wh, float scale_clamp, float score_thresh,
+                           ptmi_stream_t s);
+/* torchvision batched_nms class offset (fast_rcnn.py:104): out[beg_i + p] = boxes[beg_i + order[beg_i + p]] +
+ * (order[..] % k) * (img_max[i] + 1) in fp32, for the dense per-image segments seg_offsets (nimg+1) of (roi, class)
+ * entries; max_count = largest segment. */
+int ptmi_roi_infer_nms_boxes(const float* boxes, const int32_t* order, const int32_t* seg_offsets,
+                             const float* img_max, int nimg, int max_count, int k, float* out,
+                             ptmi_stream_t s);
 
 /* ------------------------------------------------------------------ losses (N7, N8, N14)
  * Every loss kernel writes the scalar loss (already normalised) to loss_out[0] and the gradient

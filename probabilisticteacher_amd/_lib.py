@@ -49,7 +49,9 @@ SIGNATURES = {
     "ptmi_segsort_desc": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
     "ptmi_rpn_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp]),
     "ptmi_nms_ws_bytes": (_i64, [_i64, _i]),
-    "ptmi_nms_batched": (_i, [_vp, _vp, _i, _i64, _f, _i, _vp, _vp, _vp, _vp]),
+    "ptmi_nms_batched": (_i, [_vp, _vp, _vp, _i, _i64, _f, _i, _vp, _vp, _vp, _vp]),
+    "ptmi_roi_infer_prepare": (_i, [_vp] * 11 + [_i64, _i, _i, _f, _f, _f, _f, _f, _f, _vp]),
+    "ptmi_roi_infer_nms_boxes": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ptmi_bce_logits_sum": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp]),
     "ptmi_gaussian_nll_sum": (_i, [_vp, _vp, _i64, _f, _vp, _vp, _vp, _vp, _vp]),
     "ptmi_softmax_ce_mean": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp]),

@@ -23,7 +23,22 @@ __global__ void grid_anchors_kernel(const float* __restrict__ cell, float* __res
     }
 }
 
-// box_regression.py:101-139.  One thread per (row, k) decoded box.
+// box_regression.py:101-139: decode one (dx, dy, dw, dh) quadruple on box b.
+__device__ __forceinline__ float4 decode_box(const float4 b, const float* __restrict__ d, float wx, float wy, float ww,
+                                             float wh, float clampv)
+{
+    const float widths = b.z - b.x, heights = b.w - b.y;
+    const float cx = b.x + 0.5f * widths, cy = b.y + 0.5f * heights;
+    const float dx = d[0] / wx, dy = d[1] / wy;
+    float dw = d[2] / ww, dh = d[3] / wh;
+    dw = fminf(dw, clampv);
+    dh = fminf(dh, clampv);
+    const float pcx = dx * widths + cx, pcy = dy * heights + cy;
+    const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+    return make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+}
+
+// One thread per (row, k) decoded box.
 __global__ void apply_deltas_kernel(const float* __restrict__ deltas, const float* __restrict__ boxes,
                                     float* __restrict__ out, int64_t rows, int k, int dstride, int64_t nb,
                                     float wx, float wy, float ww, float wh, float clampv)
@@ -33,21 +48,10 @@ __global__ void apply_deltas_kernel(const float* __restrict__ deltas, const floa
          i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / k;
         const int j = i % k;
-        const float4 b = reinterpret_cast<const float4*>(boxes)[row % nb];
-        const float* d = deltas + row * dstride + 4 * j;
-        const float widths = b.z - b.x, heights = b.w - b.y;
-        const float cx = b.x + 0.5f * widths, cy = b.y + 0.5f * heights;
-        const float dx = d[0] / wx, dy = d[1] / wy;
-        float dw = d[2] / ww, dh = d[3] / wh;
-        dw = fminf(dw, clampv);
-        dh = fminf(dh, clampv);
-        const float pcx = dx * widths + cx, pcy = dy * heights + cy;
-        const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+        const float4 o4 = decode_box(reinterpret_cast<const float4*>(boxes)[row % nb], deltas + row * dstride + 4 * j,
+                                     wx, wy, ww, wh, clampv);
         float* o = out + row * (int64_t)(4 * k) + 4 * j;
-        o[0] = pcx - 0.5f * pw;
-        o[1] = pcy - 0.5f * ph;
-        o[2] = pcx + 0.5f * pw;
-        o[3] = pcy + 0.5f * ph;
+        o[0] = o4.x; o[1] = o4.y; o[2] = o4.z; o[3] = o4.w;
     }
 }
 
@@ -332,7 +336,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __global__ void rpn_prepare_kernel(const float* __restrict__ decoded, const float* __restrict__ slog,
                                    const int32_t* __restrict__ sidx, const float* __restrict__ sigma,
                                    const float* __restrict__ sizes, float* __restrict__ boxes_out,
-                                   float* __restrict__ scores_out, uint8_t* __restrict__ valid_out,
+                                   float* __restrict__ keys_out, int32_t* __restrict__ counts,
                                    int32_t* __restrict__ nonfinite, int n, int64_t R, int k, float min_size)
 {
     const int64_t total = (int64_t)n * k;
@@ -356,9 +360,101 @@ __global__ void rpn_prepare_kernel(const float* __restrict__ decoded, const floa
         const float4 s4 = reinterpret_cast<const float4*>(sigma)[(int64_t)img * R + j];
         const float ssum = ((sigmoidf_(s4.x) + sigmoidf_(s4.y)) + sigmoidf_(s4.z)) + sigmoidf_(s4.w);
         const float rescore = sc * (1.f - ssum / 4.0f);
+        const bool valid = fin && ne;
         reinterpret_cast<float4*>(boxes_out)[i] = c;
-        scores_out[i] = rescore;
-        valid_out[i] = (uint8_t)(fin && ne);
+        // dropped entries (non-finite / empty after clipping) sort behind every kept one: the stable descending sort
+        // of the keys then yields exactly the order of the reference's filtered list
+        keys_out[i] = valid ? rescore : -INFINITY;
+        // one atomic per wave and image: peel off the lanes of one image at a time (wave-uniform loop)
+        const unsigned long long m = __ballot(valid);
+        unsigned long long rem = __ballot(true);
+        const int lane = threadIdx.x & 63;
+        while (rem) {
+            const int leader = __ffsll(rem) - 1;
+            const int limg = __shfl(img, leader, 64);
+            const unsigned long long grp = __ballot(img == limg);
+            if (lane == leader) {
+                const int c0 = __popcll(m & grp);
+                if (c0) atomicAdd(counts + limg, c0);
+            }
+            rem &= ~grp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- ROI inference prepare
+// fast_rcnn.py:34-101 for all ROIs of a batch in one pass (one thread per ROI): decode the K mean quadruples
+// (:63 drops the sigma quadruples), finite filter over the ROI's K boxes and K+1 probabilities (:67), clip to the
+// ROI's image (:78), score threshold on the foreground probabilities (:85), sigma rescoring (:101).  Outputs are dense
+// over (roi, class): clipped boxes, and a sort key = rescored score for candidates / -1 otherwise (scores are > 0, so
+// a stable descending sort of the keys lists an image's candidates in exactly the order batched_nms visits them);
+// per image the candidate count and the largest candidate coordinate (torchvision's batched_nms class offset is
+// boxes + cls * (max + 1)).  Coordinates are >= 0 after clipping, so the float max is an integer max on the bits.
+// roi_valid / img_invalid: the finite filter's verdict per ROI and the number of dropped ROIs per image (the reference
+// indexes its outputs by position in the FILTERED list, fast_rcnn.py:96,126 -- the caller remaps when any were dropped).
+__global__ void roi_infer_prepare_kernel(const float* __restrict__ deltas, const float* __restrict__ pboxes,
+                                         const float* __restrict__ probs, const int32_t* __restrict__ roi_img,
+                                         const float* __restrict__ sizes, float* __restrict__ boxes_out,
+                                         float* __restrict__ keys_out, uint8_t* __restrict__ roi_valid,
+                                         unsigned* __restrict__ img_max, int32_t* __restrict__ img_cnt,
+                                         int32_t* __restrict__ img_invalid, int64_t R, int K, float wx, float wy,
+                                         float ww, float wh, float clampv, float thresh)
+{
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const float4 b = reinterpret_cast<const float4*>(pboxes)[r];
+        const int img = roi_img[r];
+        const float H = sizes[2 * img], W = sizes[2 * img + 1];
+        const float* d = deltas + r * (int64_t)(8 * K);
+        const float* p = probs + r * (int64_t)(K + 1);
+        bool fin = isfinite(p[K]);
+        for (int j = 0; j < K; ++j) {
+            const float4 o = decode_box(b, d + 8 * j, wx, wy, ww, wh, clampv);
+            fin = fin && isfinite(o.x) && isfinite(o.y) && isfinite(o.z) && isfinite(o.w) && isfinite(p[j]);
+            float4 c;
+            c.x = fminf(fmaxf(o.x, 0.f), W);
+            c.y = fminf(fmaxf(o.y, 0.f), H);
+            c.z = fminf(fmaxf(o.z, 0.f), W);
+            c.w = fminf(fmaxf(o.w, 0.f), H);
+            reinterpret_cast<float4*>(boxes_out)[r * K + j] = c;
+        }
+        roi_valid[r] = (uint8_t)fin;
+        if (!fin) atomicAdd(img_invalid + img, 1);
+        int cnt = 0;
+        float mx = 0.f;
+        for (int j = 0; j < K; ++j) {
+            const bool cand = fin && p[j] > thresh;
+            float key = -1.f;
+            if (cand) {
+                const float* sg = d + 8 * j + 4;
+                const float ssum = ((sigmoidf_(sg[0]) + sigmoidf_(sg[1])) + sigmoidf_(sg[2])) + sigmoidf_(sg[3]);
+                key = p[j] * (1.f - ssum / 4.0f);
+                const float4 c = reinterpret_cast<const float4*>(boxes_out)[r * K + j];
+                mx = fmaxf(mx, fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)));
+                ++cnt;
+            }
+            keys_out[r * K + j] = key;
+        }
+        if (cnt) {
+            atomicAdd(img_cnt + img, cnt);
+            atomicMax(img_max + img, __float_as_uint(mx));
+        }
+    }
+}
+
+// boxes handed to NMS, in sorted order: box + cls * (max coordinate of the image's candidates + 1), fp32 (torchvision
+// batched_nms).  grid.y = image; `order` = position within the image's dense (roi, class) segment.
+__global__ void roi_infer_nms_boxes_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ order,
+                                           const int32_t* __restrict__ seg, const unsigned* __restrict__ img_max,
+                                           int K, float* __restrict__ out)
+{
+    const int img = blockIdx.y;
+    const int beg = seg[img], n = seg[img + 1] - beg;
+    const float off1 = __uint_as_float(img_max[img]) + 1.0f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int dpos = order[beg + i];
+        const float off = (float)(dpos % K) * off1;
+        const float4 b = reinterpret_cast<const float4*>(boxes)[beg + dpos];
+        reinterpret_cast<float4*>(out)[beg + i] = make_float4(b.x + off, b.y + off, b.z + off, b.w + off);
     }
 }
 
@@ -494,20 +590,58 @@ int ptmi_sample_by_keys(const int64_t* cls_all, const float* keys_all, const int
 }
 
 int ptmi_rpn_prepare(const float* decoded, const float* sorted_logits, const int32_t* sorted_idx,
-                     const float* sigma_logits, const float* image_sizes_hw, float* boxes_out, float* scores_out,
-                     uint8_t* valid_out, int32_t* nonfinite_out, int n, int64_t r, int k, float min_size,
+                     const float* sigma_logits, const float* image_sizes_hw, float* boxes_out, float* keys_out,
+                     int32_t* counts_out, int32_t* nonfinite_out, int n, int64_t r, int k, float min_size,
                      ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(decoded && sorted_logits && sorted_idx && sigma_logits && image_sizes_hw && boxes_out &&
-                       scores_out && valid_out && nonfinite_out && n > 0 && r > 0 && k > 0 && k <= r,
+                       keys_out && counts_out && nonfinite_out && n > 0 && r > 0 && k > 0 && k <= r,
                    "rpn_prepare: bad args");
     hipStream_t st = (hipStream_t)s;
     hipError_t e = hipMemsetAsync(nonfinite_out, 0, sizeof(int32_t) * (size_t)n, st);
+    if (e == hipSuccess) e = hipMemsetAsync(counts_out, 0, sizeof(int32_t) * (size_t)n, st);
     if (e != hipSuccess) { ptmi_set_error("rpn_prepare: memset failed"); return -2; }
     hipLaunchKernelGGL(rpn_prepare_kernel, dim3(grid_for((int64_t)n * k)), dim3(256), 0, st, decoded, sorted_logits,
-                       sorted_idx, sigma_logits, image_sizes_hw, boxes_out, scores_out, valid_out, nonfinite_out, n, r,
+                       sorted_idx, sigma_logits, image_sizes_hw, boxes_out, keys_out, counts_out, nonfinite_out, n, r,
                        k, min_size);
     PTMI_LAUNCH_CHECK("rpn_prepare");
+    return 0;
+}
+
+int ptmi_roi_infer_prepare(const float* deltas, const float* proposal_boxes, const float* probs, const int32_t* roi_img,
+                           const float* image_sizes_hw, float* boxes_out, float* keys_out, uint8_t* roi_valid_out,
+                           float* img_max_out, int32_t* img_count_out, int32_t* img_invalid_out, int64_t r, int k,
+                           int nimg, float wx, float wy, float ww, float wh, float scale_clamp, float score_thresh,
+                           ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(nimg > 0 && k > 0 && r >= 0 && img_max_out && img_count_out && img_invalid_out,
+                   "roi_infer_prepare: bad args");
+    hipStream_t st = (hipStream_t)s;
+    hipError_t e = hipMemsetAsync(img_max_out, 0, sizeof(float) * (size_t)nimg, st);
+    if (e == hipSuccess) e = hipMemsetAsync(img_count_out, 0, sizeof(int32_t) * (size_t)nimg, st);
+    if (e == hipSuccess) e = hipMemsetAsync(img_invalid_out, 0, sizeof(int32_t) * (size_t)nimg, st);
+    if (e != hipSuccess) { ptmi_set_error("roi_infer_prepare: memset failed"); return -2; }
+    if (r == 0) return 0;
+    PTMI_CHECK_ARG(deltas && proposal_boxes && probs && roi_img && image_sizes_hw && boxes_out && keys_out && roi_valid_out,
+                   "roi_infer_prepare: null buffer");
+    hipLaunchKernelGGL(roi_infer_prepare_kernel, dim3(grid_for(r)), dim3(256), 0, st, deltas, proposal_boxes, probs,
+                       roi_img, image_sizes_hw, boxes_out, keys_out, roi_valid_out,
+                       reinterpret_cast<unsigned*>(img_max_out), img_count_out, img_invalid_out, r, k, wx, wy, ww, wh,
+                       scale_clamp, score_thresh);
+    PTMI_LAUNCH_CHECK("roi_infer_prepare");
+    return 0;
+}
+
+int ptmi_roi_infer_nms_boxes(const float* boxes, const int32_t* order, const int32_t* seg_offsets, const float* img_max,
+                             int nimg, int max_count, int k, float* out, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(seg_offsets && img_max && nimg > 0 && nimg < 65536 && max_count >= 0 && k > 0,
+                   "roi_infer_nms_boxes: bad args");
+    if (max_count == 0) return 0;
+    PTMI_CHECK_ARG(boxes && order && out, "roi_infer_nms_boxes: null buffer");
+    hipLaunchKernelGGL(roi_infer_nms_boxes_kernel, dim3(cdiv(max_count, 256), nimg), dim3(256), 0, (hipStream_t)s, boxes,
+                       order, seg_offsets, reinterpret_cast<const unsigned*>(img_max), k, out);
+    PTMI_LAUNCH_CHECK("roi_infer_nms_boxes");
     return 0;
 }
 

@@ -14,13 +14,22 @@ typedef unsigned long long u64;
 
 // mask[img][i][w] bit b set  <=>  box j = 64*w + b (j > i) is suppressed by box i.
 // grid = (colBlocks, rowBlocks, nimg), block = 64 threads (one wave): thread t owns row box 64*rb + t.
+// `cnt` (may be null): only the first cnt[img] boxes of segment img exist (fixed-capacity segments whose fill level is
+// known on the device only).
+__device__ __forceinline__ int seg_count(const int32_t* __restrict__ seg, const int32_t* __restrict__ cnt, int img)
+{
+    const int cap = seg[img + 1] - seg[img];
+    return cnt ? min(cap, cnt[img]) : cap;
+}
+
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes,
-                                                      const int32_t* __restrict__ seg, float thr, int words,
+                                                      const int32_t* __restrict__ seg,
+                                                      const int32_t* __restrict__ cnt, float thr, int words,
                                                       int64_t max_count, u64* __restrict__ mask)
 {
     const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
     if (cb < rb) return;
-    const int beg = seg[img], n = seg[img + 1] - beg;
+    const int beg = seg[img], n = seg_count(seg, cnt, img);
     if (rb * 64 >= n || cb * 64 >= n) return;
     __shared__ float4 cbox[64];
     __shared__ float carea[64];
@@ -55,12 +64,13 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 
 // One wave per image walks the boxes in order, 64 at a time.
 __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ seg,
-                                                      int words, int64_t max_count, int max_keep,
+                                                      const int32_t* __restrict__ cnt, int words, int64_t max_count,
+                                                      int max_keep,
                                                       int32_t* __restrict__ keep, int32_t* __restrict__ keep_count)
 {
     extern __shared__ u64 removed[];   // words entries
     const int img = blockIdx.x, lane = threadIdx.x;
-    const int n = seg[img + 1] - seg[img];
+    const int n = seg_count(seg, cnt, img);
     const u64* M = mask + (size_t)img * max_count * words;
     for (int w = lane; w < words; w += 64) removed[w] = 0;
     __syncthreads();
@@ -128,8 +138,9 @@ int64_t ptmi_nms_ws_bytes(int64_t max_count, int nimg)
     return (int64_t)nimg * max_count * words * 8;
 }
 
-int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, int nimg, int64_t max_count, float thr,
-                     int max_keep, int32_t* keep_out, int32_t* keep_count, void* ws, ptmi_stream_t s)
+int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, const int32_t* seg_counts, int nimg,
+                     int64_t max_count, float thr, int max_keep, int32_t* keep_out, int32_t* keep_count, void* ws,
+                     ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(seg_offsets && keep_out && keep_count && nimg > 0 && max_count >= 0 && max_keep > 0,
                    "nms_batched: bad args");
@@ -143,11 +154,11 @@ int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, int nimg, i
     const int words = (int)((max_count + 63) / 64);
     PTMI_CHECK_ARG((size_t)words * 8 <= 64 * 1024, "nms_batched: max_count %lld too large", (long long)max_count);
     dim3 grid(words, words, nimg);
-    hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(64), 0, st, boxes, seg_offsets, thr, words, max_count,
+    hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(64), 0, st, boxes, seg_offsets, seg_counts, thr, words, max_count,
                        reinterpret_cast<u64*>(ws));
     PTMI_LAUNCH_CHECK("nms_mask");
     hipLaunchKernelGGL(nms_scan_kernel, dim3(nimg), dim3(64), (size_t)words * 8, st, reinterpret_cast<const u64*>(ws),
-                       seg_offsets, words, max_count, max_keep, keep_out, keep_count);
+                       seg_offsets, seg_counts, words, max_count, max_keep, keep_out, keep_count);
     PTMI_LAUNCH_CHECK("nms_scan");
     return 0;
 }

@@ -18,7 +18,12 @@ from torch import nn
 class FlatParams:
     def __init__(self, model: nn.Module):
         named = list(model.named_parameters())
-        order = [(n, p) for n, p in named if p.requires_grad] + [(n, p) for n, p in named if not p.requires_grad]
+        # trainable parameters first; among them the learnable anchor table leads: it is the one parameter that gets no
+        # gradient in supervised-only steps (anchors are detached unless danchor=True), and the bucketed reducer below
+        # walks the buffer from its END, so a never-ready parameter must not sit in front of the backbone's buckets
+        train = [(n, p) for n, p in named if p.requires_grad]
+        train = [(n, p) for n, p in train if "anchor_generator" in n] + [(n, p) for n, p in train if "anchor_generator" not in n]
+        order = train + [(n, p) for n, p in named if not p.requires_grad]
         total = sum(p.numel() for _, p in order)
         dev = order[0][1].device
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
@@ -36,6 +41,7 @@ class FlatParams:
                 self.n_trainable = off
         self.params = OrderedDict(order)
         self.grad = None
+        self.on_zero_grad = []          # callbacks run at the start of every step (the gradient reducer re-arms itself)
 
     def attach_grads(self) -> torch.Tensor:
         """Point every trainable parameter's .grad at a view of one flat buffer (autograd accumulates in place)."""
@@ -49,6 +55,8 @@ class FlatParams:
 
     def zero_grad(self) -> None:
         self.attach_grads().zero_()
+        for fn in self.on_zero_grad:
+            fn()
 
     def trainable(self) -> torch.Tensor:
         return self.flat[: self.n_trainable]
@@ -78,8 +86,12 @@ class BucketedGradReducer:
     same sequence of collectives even if autograd visits parameters in a different order; `finish()` launches what is
     left (parameters that received no gradient this step keep their zeros), waits, and divides by the world size."""
 
-    def __init__(self, fp: FlatParams, world_size: int, bucket_elems: int = 16 * 1024 * 1024, group=None):
+    def __init__(self, fp: FlatParams, world_size: int, bucket_elems: int = 16 * 1024 * 1024, group=None,
+                 force: bool = False):
+        """force: install the hooks and run the collectives even for world_size 1 (the sum over one rank is the identity;
+        used to exercise the RCCL / stream-ordering path on a single GPU)."""
         self.fp, self.world, self.group = fp, world_size, group
+        self.active = world_size > 1 or force
         grad = fp.attach_grads()
         names = [n for n, p in fp.params.items() if p.requires_grad]
         self.buckets: List[Tuple[int, int]] = []         # (start, end) in elements, bucket 0 = tail of the buffer
@@ -97,16 +109,22 @@ class BucketedGradReducer:
         self.size = [sum(1 for b in self.bucket_of.values() if b == i) for i in range(len(self.buckets))]
         self._grad = grad
         self._hooks = []
-        if world_size > 1:
+        if self.active:
             for n in names:
                 p = fp.params[n]
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[n])))
         self.reset()
+        # re-arm at the start of every step: a backward() that was not followed by finish() (an exception mid-step, a
+        # test) must not leave stale ready-counts behind
+        fp.on_zero_grad.append(self.reset)
 
     def reset(self):
+        for h in getattr(self, "handles", []):      # collectives of an abandoned step: drain before re-arming
+            h.wait()
         self.pending = list(self.size)
         self.next = 0
         self.handles = []
+        self.launched_in_backward = 0               # (diagnostic) buckets that left before finish()
 
     def _make_hook(self, b: int):
         def hook(_param):
@@ -122,17 +140,22 @@ class BucketedGradReducer:
         while self.next < len(self.buckets) and self.pending[self.next] <= 0:
             self._launch(self.next)
             self.next += 1
+            self.launched_in_backward += 1
 
     def finish(self) -> torch.Tensor:
         """Call after backward(): launches the remaining buckets in order, waits for all, averages."""
-        if self.world > 1:
+        if self.active:
             while self.next < len(self.buckets):
                 self._launch(self.next)
                 self.next += 1
             for h in self.handles:
                 h.wait()
-            self._grad.div_(self.world)
+            self.handles = []
+            if self.world > 1:
+                self._grad.div_(self.world)
+        n_early = self.launched_in_backward
         self.reset()
+        self.launched_in_backward = n_early
         return self._grad
 
 

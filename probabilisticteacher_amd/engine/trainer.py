@@ -19,7 +19,10 @@ from .flat import BucketedGradReducer, FlatParams, broadcast_, lr_at
 
 
 class PTrainer:
-    def __init__(self, cfg, data_loader=None, ratio_fn: Optional[Callable[[], float]] = None):
+    def __init__(self, cfg, data_loader=None, ratio_fn: Optional[Callable[[], float]] = None,
+                 force_grad_reducer: bool = False):
+        """force_grad_reducer: run the bucketed gradient all-reduce (hooks + collectives) even with one rank -- needs an
+        initialised process group; the sum over one rank is the identity (single-GPU validation of the DDP path)."""
         self.cfg = cfg
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.model = build_model(cfg)                  # student
@@ -35,7 +38,8 @@ class PTrainer:
         broadcast_(self.teacher.flat)
         self.momentum_buf = torch.zeros_like(self.student.trainable())
         # gradient exchange overlapped with backward: 16 MB buckets from the tail of the flat buffer (box head first)
-        self.reducer = BucketedGradReducer(self.student, self.world_size, bucket_elems=4 * 1024 * 1024)
+        self.reducer = BucketedGradReducer(self.student, self.world_size, bucket_elems=4 * 1024 * 1024,
+                                           force=force_grad_reducer)
         self._first_step = True
         self.joint_student_pass = True      # one backbone pass for the two student branches when they share a canvas
         self.ensem_ts_model = EnsembleTSModel(self.model_teacher, self.model)
@@ -179,20 +183,41 @@ class PTrainer:
         self.iter += 1
         return self.last_metrics
 
+    # every loss key a step can produce (burn-in: bare names; mutual learning: _sup / _unsup), in a fixed order, so that
+    # ranks exchange equally laid-out vectors whatever subset each of them holds
+    METRIC_KEYS = tuple(k + sfx for sfx in ("", "_sup", "_unsup")
+                        for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"))
+
     def _write_metrics(self, record_dict, data_time, sumsq):
         """trainer.py:394-429 with ONE device->host copy: all loss scalars packed into a single tensor (the
-        reference does ~10 `.cpu().item()` syncs and a pickled gloo gather)."""
-        keys = list(record_dict.keys())
-        packed = torch.stack([record_dict[k].detach().float() for k in keys] + [sumsq.reshape(())])
+        reference does ~10 `.cpu().item()` syncs and a pickled gloo gather).  Multi-rank semantics of the reference:
+        the keys of rank 0, each averaged over ALL ranks with 0.0 for a rank that lacks the key (:413-417); data_time is
+        the maximum over ranks (:407-411).  One all-gather of a fixed-layout vector (values + presence + data_time)."""
+        extra = [k for k in record_dict if k not in self.METRIC_KEYS]
+        if self.world_size > 1 and extra:
+            raise KeyError(f"metrics {extra} have no slot in the cross-rank layout (PTrainer.METRIC_KEYS)")
+        keys = list(self.METRIC_KEYS) + extra
+        dev = sumsq.device
+        zero = torch.zeros((), device=dev)
+        present = [k in record_dict for k in keys]
+        packed = torch.stack([record_dict[k].detach().float() if p else zero for k, p in zip(keys, present)] +
+                             [sumsq.reshape(())])
         if self.world_size > 1:
-            red = packed.clone()
-            red[-1] = 0
-            dist.all_reduce(red)
-            packed[:-1] = red[:-1] / self.world_size
-        vals = packed.cpu().tolist()
-        m = dict(zip(keys, vals[:-1]))
+            mine = torch.cat([packed, torch.tensor([float(p) for p in present] + [data_time], device=dev)])
+            allv = torch.empty(self.world_size * mine.numel(), device=dev)
+            dist.all_gather_into_tensor(allv, mine)
+            allv = allv.view(self.world_size, mine.numel()).cpu()
+            nk = len(keys)
+            mean = allv[:, :nk].mean(dim=0).tolist()            # absent entries were packed as 0.0
+            m = {k: v for k, v, p in zip(keys, mean, allv[0, nk + 1:2 * nk + 1].tolist()) if p > 0}   # rank 0's keys
+            data_time = float(allv[:, -1].max())
+            gsq = float(allv[dist.get_rank(), nk])
+        else:
+            vals = packed.cpu().tolist()
+            m = {k: v for k, v, p in zip(keys, vals[:-1], present) if p}
+            gsq = vals[-1]
         m["total_loss"] = sum(v for k, v in m.items() if k[:4] == "loss")
-        m["grad_norm"] = vals[-1] ** 0.5
+        m["grad_norm"] = gsq ** 0.5
         m["data_time"] = data_time
         self.last_metrics = m
 
@@ -214,6 +239,7 @@ def _flatten_like(model, ref: FlatParams) -> FlatParams:
     fp.n_trainable = ref.n_trainable
     fp.params = {}
     fp.grad = None
+    fp.on_zero_grad = []
     for n, (off, k) in ref.index.items():
         p = named[n]
         view = fp.flat[off:off + k].view(p.shape)

@@ -138,65 +138,54 @@ class GuassianFastRCNNOutputLayers(nn.Module):
     # ---- teacher inference (fast_rcnn.py:338-409, :34-141)
     @torch.no_grad()
     def inference(self, predictions, proposals: List[FreeInstances]):
-        """fast_rcnn.py:338-409 + fast_rcnn_inference(_single_image) :34-141 for the whole batch at once: the per-image
-        steps of the reference (finite filter, clip, score threshold, sigma rescoring, per-class NMS offsets) are
-        evaluated on the concatenated ROIs with per-ROI image indices -- three device->host reads per call instead of
-        ~5 per image."""
+        """fast_rcnn.py:338-409 + fast_rcnn_inference(_single_image) :34-141 for the whole batch at once.
+        `ptmi_roi_infer_prepare` does the per-ROI part (decode, finite filter, clip, score threshold, sigma rescoring,
+        per-image candidate count / max coordinate) in one launch and leaves dense (roi, class) arrays; candidates are
+        never compacted on the host: a segmented stable sort of the keys over the fixed (R_i * K)-entry segments puts
+        each image's candidates first, in the order batched_nms visits them, and the NMS runs on the first count[i]
+        entries (counts stay on the device).  ONE device->host read per call (the kept-detection counts)."""
         scores, deltas = predictions
         K = self.num_classes
         dev = scores.device
         n = len(proposals)
         counts = [len(p) for p in proposals]
         R = sum(counts)
-        pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
-        dec = self.box2box_transform.apply_deltas(deltas, pb)          # (R, 8K): 2K boxes per ROI
+        pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0).contiguous()
         probs = ops.softmax_rows(scores)
-        boxes = dec.view(R, K, 8)[..., :4]
-        bsig_all = deltas.view(R, K, 8)[..., 4:]
-        valid = torch.isfinite(boxes).all(dim=2).all(dim=1) & torch.isfinite(probs).all(dim=1)
-        img_of_roi = torch.repeat_interleave(torch.arange(n, device=dev), ops.dev_i32(counts, dev), output_size=R)
-        hw = torch.tensor([[float(p.image_size[0]), float(p.image_size[1])] for p in proposals]).pin_memory().to(
-            dev, non_blocking=True)[img_of_roi]                        # (R, 2) clip limits of each ROI's image
-        zero = boxes.new_zeros(())
-        lim_w, lim_h = hw[:, 1:2], hw[:, 0:1]
-        boxes = torch.stack((torch.minimum(torch.maximum(boxes[..., 0], zero), lim_w),
-                             torch.minimum(torch.maximum(boxes[..., 1], zero), lim_h),
-                             torch.minimum(torch.maximum(boxes[..., 2], zero), lim_w),
-                             torch.minimum(torch.maximum(boxes[..., 3], zero), lim_h)), dim=-1)
-        sc = probs[:, :-1]
-        fm = (sc > self.test_score_thresh) & valid[:, None]            # non-finite ROIs contribute no candidate
-        finds = fm.nonzero()                                            # (C, 2) = (roi, class), image-major order
-        cand_img = img_of_roi[finds[:, 0]]
-        ccounts = torch.bincount(cand_img, minlength=n).cpu().tolist()
-        cboxes = boxes[finds[:, 0], finds[:, 1]]
-        cbsig = bsig_all[finds[:, 0], finds[:, 1]]
-        csc = sc[finds[:, 0], finds[:, 1]]
-        csc = csc * (1 - torch.sigmoid(cbsig).sum(-1) / 4.0)
-        if cboxes.shape[0]:
-            # batched_nms offset trick, per image: boxes + class * (max coordinate of that image's candidates + 1)
-            mx = torch.zeros(n, device=dev).scatter_reduce_(0, cand_img, cboxes.amax(dim=1), "amax", include_self=False)
-            nms_boxes = cboxes + (finds[:, 1].to(cboxes) * (mx[cand_img] + torch.tensor(1.0, device=dev)))[:, None]
-        else:
-            nms_boxes = cboxes
-        offs = [0]
-        for c in ccounts:
-            offs.append(offs[-1] + c)
-        seg = ops.dev_i32(offs, dev)
-        _, order = ops.segsort_desc(csc.contiguous(), seg)
-        base = torch.repeat_interleave(seg[:-1].long(), seg[1:] - seg[:-1], output_size=offs[-1])
-        gorder = base + order.long()
-        sorted_nb = nms_boxes[gorder]
-        topk = self.test_topk_per_image if self.test_topk_per_image >= 0 else max(max(ccounts), 1)
-        keep, kcnt = ops.nms_batched(sorted_nb, seg, max(ccounts) if ccounts else 0, float(self.test_nms_thresh),
-                                     int(max(topk, 1)))
-        kc = kcnt.cpu().tolist()
-        sel = torch.cat([gorder[keep[i, :kc[i]].long() + offs[i]] for i in range(n)], 0) if n else gorder[:0]
-        f_sel = finds[sel]
-        r_boxes, r_scores, r_sig = cboxes[sel], csc[sel], cbsig[sel]
-        r_logits = scores[f_sel[:, 0]]
         roff = [0]
         for c in counts:
             roff.append(roff[-1] + c)
+        roi_img = torch.repeat_interleave(torch.arange(n, dtype=torch.int32, device=dev), ops.dev_i32(counts, dev),
+                                          output_size=R)
+        hw = torch.tensor([[float(p.image_size[0]), float(p.image_size[1])] for p in proposals]).pin_memory().to(
+            dev, non_blocking=True)
+        boxes, keys, roi_valid, img_max, img_cnt, img_inv = ops.roi_infer_prepare(
+            deltas.contiguous(), pb, probs, roi_img, hw, K, self.box2box_transform.weights,
+            self.box2box_transform.scale_clamp, self.test_score_thresh)
+        seg = ops.dev_i32([K * o for o in roff], dev)                     # dense (roi, class) segments per image
+        cap = K * max(counts) if counts else 0
+        srt, order = ops.segsort_desc(keys.view(-1), seg)
+        nms_boxes = ops.roi_infer_nms_boxes(boxes, order, seg, img_max, cap, K)
+        topk = self.test_topk_per_image if self.test_topk_per_image >= 0 else max(cap, 1)
+        keep, kcnt = ops.nms_batched(nms_boxes, seg, cap, float(self.test_nms_thresh), int(max(topk, 1)),
+                                     seg_counts=img_cnt)
+        host = torch.cat([kcnt, img_inv]).cpu().tolist()                  # the one sync
+        kc, dropped = host[:n], host[n:]
+        pos = torch.cat([keep[i, :kc[i]].long() + K * roff[i] for i in range(n)], 0) if n else seg[:0].long()
+        img_base = torch.repeat_interleave(seg[:-1].long(), ops.dev_i32(kc, dev).long(), output_size=sum(kc))
+        dense = img_base + order[pos].long()                              # flat (roi, class) index of every detection
+        roi, cls = torch.div(dense, K, rounding_mode="floor"), dense % K
+        r_boxes, r_scores = boxes.view(-1, 4)[dense], srt[pos]
+        r_sig = deltas.view(R, K, 8)[roi, cls, 4:]
+        img_start = torch.div(img_base, K, rounding_mode="floor")        # first ROI row of the detection's image
+        row = roi
+        if any(dropped):
+            # reference quirk (fast_rcnn.py:68-71,96,126): after the finite filter the kept ROIs are re-indexed by their
+            # position in the FILTERED list, and `scores_logists` / the returned ROI indices use that position (the
+            # logits are even read from the UNfiltered tensor at it)
+            excl = torch.cumsum(roi_valid.long(), 0) - roi_valid.long()
+            row = img_start + (excl[roi] - excl[img_start])
+        r_logits = scores[row]
         results, kept_rows = [], []
         c0 = 0
         for i, prop in enumerate(proposals):
@@ -204,11 +193,11 @@ class GuassianFastRCNNOutputLayers(nn.Module):
             res = FreeInstances(prop.image_size)
             res.pred_boxes = Boxes(r_boxes[c0:c0 + k])
             res.scores = r_scores[c0:c0 + k]
-            res.pred_classes = f_sel[c0:c0 + k, 1]
+            res.pred_classes = cls[c0:c0 + k]
             res.scores_logists = r_logits[c0:c0 + k]
             res.boxes_sigma = r_sig[c0:c0 + k]
             results.append(res)
-            kept_rows.append(f_sel[c0:c0 + k, 0] - roff[i])             # ROI index within the image
+            kept_rows.append(row[c0:c0 + k] - roff[i])                    # ROI index within the image
             c0 += k
         return results, kept_rows
 

@@ -58,38 +58,29 @@ def build_rpn_head(cfg, input_shape):
 def find_top_rpn_proposals(decoded, logits, sigma_logits, image_sizes, nms_thresh, pre_nms_topk, post_nms_topk,
                            min_box_size, training) -> List[FreeInstances]:
     """proposal_utils.py:27-154 for one feature level, batched over images on the device:
-    segmented sort -> clip / nonempty / sigma-rescoring kernel -> compaction -> segmented sort of the rescored
-    scores -> batched bitmask NMS.  Two small device->host reads (counts) per call."""
+    segmented sort -> clip / nonempty / sigma-rescoring kernel (dropped entries get key -inf, kept counts stay on the
+    device) -> segmented sort of the keys over fixed k-entry segments -> batched bitmask NMS on the first count[i]
+    entries.  ONE device->host read per call (kept-after-NMS counts + the non-finite flags)."""
     n, r = logits.shape
     dev = logits.device
     k = min(r, pre_nms_topk)
     seg = torch.arange(0, (n + 1) * r, r, dtype=torch.int32, device=dev)
     srt, idx = ops.segsort_desc(logits.reshape(-1), seg)
-    sizes = torch.tensor([[float(h), float(w)] for h, w in image_sizes], dtype=torch.float32, device=dev)
-    boxes, scores, valid, nonfinite = ops.rpn_prepare(decoded, srt.view(n, r), idx.view(n, r), sigma_logits, sizes,
-                                                      k, float(min_box_size))
-    valid_b = valid.bool()
-    counts_dev = valid_b.sum(dim=1)
-    host = torch.cat([counts_dev, nonfinite.long()]).cpu()           # one sync
-    counts, bad = host[:n].tolist(), host[n:].tolist()
+    sizes = torch.tensor([[float(h), float(w)] for h, w in image_sizes], dtype=torch.float32).pin_memory().to(
+        dev, non_blocking=True)
+    boxes, keys, counts, nonfinite = ops.rpn_prepare(decoded, srt.view(n, r), idx.view(n, r), sigma_logits, sizes, k,
+                                                     float(min_box_size))
+    seg2 = torch.arange(0, (n + 1) * k, k, dtype=torch.int32, device=dev)
+    s2, i2 = ops.segsort_desc(keys.view(-1), seg2)
+    sb = torch.gather(boxes, 1, i2.view(n, k, 1).long().expand(n, k, 4)).view(n * k, 4)
+    keep, kcnt = ops.nms_batched(sb, seg2, k, float(nms_thresh), int(post_nms_topk), seg_counts=counts)
+    host = torch.cat([kcnt, nonfinite]).cpu().tolist()                # the one sync
+    kc, bad = host[:n], host[n:]
     if any(bad) and training:
         raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
-    flat = valid_b.view(-1)
-    vb = boxes.view(-1, 4)[flat]
-    vs = scores.view(-1)[flat]
-    offs = [0]
-    for c in counts:
-        offs.append(offs[-1] + c)
-    seg2 = torch.tensor(offs, dtype=torch.int32, device=dev)
-    s2, i2 = ops.segsort_desc(vs, seg2)
-    base = torch.repeat_interleave(seg2[:-1].long(), torch.tensor(counts, device=dev))
-    sb = vb[base + i2.long()]
-    max_count = max(counts) if counts else 0
-    keep, kcnt = ops.nms_batched(sb, seg2, max_count, float(nms_thresh), int(post_nms_topk))
-    kc = kcnt.cpu().tolist()                                          # second sync
     results = []
     for i, size in enumerate(image_sizes):
-        sel = keep[i, :kc[i]].long() + offs[i]
+        sel = keep[i, :kc[i]].long() + i * k
         res = FreeInstances(size)
         res.proposal_boxes = Boxes(sb[sel])
         res.objectness_logits = s2[sel]

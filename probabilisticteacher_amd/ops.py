@@ -572,20 +572,23 @@ def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor) -> Tuple[torch.T
 
 
 def rpn_prepare(decoded, sorted_logits, sorted_idx, sigma_logits, image_sizes_hw, k: int, min_size: float):
+    """-> boxes (n,k,4) clipped, keys (n,k) (rescored logit, -inf for dropped entries), counts (n,) int32, nonfinite (n,)"""
     n, r = sorted_logits.shape
     dev = decoded.device
     boxes = torch.empty((n, k, 4), dtype=F32, device=dev)
-    scores = torch.empty((n, k), dtype=F32, device=dev)
-    valid = torch.empty((n, k), dtype=torch.uint8, device=dev)
+    keys = torch.empty((n, k), dtype=F32, device=dev)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
     nonfinite = torch.empty(n, dtype=torch.int32, device=dev)
     _lib.call("ptmi_rpn_prepare", _ptr(_chk(decoded)), _ptr(_chk(sorted_logits)), _ptr(_chk(sorted_idx, torch.int32)),
-              _ptr(_chk(sigma_logits)), _ptr(_chk(image_sizes_hw)), _ptr(boxes), _ptr(scores), _ptr(valid),
+              _ptr(_chk(sigma_logits)), _ptr(_chk(image_sizes_hw)), _ptr(boxes), _ptr(keys), _ptr(counts),
               _ptr(nonfinite), n, r, k, float(min_size), _stream())
-    return boxes, scores, valid, nonfinite
+    return boxes, keys, counts, nonfinite
 
 
-def nms_batched(boxes_sorted: torch.Tensor, seg_offsets: torch.Tensor, max_count: int, thr: float, max_keep: int):
-    """boxes (sum,4) sorted by descending score per image; returns keep (nimg,max_keep) int32 positions, counts."""
+def nms_batched(boxes_sorted: torch.Tensor, seg_offsets: torch.Tensor, max_count: int, thr: float, max_keep: int,
+                seg_counts: Optional[torch.Tensor] = None):
+    """boxes (sum,4) sorted by descending score per image; returns keep (nimg,max_keep) int32 positions, counts.
+    seg_counts (nimg,) int32: fill level of fixed-capacity segments (device-side, no host read needed)."""
     boxes_sorted = _chk(boxes_sorted.contiguous())
     seg_offsets = _chk(seg_offsets.contiguous(), torch.int32)
     nimg = seg_offsets.numel() - 1
@@ -595,9 +598,38 @@ def nms_batched(boxes_sorted: torch.Tensor, seg_offsets: torch.Tensor, max_count
     nbytes = _lib.load().ptmi_nms_ws_bytes(max_count, nimg)
     ws = _ws("nms", nbytes, dev)
     with _prof("nms_batched"):
-        _lib.call("ptmi_nms_batched", _ptr(boxes_sorted), _ptr(seg_offsets), nimg, max_count, float(thr), max_keep,
-                  _ptr(keep), _ptr(cnt), _ptr(ws), _stream())
+        _lib.call("ptmi_nms_batched", _ptr(boxes_sorted), _ptr(seg_offsets),
+                  _ptr(_chk(seg_counts, torch.int32)) if seg_counts is not None else None, nimg, int(max_count),
+                  float(thr), max_keep, _ptr(keep), _ptr(cnt), _ptr(ws), _stream())
     return keep, cnt
+
+
+def roi_infer_prepare(deltas, proposal_boxes, probs, roi_img, image_sizes_hw, k: int, weights, scale_clamp: float,
+                      score_thresh: float):
+    """fast_rcnn.py:34-101 for all ROIs of a batch (ptmi_roi_infer_prepare): -> boxes (R,K,4) clipped, keys (R,K),
+    roi_valid (R,) u8, img_max (nimg,), img_count (nimg,) int32, img_invalid (nimg,) int32."""
+    r, nimg = deltas.shape[0], image_sizes_hw.shape[0]
+    dev = deltas.device
+    boxes = torch.empty((r, k, 4), dtype=F32, device=dev)
+    keys = torch.empty((r, k), dtype=F32, device=dev)
+    valid = torch.empty(r, dtype=torch.uint8, device=dev)
+    img_max = torch.empty(nimg, dtype=F32, device=dev)
+    img_cnt = torch.empty(nimg, dtype=torch.int32, device=dev)
+    img_inv = torch.empty(nimg, dtype=torch.int32, device=dev)
+    wx, wy, ww, wh = [float(v) for v in weights]
+    _lib.call("ptmi_roi_infer_prepare", _ptr(_chk(deltas)), _ptr(_chk(proposal_boxes)), _ptr(_chk(probs)),
+              _ptr(_chk(roi_img, torch.int32)), _ptr(_chk(image_sizes_hw)), _ptr(boxes), _ptr(keys), _ptr(valid),
+              _ptr(img_max), _ptr(img_cnt), _ptr(img_inv), r, k, nimg, wx, wy, ww, wh, float(scale_clamp),
+              float(score_thresh), _stream())
+    return boxes, keys, valid, img_max, img_cnt, img_inv
+
+
+def roi_infer_nms_boxes(boxes, order, seg_offsets, img_max, max_count: int, k: int) -> torch.Tensor:
+    out = torch.empty((boxes.shape[0] * boxes.shape[1], 4), dtype=F32, device=boxes.device)
+    _lib.call("ptmi_roi_infer_nms_boxes", _ptr(_chk(boxes)), _ptr(_chk(order, torch.int32)),
+              _ptr(_chk(seg_offsets, torch.int32)), _ptr(_chk(img_max)), seg_offsets.numel() - 1, int(max_count), k,
+              _ptr(out), _stream())
+    return out
 
 
 # ============================================================================ losses (loss + gradient in one launch)

@@ -1,0 +1,305 @@
+"""GPU parity at BASELINE size (pytest -m gpu): the shapes `bench.py` times, against stock torch CPU fp32 autograd
+(conv stack, per layer group) and against the CPU oracle's full `run_step` (1333 x 800 images, final_c2f.yaml).
+
+  * every distinct (Cin, Cout, H, W) of the VGG16 + RPN 3x3 stack at n = 2: forward, dgrad (incl. the fused ReLU-mask
+    epilogue), wgrad and bias gradient through the production autograd nodes (`ops.vgg_block`, fused conv+ReLU+pool
+    for the frozen blocks);
+  * ONE n = 48 launch of conv3_2 (256 -> 256 at 200 x 333: the 8-wave variant, the n = 48 split-K count, the merged
+    main + right-edge wgrad launch, epilogue 3) -- the launch shape of the joint student pass in the bench;
+  * BASELINE configs[1]-shaped supervised student step (2 images) and configs[2]-shaped full mutual-learning step
+    (1 labelled + 1 unlabelled image: EMA, teacher, pseudo labels, joint student pass, clip + SGD) vs the oracle.
+
+Tolerances: conv outputs / gradients 1e-4 of the tensor's largest magnitude (fp32 MFMA k-order vs oneDNN blocking);
+losses 1e-4 relative (BASELINE.json north_star); updated parameters 1e-4."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import d2, pt as opt
+from tests.helpers import close, keyed_perm_source, match_detections
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _threads():
+    torch.set_num_threads(max(2, min(os.cpu_count() or 2, 64)))
+
+
+def _rel(a, b, tol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, f"{what}: {tuple(a.shape)} vs {tuple(b.shape)}"
+    scale = float(b.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= tol * scale + 1e-30, f"{what}: max abs err {err:.3e} vs {tol:.0e} x max|ref| {scale:.3e}"
+
+
+def _block_ref(x, params, pool, need_dx):
+    xr = x.clone().requires_grad_(need_dx)
+    ps = [p.clone().requires_grad_() for p in params]
+    y = xr
+    for j in range(len(ps) // 2):
+        y = F.relu(F.conv2d(y, ps[2 * j], ps[2 * j + 1], padding=1))
+    if pool:
+        y = F.max_pool2d(y, 2, 2)
+    return xr, ps, y
+
+
+# (name, cin, couts, H, W, pool, input is a post-ReLU activation that needs dx)
+TRAINABLE_BLOCKS = [
+    ("block3", 128, [256, 256, 256], 200, 333, True, False),     # conv3_1 (128->256), conv3_2/3 (256->256), 8-wave variant
+    ("block4", 256, [512, 512, 512], 100, 166, True, True),      # conv4_1 (256->512), conv4_2/3 (512->512)
+    ("block5", 512, [512, 512, 512], 50, 83, False, True),       # conv5_x (512->512), no pool (vgg.py:59)
+]
+
+
+@pytest.mark.parametrize("name,cin,couts,h,w,pool,need_dx", TRAINABLE_BLOCKS)
+def test_trainable_vgg_blocks_full_size_vs_torch(name, cin, couts, h, w, pool, need_dx):
+    from probabilisticteacher_amd import ops
+    _threads()
+    gen = torch.Generator().manual_seed(h + cin)
+    n = 2
+    x = torch.relu(torch.randn(n, cin, h, w, generator=gen))
+    params, c = [], cin
+    for co in couts:
+        params += [torch.randn(co, c, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * c)), torch.randn(co, generator=gen) * 0.1]
+        c = co
+    xr, ps, yr = _block_ref(x, params, pool, need_dx)
+    gy = torch.randn(yr.shape, generator=gen)
+    yr.backward(gy)
+    xd = x.to(DEV).requires_grad_(need_dx)
+    pd = [p.to(DEV).requires_grad_() for p in params]
+    yd = ops.vgg_block(xd, pool, pd)
+    _rel(yd, yr, 1e-4, f"{name} forward")
+    yd.backward(gy.to(DEV))
+    if need_dx:
+        _rel(xd.grad, xr.grad, 1e-4, f"{name} dgrad")
+    for j, (a, b) in enumerate(zip(pd, ps)):
+        _rel(a.grad, b.grad, 1e-4, f"{name} {'dW' if j % 2 == 0 else 'db'} of conv{j // 2 + 1}")
+
+
+def test_frozen_blocks_and_rpn_conv_full_size_vs_torch():
+    """blocks 1-2 (frozen: stem kernel, fused conv + ReLU + pool epilogue) at 800 x 1333 / 400 x 666 and the RPN 3x3
+    conv (512 -> 512 + ReLU on the 50 x 83 map, all three gradients)"""
+    from probabilisticteacher_amd import ops
+    _threads()
+    gen = torch.Generator().manual_seed(1)
+    n = 2
+    x = torch.randn(n, 3, 800, 1333, generator=gen)
+    ws = []
+    for ci, co in ((3, 64), (64, 64), (64, 128), (128, 128)):
+        ws.append((torch.randn(co, ci, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * ci)), torch.randn(co, generator=gen) * 0.1))
+    with torch.no_grad():
+        r = F.relu(F.conv2d(x, *ws[0], padding=1))
+        d = ops.conv3x3(x.to(DEV), ws[0][0].to(DEV), ws[0][1].to(DEV), True)
+        _rel(d, r, 1e-4, "conv1_1 (stem)")
+        r = F.max_pool2d(F.relu(F.conv2d(r, *ws[1], padding=1)), 2, 2)
+        d = ops.conv3x3_relu_pool_nograd(d, ws[1][0].to(DEV), ws[1][1].to(DEV))
+        _rel(d, r, 1e-4, "conv1_2 + pool")
+        r = F.relu(F.conv2d(r, *ws[2], padding=1))
+        d = ops.conv3x3(d, ws[2][0].to(DEV), ws[2][1].to(DEV), True)
+        _rel(d, r, 1e-4, "conv2_1")
+        r = F.max_pool2d(F.relu(F.conv2d(r, *ws[3], padding=1)), 2, 2)
+        d = ops.conv3x3_relu_pool_nograd(d, ws[3][0].to(DEV), ws[3][1].to(DEV))
+        _rel(d, r, 1e-4, "conv2_2 + pool")
+        assert d.shape == (n, 128, 200, 333)
+    f = torch.relu(torch.randn(n, 512, 50, 83, generator=gen))
+    wt, b = torch.randn(512, 512, 3, 3, generator=gen) * 0.01, torch.zeros(512)
+    fr, wr, br = f.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.relu(F.conv2d(fr, wr, br, padding=1))
+    gy = torch.randn(yr.shape, generator=gen)
+    yr.backward(gy)
+    fd, wd, bd = (t.to(DEV).requires_grad_() for t in (f, wt, b))
+    yd = ops.conv3x3(fd, wd, bd, True)
+    _rel(yd, yr, 1e-4, "rpn conv forward")
+    yd.backward(gy.to(DEV))
+    _rel(fd.grad, fr.grad, 1e-4, "rpn conv dgrad")
+    _rel(wd.grad, wr.grad, 1e-4, "rpn conv dW")
+    _rel(bd.grad, br.grad, 1e-4, "rpn conv db")
+
+
+def test_conv3_2_at_n48_bench_launch_shape_vs_torch():
+    """ONE launch of each conv3_2 kernel at the joint student pass's batch (n = 48 = 32 labelled views + 16 unlabelled):
+    forward (8-wave variant, epilogue 1), dgrad with the producer's ReLU mask (epilogue 3), wgrad with the n = 48 split-K
+    count and the merged main + right-edge launch, bias gradient."""
+    from probabilisticteacher_amd import ops
+    from probabilisticteacher_amd import _lib
+    _threads()
+    gen = torch.Generator().manual_seed(48)
+    n, c, h, w = 48, 256, 200, 333
+    x = torch.relu(torch.randn(n, c, h, w, generator=gen))          # post-ReLU activation of conv3_1 (has zeros)
+    wt = torch.randn(c, c, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * c))
+    b = torch.randn(c, generator=gen) * 0.1
+    gy = torch.randn(n, c, h, w, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yrelu = F.relu(yr)
+    yr.backward(gy)
+    xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
+    yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0), bd, None, c, 1)
+    _rel(yd, yrelu.detach(), 1e-4, "conv3_2 forward n=48")
+    del yd
+    dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1), None, xd, c, 3)
+    _rel(dx, xr.grad * (x > 0), 1e-4, "conv3_2 dgrad + mask n=48")
+    del dx
+    dw, db = torch.empty_like(wd), torch.empty(c, device=DEV)
+    nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, c, c, h, w)
+    ws = torch.empty(nws, device=DEV)
+    _lib.call("ptmi_conv3x3_wgrad", ops._ptr(xd), ops._ptr(gd), ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, c, c, h, w, 0,
+              ops._stream())
+    _rel(dw, wr.grad, 1e-4, "conv3_2 wgrad n=48")
+    _rel(db, br.grad, 1e-4, "conv3_2 bias grad n=48")
+
+
+def _records(gen, n_img, h, w, K, m0=3):
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    recs, orecs = [], []
+    for i in range(n_img):
+        img = torch.randint(0, 256, (3, h, w), generator=gen, dtype=torch.uint8)
+        m = m0 + i
+        xy = torch.rand(m, 2, generator=gen) * torch.tensor([w * 0.6, h * 0.6])
+        boxes = torch.cat([xy, xy + 40 + torch.rand(m, 2, generator=gen) * 300], 1)
+        boxes[:, 0::2].clamp_(0, w)
+        boxes[:, 1::2].clamp_(0, h)
+        cls = torch.randint(0, K, (m,), generator=gen)
+        a, b = FreeInstances((h, w)), opt.FreeInstances((h, w))
+        a.gt_boxes, a.gt_classes = Boxes(boxes.clone()), cls.clone()
+        b.gt_boxes, b.gt_classes = d2.Boxes(boxes.clone()), cls.clone()
+        recs.append({"image": img, "height": h, "width": w, "instances": a})
+        orecs.append({"image": img, "height": h, "width": w, "instances": b})
+    return recs, orecs
+
+
+PROBES = ("roi_heads.box_predictor.cls_score.weight", "proposal_generator.rpn_head.conv.bias",
+          "backbone.vgg_block5.0.conv3.weight", "backbone.vgg_block3.0.conv1.weight", "roi_heads.box_head.fc1.bias")
+
+
+def _load(model, params):
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(v)
+
+
+def _compare_step(m, om, kp, tr, state, params, sup_keys, unsup_keys, tag):
+    # the anchor sample is always identical (fixed 37 350 candidates per image); the ROI sample is identical unless the two
+    # sides kept a different number of proposals (an exact-threshold NMS decision on fp32 values that differ in the last
+    # ulp), in which case the ROI-head losses of that branch are only statistically equal
+    for k in sup_keys + unsup_keys:
+        roi = k.startswith("loss_cls") or k.startswith("loss_box_reg")
+        tol = 5e-2 if (roi and kp.mismatch) else 1e-4
+        close(torch.tensor(m[k]), torch.tensor(om[k]), tol, 1e-6, f"{tag} {k}")
+    if kp.mismatch:
+        return False
+    close(torch.tensor(m["total_loss"]), torch.tensor(om["total_loss"]), 1e-4, 1e-6, f"{tag} total_loss")
+    close(torch.tensor(m["grad_norm"]), torch.tensor(om["grad_norm"]), 1e-3, 1e-6, f"{tag} grad_norm")
+    sd = tr.model.state_dict()
+    for k in PROBES:
+        ref = state["student"][k].detach()
+        assert not torch.equal(ref, params[k]), k + " must have been updated"
+        close(sd[k].cpu(), ref, 1e-4, 1e-5 * float(ref.abs().max()) + 1e-7, f"{tag} updated {k}")
+    return True
+
+
+def test_baseline_config1_supervised_step_1333x800_vs_oracle():
+    """BASELINE.json configs[1] shape: final_c2f.yaml (K = 8), student-only supervised forward/backward + clip + SGD on
+    1333 x 800 images (here the strong + weak view of one labelled image = a batch of 2; the bench runs 8)."""
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.modeling import sampling
+    _threads()
+    cfg = setup_cfg("configs/pt/final_c2f.yaml", ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", 10 ** 6,
+                                                  "SOLVER.IMG_PER_BATCH_LABEL", 1, "SOLVER.IMG_PER_BATCH_UNLABEL", 1])
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    ocfg = opt.Cfg(num_classes=K, anchor_generator=cfg.MODEL.ANCHOR_GENERATOR.NAME, burn_up_step=10 ** 6)
+    params = opt.golden_params(ocfg, 31)
+    ratios = [0.9, 0.55]
+    it = iter(list(ratios))
+    tr = PTrainer(cfg, ratio_fn=lambda: next(it))
+    _load(tr.model, params)
+    _load(tr.model_teacher, params)
+    recs, orecs = _records(torch.Generator().manual_seed(3), 2, 800, 1333, K)
+    kp = opt.KeyedPerm(51, strict=False)
+    sampling.set_key_source(keyed_perm_source(kp))
+    try:
+        m = tr.run_step(([recs[0]], [recs[1]], [recs[0]], [recs[1]]))
+    finally:
+        sampling.set_key_source(None)
+    kp.start_replay()
+    state = {"student": {k: v.clone() for k, v in params.items()}, "teacher": {k: v.clone() for k, v in params.items()},
+             "bufs": {}, "iter": 0}
+    om = opt.run_step(ocfg, state, ([orecs[0]], [orecs[1]], [orecs[0]], [orecs[1]]), {"label": ratios, "unlabel": []},
+                      perm_fn=kp)
+    _compare_step(m, om, kp, tr, state, params, ["loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"], [], "configs[1]")
+
+
+def test_baseline_config2_full_mutual_learning_step_1333x800_vs_oracle():
+    """BASELINE.json configs[2] shape: final_c2f.yaml, BURN_UP_STEP = 0 -> EMA copy, teacher forward + pseudo labels,
+    shrink-paste, joint supervised + unsupervised student pass, one backward, clip + SGD, with 1 labelled + 1 unlabelled
+    1333 x 800 image.  The student of the oracle is handed the HIP teacher's pseudo labels (so that all eight student
+    losses are compared on identical targets); the two teachers' pseudo labels are compared with each other."""
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.modeling import sampling
+    _threads()
+    cfg = setup_cfg("configs/pt/final_c2f.yaml", ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", 0,
+                                                  "SOLVER.IMG_PER_BATCH_LABEL", 1, "SOLVER.IMG_PER_BATCH_UNLABEL", 1])
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    ocfg = opt.Cfg(num_classes=K, anchor_generator=cfg.MODEL.ANCHOR_GENERATOR.NAME, burn_up_step=0,
+                   tau=tuple(cfg.UNSUPNET.TAU))
+    params, tparams = opt.golden_params(ocfg, 33), opt.golden_params(ocfg, 34)
+    r_unlabel, r_label = [0.7], [0.85]
+    seq = iter(r_unlabel + r_label)                     # run_step resizes unlabel_q first, then label_q (trainer.py:329-330)
+
+    class Recording(PTrainer):
+        mine = None
+
+        def process_pseudo_label(self, proposals, proposal_type, psedo_label_method=""):
+            out, nn = super().process_pseudo_label(proposals, proposal_type, psedo_label_method)
+            self.mine = out
+            return out, nn
+
+    tr = Recording(cfg, ratio_fn=lambda: next(seq))
+    _load(tr.model, params)
+    _load(tr.model_teacher, tparams)
+    assert tr.joint_student_pass
+    g = torch.Generator().manual_seed(5)
+    lab, olab = _records(g, 2, 800, 1333, K)            # label_q[0], label_k[0]
+    unl, ounl = _records(g, 2, 800, 1333, K)            # unlabel_q[0], unlabel_k[0] (their ground truth is dropped)
+    kp = opt.KeyedPerm(61, strict=False)
+    sampling.set_key_source(keyed_perm_source(kp))
+    try:
+        m = tr.run_step(([lab[0]], [lab[1]], [unl[0]], [unl[1]]))
+    finally:
+        sampling.set_key_source(None)
+    kp.start_replay()
+    override = []
+    for p in tr.mine:
+        o = opt.FreeInstances(p.image_size)
+        o.pseudo_boxes = d2.Boxes(p.pseudo_boxes.tensor.cpu().clone())
+        o.scores_logists, o.boxes_sigma = p.scores_logists.cpu().clone(), p.boxes_sigma.cpu().clone()
+        override.append(o)
+    state = {"student": {k: v.clone() for k, v in params.items()}, "teacher": {k: v.clone() for k, v in tparams.items()},
+             "bufs": {}, "iter": 0}
+    om = opt.run_step(ocfg, state, ([olab[0]], [olab[1]], [ounl[0]], [ounl[1]]), {"label": r_label, "unlabel": r_unlabel},
+                      perm_fn=kp, pseudo_override=override)
+    # EMA with keep_rate 0 at iter == BURN_UP_STEP: the teacher is a copy of the (pre-step) student on both sides
+    tsd = tr.model_teacher.state_dict()
+    for k in PROBES:
+        assert torch.equal(tsd[k].cpu(), params[k]) and torch.equal(state["teacher"][k], params[k]), "EMA copy " + k
+    # teacher pseudo labels, HIP vs oracle (order-insensitive: near-equal scores may swap ranks)
+    for mine, ref in zip(tr.mine, state["last_pseudo"]):
+        assert len(mine) == len(ref) == 100
+        zero = np.zeros(len(ref), np.int64)
+        frac, idx = match_detections(mine.pseudo_boxes.tensor.cpu(), zero, ref.pseudo_boxes.tensor, zero, box_tol=5e-2)
+        assert frac >= 0.95, f"pseudo boxes matched {frac:.3f}"
+        ok = idx >= 0
+        close(mine.scores_logists.cpu()[idx[ok]], ref.scores_logists[ok], 1e-3, 5e-4, "pseudo logits")
+    sup = [k + "_sup" for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg")]
+    unsup = [k + "_unsup" for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg")]
+    assert set(sup + unsup) <= set(m) and set(sup + unsup) <= set(om)
+    _compare_step(m, om, kp, tr, state, params, sup, unsup, "configs[2]")

@@ -130,3 +130,39 @@ def test_bucketed_reducer_overlaps_and_matches_plain_allreduce():
             # every bucket before the one holding the gradient-less parameter went out DURING backward
             assert launched == unused_bucket == len(buckets) - 1 and launched >= 2, (launched, unused_bucket)
     assert torch.equal(out[0][1][1][0], out[1][1][1][0]), "both ranks hold the same averaged gradient"
+
+
+def _worker_metrics(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from probabilisticteacher_amd.engine.trainer import PTrainer
+    me = SimpleNamespace(world_size=world, METRIC_KEYS=PTrainer.METRIC_KEYS, last_metrics={})
+    if rank == 0:
+        rec = {"loss_cls_sup": torch.tensor(1.0), "loss_rpn_cls_sup": torch.tensor(3.0), "loss_cls_unsup": torch.tensor(5.0)}
+    else:                                                     # a different key set on the other rank
+        rec = {"loss_cls_sup": torch.tensor(2.0), "loss_box_reg_sup": torch.tensor(7.0)}
+    PTrainer._write_metrics(me, rec, 0.25 + rank, torch.tensor([4.0 * (rank + 1) ** 2]))
+    q.put((rank, me.last_metrics))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_write_metrics_reference_semantics_with_rank_dependent_keys():
+    """reference trainer.py:403-417: rank 0's keys, each the mean over ALL ranks with 0.0 where a rank lacks the key;
+    data_time = max over ranks"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_metrics, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m0 = out[0]
+    assert set(m0) == {"loss_cls_sup", "loss_rpn_cls_sup", "loss_cls_unsup", "total_loss", "grad_norm", "data_time"}
+    assert m0["loss_cls_sup"] == 1.5 and m0["loss_rpn_cls_sup"] == 1.5 and m0["loss_cls_unsup"] == 2.5
+    assert m0["total_loss"] == 5.5 and m0["data_time"] == 1.25 and m0["grad_norm"] == 2.0 and out[1]["grad_norm"] == 4.0

@@ -335,20 +335,49 @@ def test_rpn_prepare(ops):
     sigma = torch.randn(n, r, 4, generator=gen)
     sizes = torch.tensor([[600.0, 800.0], [544.0, 720.0]])
     srt, idx = logits.sort(descending=True, dim=1, stable=True)
-    boxes, scores, valid, nonfin = ops.rpn_prepare(dec.to(DEV), srt.to(DEV), idx.int().to(DEV), sigma.to(DEV),
-                                                   sizes.to(DEV), k, 0.0)
+    boxes, keys, counts, nonfin = ops.rpn_prepare(dec.to(DEV), srt.to(DEV), idx.int().to(DEV), sigma.to(DEV),
+                                                  sizes.to(DEV), k, 0.0)
     for i in range(n):
         bx = d2.Boxes(dec[i][idx[i, :k]].clone())
         bx.clip((int(sizes[i, 0]), int(sizes[i, 1])))
         assert torch.equal(boxes[i].cpu(), bx.tensor), "clipped boxes must be bit-exact"
-        assert torch.equal(valid[i].cpu().bool(), bx.nonempty(0.0)), "nonempty mask must be bit-exact"
+        ne = bx.nonempty(0.0)
+        valid = keys[i].cpu() != float("-inf")
+        assert torch.equal(valid, ne), "nonempty mask must be bit-exact"
+        assert int(counts[i]) == int(ne.sum()) and 0 < int(ne.sum()) < k, "kept count"
         ref_sc = srt[i, :k] * (1 - torch.sigmoid(sigma[i, :k]).sum(-1) / 4.0)
-        close(scores[i], ref_sc, 1e-5, 1e-6, "rescoring")
+        close(keys[i].cpu()[valid], ref_sc[valid], 1e-5, 1e-6, "rescoring")
     assert int(nonfin.sum()) == 0
     dec[1, idx[1, 3], 0] = float("inf")
-    _, _, valid2, nonfin2 = ops.rpn_prepare(dec.to(DEV), srt.to(DEV), idx.int().to(DEV), sigma.to(DEV), sizes.to(DEV),
-                                            k, 0.0)
-    assert nonfin2.cpu().tolist() == [0, 1] and not bool(valid2[1, 3])
+    _, keys2, counts2, nonfin2 = ops.rpn_prepare(dec.to(DEV), srt.to(DEV), idx.int().to(DEV), sigma.to(DEV),
+                                                 sizes.to(DEV), k, 0.0)
+    assert nonfin2.cpu().tolist() == [0, 1] and float(keys2[1, 3]) == float("-inf")
+    assert int(counts2[1]) == int(counts[1]) - int(keys[1, 3] != float("-inf"))
+    # k < 64: a wave spans several images (per-image counting peels one image at a time)
+    n, r, k = 5, 40, 17
+    dec = torch.rand(n, r, 4, generator=gen) * 50
+    dec[..., 2:] = dec[..., :2] + torch.rand(n, r, 2, generator=gen) * 40 - 10
+    srt, idx = torch.randn(n, r, generator=gen).sort(descending=True, dim=1, stable=True)
+    sizes = torch.tensor([[64.0, 64.0]] * n)
+    boxes, keys, counts, _ = ops.rpn_prepare(dec.to(DEV), srt.to(DEV), idx.int().to(DEV), torch.zeros(n, r, 4, device=DEV),
+                                             sizes.to(DEV), k, 0.0)
+    assert counts.cpu().tolist() == (keys.cpu() != float("-inf")).sum(1).tolist()
+
+
+def test_nms_with_device_side_counts(ops):
+    """fixed-capacity segments: only the first seg_counts[i] boxes of a segment exist"""
+    gen = g(77)
+    cap, fills, thr = 700, [700, 0, 333, 64, 1], 0.6
+    allb, refs = [], []
+    for f in fills:
+        b = _rand_boxes(gen, cap, 300, 300, lo=8.0)
+        allb.append(b)
+        refs.append(d2.nms(b[:f], torch.arange(f, 0, -1).float(), thr)[:50] if f else torch.zeros(0, dtype=torch.int64))
+    seg = torch.arange(0, (len(fills) + 1) * cap, cap, dtype=torch.int32, device=DEV)
+    keep, cnt = ops.nms_batched(torch.cat(allb).to(DEV), seg, cap, thr, 50,
+                                seg_counts=torch.tensor(fills, dtype=torch.int32, device=DEV))
+    for i, ref in enumerate(refs):
+        assert int(cnt[i]) == len(ref) and torch.equal(keep[i, :len(ref)].cpu().long(), ref), f"segment {i}"
 
 
 # ------------------------------------------------------------------------------------------ losses
