@@ -589,6 +589,18 @@ def c2_xavier_fill(module: torch.nn.Module) -> None:
 # --------------------------------------------------------------------------- #
 # A.15 LR schedule / optimiser
 # --------------------------------------------------------------------------- #
+def warmup_factor_at_iter(method: str, it: int, warmup_iters: int, warmup_factor: float) -> float:
+    """detectron2 0.5 `_get_warmup_factor_at_iter` (imported by the reference at pt/solver/lr_scheduler.py:19)."""
+    if it >= warmup_iters:
+        return 1.0
+    if method == "constant":
+        return warmup_factor
+    if method == "linear":
+        alpha = it / warmup_iters
+        return warmup_factor * (1 - alpha) + alpha
+    raise ValueError("Unknown warmup method: {}".format(method))
+
+
 def warmup_multistep_lr(it: int, base_lr: float, steps: Sequence[int], gamma: float = 0.1,
                         warmup_factor: float = 1e-3, warmup_iters: int = 1000,
                         warmup_method: str = "linear") -> float:

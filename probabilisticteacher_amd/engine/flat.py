@@ -166,16 +166,4 @@ def broadcast_(flat: torch.Tensor, src: int = 0, group=None):
     return flat
 
 
-def lr_at(cfg, it: int) -> float:
-    """D2 WarmupMultiStepLR: BASE_LR * warmup(it) * GAMMA^bisect_right(STEPS, it)."""
-    import bisect
-
-    S = cfg.SOLVER
-    if it >= S.WARMUP_ITERS:
-        f = 1.0
-    elif S.WARMUP_METHOD == "constant":
-        f = S.WARMUP_FACTOR
-    else:
-        alpha = it / S.WARMUP_ITERS
-        f = S.WARMUP_FACTOR * (1 - alpha) + alpha
-    return S.BASE_LR * f * S.GAMMA ** bisect.bisect_right(list(S.STEPS), it)
+from ..solver import lr_at  # noqa: E402,F401  (re-exported: the schedule lives in solver.py)

@@ -15,7 +15,8 @@ import torch.distributed as dist
 from .. import ops
 from ..modeling import EnsembleTSModel, build_model
 from ..structures import Boxes, FreeInstances
-from .flat import BucketedGradReducer, FlatParams, broadcast_, lr_at
+from ..solver import check_optimizer_options, lr_at
+from .flat import BucketedGradReducer, FlatParams, broadcast_
 
 
 class PTrainer:
@@ -24,6 +25,7 @@ class PTrainer:
         """force_grad_reducer: run the bucketed gradient all-reduce (hooks + collectives) even with one rank -- needs an
         initialised process group; the sum over one rank is the identity (single-GPU validation of the DDP path)."""
         self.cfg = cfg
+        check_optimizer_options(cfg)
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.model = build_model(cfg)                  # student
         self.model_teacher = build_model(cfg)          # teacher (per-rank replica, never all-reduced)
@@ -221,13 +223,52 @@ class PTrainer:
         m["data_time"] = data_time
         self.last_metrics = m
 
-    def train(self, start_iter=0, max_iter=None):
-        self.iter = self.start_iter = start_iter
-        for _ in range(start_iter, max_iter or self.max_iter):
-            self.run_step()
+    # ------------------------------------------------------------------ trainer shell (trainer.py:466-547)
+    def resume_or_load(self, resume: bool = False):
+        """trainer.py:466-496: weights (resume=False) or weights + optimiser + iteration (resume=True) from
+        cfg.MODEL.WEIGHTS; parameters are then broadcast from rank 0 (`_sync_params_and_buffers`)."""
+        from .. import checkpoint
+        inc = checkpoint.resume_or_load(self, resume=resume)
+        broadcast_(self.student.flat)
+        broadcast_(self.teacher.flat)
+        if self.world_size > 1:
+            t = torch.tensor([self.start_iter], device=self.student.flat.device)
+            dist.broadcast(t, src=0)
+            self.iter = self.start_iter = int(t.item())
+        return inc
 
-    def state_dict(self):
-        return {"model": self.ensem_ts_model.state_dict(), "momentum": self.momentum_buf, "iteration": self.iter}
+    def train(self, start_iter: Optional[int] = None, max_iter: Optional[int] = None, log_period: int = 20):
+        """TrainerBase.train with the reference's hooks (trainer.py:498-547) that do not need a dataset: LR schedule
+        (folded into the fused step), PeriodicCheckpointer (rank 0: model_{iter:07d}.pth every CHECKPOINT_PERIOD
+        iterations, model_final.pth, `last_checkpoint`), PeriodicWriter every 20 iterations (console line + one JSON
+        record per line in OUTPUT_DIR/metrics.json, D2's JSONWriter format)."""
+        import json
+        import os
+        from .. import checkpoint
+        if start_iter is not None:
+            self.iter = self.start_iter = start_iter
+        max_iter = max_iter or self.max_iter
+        rank0 = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        ckpt = checkpoint.PeriodicCheckpointer(self, self.cfg.SOLVER.CHECKPOINT_PERIOD, max_iter) if rank0 else None
+        out_dir = self.cfg.OUTPUT_DIR
+        if rank0:
+            os.makedirs(out_dir, exist_ok=True)
+        t_last, it_last = time.perf_counter(), self.iter
+        while self.iter < max_iter:
+            it = self.iter
+            m = self.run_step()
+            if ckpt is not None:
+                ckpt.step(it)
+            if rank0 and ((it + 1) % log_period == 0 or it == max_iter - 1):
+                now = time.perf_counter()
+                rec = dict(m, iteration=it, lr=lr_at(self.cfg, it), time=(now - t_last) / max(it + 1 - it_last, 1))
+                t_last, it_last = now, it + 1
+                with open(os.path.join(out_dir, "metrics.json"), "a") as f:
+                    f.write(json.dumps(rec, sort_keys=True) + "\n")
+                print(f"iter: {it}  total_loss: {m['total_loss']:.4f}  " +
+                      "  ".join(f"{k}: {v:.4f}" for k, v in m.items() if k[:4] == "loss") +
+                      f"  time: {rec['time']:.4f}  lr: {rec['lr']:.6f}", flush=True)
+        return self.last_metrics
 
 
 def _flatten_like(model, ref: FlatParams) -> FlatParams:

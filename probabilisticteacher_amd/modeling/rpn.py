@@ -96,8 +96,10 @@ class GuassianRPN(nn.Module):
         self.cfg = cfg
         self.in_features = R.IN_FEATURES
         shapes = [input_shape[f] for f in self.in_features]
-        self.anchor_generator = build_anchor_generator(cfg, shapes)
+        # registration order as in D2's RPN.__init__ (head, then anchor generator): it fixes the state_dict key order
+        # and, through D2's build_optimizer, the parameter numbering of the optimiser state in checkpoints
         self.rpn_head = build_rpn_head(cfg, shapes)
+        self.anchor_generator = build_anchor_generator(cfg, shapes)
         self.box2box_transform = Box2BoxTransform(weights=R.BBOX_REG_WEIGHTS)
         self.iou_thresholds, self.iou_labels = list(R.IOU_THRESHOLDS), list(R.IOU_LABELS)
         self.batch_size_per_image = R.BATCH_SIZE_PER_IMAGE

@@ -101,29 +101,6 @@ def test_structures_and_sampler():
     assert torch.equal(got[0], ref) and len(rp) == 2 and len(rn) == 2
 
 
-def test_checkpoint_layout_roundtrip(tmp_path):
-    """modelTeacher.* / modelStudent.* key layout (ts_ensemble.py:20-29) survives a save -> load round trip."""
-    import types
-    from probabilisticteacher_amd import checkpoint
-    from probabilisticteacher_amd.engine.flat import FlatParams
-    from probabilisticteacher_amd.modeling import EnsembleTSModel
-    torch.manual_seed(0)
-    s, t = torch.nn.Linear(4, 3), torch.nn.Linear(4, 3)
-    tr = types.SimpleNamespace(model=s, model_teacher=t, ensem_ts_model=EnsembleTSModel(t, s), iter=7, start_iter=0,
-                               student=FlatParams(s), _first_step=False)
-    tr.momentum_buf = torch.arange(tr.student.n_trainable, dtype=torch.float32)
-    p = str(tmp_path / "model_0000006.pth")
-    checkpoint.save_checkpoint(tr, p)
-    raw = torch.load(p)
-    assert sorted(raw["model"]) == ["modelStudent.bias", "modelStudent.weight", "modelTeacher.bias", "modelTeacher.weight"]
-    want = {k: v.clone() for k, v in tr.ensem_ts_model.state_dict().items()}
-    with torch.no_grad():
-        for v in tr.ensem_ts_model.state_dict().values():
-            v.zero_()
-    tr.iter, tr.momentum_buf = 0, torch.zeros_like(tr.momentum_buf)
-    checkpoint.load_checkpoint(tr, p)
-    assert all(torch.equal(v, want[k]) for k, v in tr.ensem_ts_model.state_dict().items())
-    assert tr.iter == 7 and float(tr.momentum_buf[-1]) == tr.student.n_trainable - 1
 
 
 def test_detector_postprocess_rescales_clips_and_drops_empty():
@@ -176,3 +153,136 @@ def test_keyed_sampling_equals_reference_subsample_labels():
     p1 = int((labels[1] == 1).sum())
     assert 0 < p1 <= 20 and int((got[1] == 1).sum()) == p1 and int((got[1] == 0).sum()) == 256 - p1
     assert int((got[2] == 1).sum()) == 0 and int((got[2] == 0).sum()) == 50 and int((got[3] == 1).sum()) == 128
+
+
+def test_lr_schedules_match_the_reference_table():
+    """WarmupTwoStageMultiStepLR: lr(it) of the REAL reference class driving a real torch SGD (tests/golden/
+    solver_checkpoint.npz, tools/gen_golden.py::gen_solver_checkpoint); WarmupCosineLR / unknown names; optimiser options
+    that the fused step does not implement fail loudly."""
+    import numpy as np
+    import pytest
+    from probabilisticteacher_amd import solver
+    from probabilisticteacher_amd.config import setup_cfg
+    z = np.load(os.path.join(ROOT, "tests", "golden", "solver_checkpoint.npz"))
+    base, wf, wi, s0, s1, f0, f1, f2 = [float(v) for v in z["lr_twostage_cfg"]]
+    cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), [
+        "SOLVER.LR_SCHEDULER_NAME", "WarmupTwoStageMultiStepLR", "SOLVER.BASE_LR", base, "SOLVER.WARMUP_FACTOR", wf,
+        "SOLVER.WARMUP_ITERS", int(wi), "SOLVER.STEPS", (int(s0), int(s1)), "SOLVER.FACTOR_LIST", (f0, f1, f2)])
+    got = [solver.lr_at(cfg, it) for it in range(len(z["lr_twostage"]))]
+    assert np.allclose(got, z["lr_twostage"], rtol=1e-12, atol=0)
+    cos = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), ["SOLVER.LR_SCHEDULER_NAME", "WarmupCosineLR",
+                                                                    "SOLVER.MAX_ITER", 1000, "SOLVER.WARMUP_ITERS", 10])
+    assert math.isclose(solver.lr_at(cos, 500), 0.016 * 0.5) and math.isclose(solver.lr_at(cos, 0), 0.016 * 1e-3)
+    for bad in (["SOLVER.LR_SCHEDULER_NAME", "StepLR"], ["SOLVER.NESTEROV", True], ["SOLVER.BIAS_LR_FACTOR", 2.0],
+                ["SOLVER.WEIGHT_DECAY_BIAS", 0.0], ["SOLVER.STEPS", (5, 3), "SOLVER.LR_SCHEDULER_NAME", "WarmupTwoStageMultiStepLR",
+                                                   "SOLVER.FACTOR_LIST", (1, 1, 1)]):
+        with pytest.raises(ValueError):
+            solver.check_optimizer_options(setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), bad))
+
+
+def _cpu_trainer(tmp_path, extra=()):
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), [
+        "MODEL.DEVICE", "cpu", "MODEL.VGG.PRETRAIN", "", "MODEL.ANCHOR_GENERATOR.NAME", "DifferentiableAnchorGenerator",
+        "OUTPUT_DIR", str(tmp_path)] + list(extra))
+    return cfg, PTrainer(cfg)
+
+
+def test_checkpoint_file_has_the_reference_layout(tmp_path):
+    """The file `save_checkpoint` writes against what the reference's own classes produce (EnsembleTSModel key layout,
+    D2's per-parameter SGD groups in modules() order, torch SGD / scheduler state_dict keys, fvcore's top-level dict;
+    tests/golden/solver_checkpoint.npz), and the off-by-one-free iteration bookkeeping: "iteration" = the
+    iteration that just finished, resume continues at iteration + 1."""
+    import numpy as np
+    from probabilisticteacher_amd import checkpoint
+    z = np.load(os.path.join(ROOT, "tests", "golden", "solver_checkpoint.npz"))
+    cfg, tr = _cpu_trainer(tmp_path)
+    g = torch.Generator().manual_seed(1)
+    tr.momentum_buf.copy_(torch.randn(tr.momentum_buf.shape, generator=g))
+    tr._first_step = False
+    tr.iter = 2                                               # two iterations (0 and 1) are done
+    path = checkpoint.PeriodicCheckpointer(tr, period=2, max_iter=100).step(1)
+    assert os.path.basename(path) == "model_0000001.pth" and checkpoint.last_checkpoint(str(tmp_path)) == path
+    raw = torch.load(path, weights_only=False)
+    assert list(raw.keys()) == list(z["top_keys"]) and raw["iteration"] == int(z["iteration"][0]) == 1
+    assert list(raw["model"].keys()) == list(z["model_keys"])
+    assert [",".join(str(d) for d in v.shape) for v in raw["model"].values()] == list(z["model_shapes"])
+    osd = raw["optimizer"]
+    assert [n for n, p in tr.model.named_parameters() if p.requires_grad] == list(z["opt_index_names"])
+    assert [gr["params"][0] for gr in osd["param_groups"]] == list(z["opt_group_params"])
+    assert set(osd["param_groups"][0]) <= set(z["opt_group_keys"]) and {"lr", "momentum", "weight_decay", "nesterov", "params"} <= set(osd["param_groups"][0])
+    assert sorted(osd["state"][0].keys()) == list(z["opt_state_keys"])
+    assert raw["scheduler"]["last_epoch"] == int(z["sched_last_epoch"][0]) == 2 and set(raw["scheduler"]) <= set(z["sched_keys"])
+    # a real torch.optim.SGD (the reference's optimiser class) built the D2 way accepts the state, and its momentum
+    # buffers are the slices of the flat buffer
+    params = [p for _, p in tr.model.named_parameters() if p.requires_grad]
+    sgd = torch.optim.SGD([{"params": [p]} for p in params], lr=0.016, momentum=0.9)
+    sgd.load_state_dict(osd)
+    names = list(z["opt_index_names"])
+    for j in (0, 5, len(names) - 1):
+        off, k = tr.student.index[names[j]]
+        assert torch.equal(sgd.state[params[j]]["momentum_buffer"].reshape(-1), tr.momentum_buf[off:off + k])
+    # ... and the way back: a state_dict produced by torch SGD loads into the flat buffer; resume = iteration + 1
+    cfg2, tr2 = _cpu_trainer(tmp_path)
+    raw["optimizer"] = sgd.state_dict()
+    torch.save(raw, path)
+    inc = checkpoint.load_checkpoint(tr2, path, resume=True)
+    assert inc == checkpoint.IncompatibleKeys([], [], []) and tr2.iter == tr2.start_iter == 2 and not tr2._first_step
+    assert torch.equal(tr2.momentum_buf, tr.momentum_buf) and torch.equal(tr2.student.flat, tr.student.flat)
+    assert torch.equal(tr2.teacher.flat, tr.teacher.flat)
+    # weights only (resume=False): iteration and momentum untouched
+    cfg3, tr3 = _cpu_trainer(tmp_path)
+    checkpoint.load_checkpoint(tr3, path, resume=False)
+    assert tr3.iter == 0 and tr3._first_step and float(tr3.momentum_buf.abs().sum()) == 0.0
+    assert torch.equal(tr3.student.flat, tr.student.flat)
+
+
+def test_student_only_checkpoints_prefix_shapes_and_final(tmp_path):
+    """detection_checkpoint.py:26-50,75-103: a Caffe2-tagged / bare-key file updates the student only; a `module.` prefix
+    is stripped; wrongly-shaped tensors are reported and skipped (never broadcast); missing keys are reported;
+    PeriodicCheckpointer writes model_final.pth after the last iteration."""
+    from probabilisticteacher_amd import checkpoint
+    cfg, tr = _cpu_trainer(tmp_path)
+    t0 = tr.teacher.flat.clone()
+    sd = {("module." + k): torch.full_like(v, 0.5) for k, v in tr.model.state_dict().items()}
+    k_bad = "module.roi_heads.box_predictor.cls_score.bias"
+    sd[k_bad] = torch.zeros(1)                                # would broadcast under a bare copy_()
+    del sd["module.proposal_generator.rpn_head.conv.bias"]
+    sd["module.not_in_model"] = torch.zeros(2)
+    p = str(tmp_path / "student.pth")
+    torch.save({"model": sd, "__author__": "Caffe2"}, p)
+    before = tr.model.state_dict()["roi_heads.box_predictor.cls_score.bias"].clone()
+    inc = checkpoint.load_checkpoint(tr, p, resume=False)
+    assert inc.missing_keys == ["proposal_generator.rpn_head.conv.bias"] and inc.unexpected_keys == ["not_in_model"]
+    assert inc.incorrect_shapes == [("roi_heads.box_predictor.cls_score.bias", (1,), tuple(before.shape))]
+    ssd = tr.model.state_dict()
+    assert torch.equal(ssd["roi_heads.box_predictor.cls_score.bias"], before)
+    assert float(ssd["backbone.vgg_block4.0.conv2.weight"].mean()) == 0.5 and torch.equal(tr.teacher.flat, t0)
+    tr.iter = 10
+    out = checkpoint.PeriodicCheckpointer(tr, period=0, max_iter=10).step(9)
+    assert os.path.basename(out) == "model_final.pth" and torch.load(out, weights_only=False)["iteration"] == 9
+
+
+def test_vgg_pretrained_key_map_matches_the_reference(tmp_path):
+    """vgg.py:127-152: which `features.N` tensor of vgg16_caffe.pth each backbone parameter receives, as recorded from the
+    real VGG.__init__ (every source tensor carried a distinct constant), and which parameters FREEZE_AT=2 freezes."""
+    import numpy as np
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.modeling import build_model
+    z = np.load(os.path.join(ROOT, "tests", "golden", "solver_checkpoint.npz"))
+    cfg0 = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), ["MODEL.DEVICE", "cpu", "MODEL.VGG.PRETRAIN", ""])
+    shapes = {k: v.shape for k, v in build_model(cfg0).backbone.state_dict().items()}
+    sd, val = {}, {}
+    for mk, sk in zip(z["vgg_model_keys"], z["vgg_source_keys"]):
+        val[str(sk)] = float(len(val) + 1)
+        sd[str(sk)] = torch.full(shapes[str(mk)], val[str(sk)])
+    path = str(tmp_path / "vgg16_caffe.pth")
+    torch.save(sd, path)
+    cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), ["MODEL.DEVICE", "cpu", "MODEL.VGG.PRETRAIN", path])
+    bb = build_model(cfg).backbone
+    got = bb.state_dict()
+    assert list(got.keys()) == list(z["vgg_model_keys"])
+    for mk, sk in zip(z["vgg_model_keys"], z["vgg_source_keys"]):
+        assert float(got[str(mk)].flatten()[0]) == val[str(sk)], f"{mk} <- {sk}"
+    assert [n for n, p in bb.named_parameters() if not p.requires_grad] == list(z["vgg_frozen"])

@@ -115,6 +115,7 @@ def install_stubs():
         "detectron2.utils.comm": dict(get_world_size=lambda: 1, gather=lambda x, dst=0: [x],
                                       is_main_process=lambda: True, get_local_rank=lambda: 0),
         "fvcore.nn.weight_init": dict(c2_msra_fill=d2.c2_msra_fill, c2_xavier_fill=d2.c2_xavier_fill),
+        "detectron2.solver.lr_scheduler": dict(_get_warmup_factor_at_iter=d2.warmup_factor_at_iter),
     }
     for name, attrs in real.items():
         m = mod(name)
@@ -470,11 +471,101 @@ def gen_run_step():
     save("run_step", **out)
 
 
+def gen_solver_checkpoint():
+    """Facts about the LR schedule and the checkpoint file that only the reference's own classes can supply:
+      * lr(it) of the REAL pt.solver.lr_scheduler.WarmupTwoStageMultiStepLR driving a real torch SGD;
+      * the key layout of `EnsembleTSModel(teacher, student).state_dict()` (pt/modeling/meta_arch/ts_ensemble.py) over the
+        real reference model, the order in which D2's build_optimizer (one param group per trainable parameter, modules()
+        traversal) numbers the parameters, the keys of a torch SGD / _LRScheduler state_dict, and the dict fvcore's
+        Checkpointer.save writes ({"model", "optimizer", "scheduler", "iteration"}; the iteration that just finished);
+      * which `features.N` tensor of vgg16_caffe.pth each backbone parameter receives in the real VGG.__init__ (vgg.py:127-152).
+    Only names, shapes and small number tables are stored."""
+    from pt.solver.lr_scheduler import WarmupTwoStageMultiStepLR
+    from pt.modeling.meta_arch.ts_ensemble import EnsembleTSModel
+    out = {}
+    # ---- schedule
+    w = torch.nn.Parameter(torch.zeros(3))
+    sgd = torch.optim.SGD([w], lr=0.016, momentum=0.9)
+    sch = WarmupTwoStageMultiStepLR(sgd, milestones=[10, 25], factor_list=[1, 0.3, 0.05], warmup_factor=1e-3, warmup_iters=8,
+                                    warmup_method="linear")
+    lrs = []
+    for it in range(40):
+        lrs.append(sgd.param_groups[0]["lr"])
+        w.grad = torch.ones(3)
+        sgd.step()
+        sch.step()
+    out["lr_twostage"] = np.asarray(lrs, np.float64)
+    out["lr_twostage_cfg"] = np.asarray([0.016, 1e-3, 8, 10, 25, 1, 0.3, 0.05], np.float64)
+    # ---- checkpoint layout
+    K, anchor, tau = 8, "DifferentiableAnchorGenerator", (0.5, 0.5)
+    cfg, ocfg, params, student = build_reference_model(K, anchor, tau, seed=3)
+    _, _, tparams, teacher = build_reference_model(K, anchor, tau, seed=4)
+    ens = EnsembleTSModel(teacher, student)
+    esd = ens.state_dict()
+    out["model_keys"] = np.asarray(list(esd.keys()))
+    out["model_shapes"] = np.asarray([",".join(str(d) for d in v.shape) for v in esd.values()])
+    # D2 0.5 build_optimizer -> get_default_optimizer_params: one group per trainable parameter, modules() order
+    groups, names, memo = [], [], set()
+    pname = {id(p): n for n, p in student.named_parameters()}
+    for module in student.modules():
+        for _, value in module.named_parameters(recurse=False):
+            if not value.requires_grad or id(value) in memo:
+                continue
+            memo.add(id(value))
+            groups.append({"params": [value], "lr": cfg.SOLVER.BASE_LR, "weight_decay": cfg.SOLVER.WEIGHT_DECAY})
+            names.append(pname[id(value)])
+    opt_ = torch.optim.SGD(groups, lr=cfg.SOLVER.BASE_LR, momentum=0.9, nesterov=False)   # D2 defaults the reference keeps
+    sch = WarmupTwoStageMultiStepLR(opt_, milestones=[30000], factor_list=[1, 0.1], warmup_factor=1e-3, warmup_iters=400)
+    g = torch.Generator().manual_seed(9)
+    for it in range(2):
+        for grp in groups:
+            p = grp["params"][0]
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3
+        opt_.step()
+        sch.step()
+    data = {"model": esd, "optimizer": opt_.state_dict(), "scheduler": sch.state_dict(), "iteration": 1}   # Checkpointer.save
+    out["top_keys"] = np.asarray(list(data.keys()))
+    osd = data["optimizer"]
+    out["opt_index_names"] = np.asarray(names)
+    out["opt_group_keys"] = np.asarray(sorted(osd["param_groups"][0].keys()))
+    out["opt_group_params"] = np.asarray([g_["params"][0] for g_ in osd["param_groups"]], np.int64)
+    out["opt_state_keys"] = np.asarray(sorted(osd["state"][0].keys()))
+    probe = [0, 5, len(names) - 1]
+    out["opt_probe_index"] = np.asarray(probe, np.int64)
+    for j in probe:
+        out[f"opt_probe_momentum_head_{j}"] = osd["state"][j]["momentum_buffer"].flatten()[:8]
+    out["opt_grad_seed"] = np.asarray([9])
+    out["sched_keys"] = np.asarray(sorted(data["scheduler"].keys()))
+    out["sched_last_epoch"] = np.asarray([data["scheduler"]["last_epoch"]])
+    out["iteration"] = np.asarray([data["iteration"]])
+    # ---- vgg16_caffe.pth key map as the real VGG.__init__ applies it: every source tensor gets a distinct constant
+    tmp = tempfile.mkdtemp()
+    vp = os.path.join(tmp, "vgg16_caffe.pth")
+    sd, val = {}, {}
+    for j, i in enumerate([0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]):
+        for sfx in ("weight", "bias"):
+            ref = params[[n for n in params if n.startswith("backbone.")][2 * j + (sfx == "bias")]]
+            sd[f"features.{i}.{sfx}"] = torch.full(ref.shape, float(len(val) + 1))
+            val[float(len(val) + 1)] = f"features.{i}.{sfx}"
+    torch.save(sd, vp)
+    import pt.modeling.backbone.vgg as refvgg
+    bcfg = build_cfg(K, anchor, tau, vp)
+    bb = refvgg.build_vgg_backbone(bcfg, dm.ShapeSpec(channels=3))
+    keys, srcs = [], []
+    for n, p in bb.state_dict().items():
+        keys.append(n)
+        srcs.append(val[float(p.flatten()[0])])
+    out["vgg_model_keys"] = np.asarray(keys)
+    out["vgg_source_keys"] = np.asarray(srcs)
+    out["vgg_frozen"] = np.asarray([n for n, p in bb.named_parameters() if not p.requires_grad])
+    save("solver_checkpoint", **out)
+
+
 def main():
     install_stubs()
     torch.Tensor.cuda = lambda self, *a, **k: self   # anchor_generator.py:69 hard-codes .cuda()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["codec", "pieces", "model", "step"]
+    which = sys.argv[1:] or ["codec", "pieces", "model", "step", "solver"]
     if "codec" in which:
         gen_box_codec()
     if "pieces" in which:
@@ -484,6 +575,8 @@ def main():
         gen_model_branches("DifferentiableAnchorGenerator", "diff_anchor")
     if "step" in which:
         gen_run_step()
+    if "solver" in which:
+        gen_solver_checkpoint()
 
 
 if __name__ == "__main__":

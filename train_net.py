@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--num-gpus", type=int, default=1)
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--max-iter", type=int, default=None)
+    ap.add_argument("--resume", action="store_true",
+                    help="continue from MODEL.WEIGHTS (or OUTPUT_DIR/last_checkpoint): weights, optimiser state, iteration")
+    ap.add_argument("--eval-only", action="store_true")
     ap.add_argument("opts", nargs=argparse.REMAINDER)
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
@@ -52,11 +55,16 @@ def main():
         raise SystemExit("only --synthetic input is available in this build (the data pipeline is out of scope)")
     torch.manual_seed(0)
     trainer = PTrainer(cfg, data_loader=synthetic_loader(cfg, torch.device("cuda", local), rank, world))
-    for it in range(args.max_iter or cfg.SOLVER.MAX_ITER):
-        m = trainer.run_step()
-        if rank == 0 and it % 20 == 0:
-            print(f"iter {it}: total_loss {m['total_loss']:.4f} grad_norm {m['grad_norm']:.3f} "
-                  + " ".join(f"{k} {v:.4f}" for k, v in m.items() if k.startswith("loss")), flush=True)
+    inc = trainer.resume_or_load(resume=args.resume)          # trainer.py:466-496 (no-op without MODEL.WEIGHTS / checkpoint)
+    if inc is not None and rank == 0:
+        print(f"loaded {cfg.MODEL.WEIGHTS or 'last_checkpoint'}: start_iter {trainer.start_iter}, "
+              f"missing {len(inc.missing_keys)}, unexpected {len(inc.unexpected_keys)}, wrong shape {len(inc.incorrect_shapes)}",
+              flush=True)
+    if args.eval_only:
+        raise SystemExit("--eval-only needs a dataset + evaluator (pt/engine/trainer.py:127-137); not part of this build yet")
+    trainer.train(max_iter=args.max_iter)                      # periodic checkpoints, metrics.json, model_final.pth
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
