@@ -79,20 +79,24 @@ def cpu_baseline(h, w, K, seed=0, student_only=False):
                        f"1 unlabelled {w}x{h} image, {dt:.1f} s")}
 
 
+PMC_PROFILE = "profiles/r02_bench_b16_pmc_by_kernel.json"
+
+
 def pmc_traffic():
-    """HBM-side bytes per conv fwd/dgrad launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_bench_b16_pmc_by_kernel.json: FETCH_SIZE and WRITE_SIZE in KB, collected in separate --pmc passes;
-    FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md).  None if the profile is absent."""
-    f = os.path.join(ROOT, "profiles", "r01_bench_b16_pmc_by_kernel.json")
+    """HBM-side bytes per conv fwd/dgrad launch: NOT measured in this run (PMC collection serialises kernels and needs
+    rocprofv3) -- read from the committed rocprofv3 PMC passes of this same command (tools/pmc_collect.py: FETCH_SIZE and
+    WRITE_SIZE in KB from separate --pmc passes, FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md),
+    restricted to the kernels this bench launches.  Returns (bytes per launch, provenance) or (None, reason)."""
+    f = os.path.join(ROOT, PMC_PROFILE)
     if not os.path.exists(f):
-        return None
+        return None, f"{PMC_PROFILE} absent"
     d = json.load(open(f))
     tot, n = 0.0, 0
-    for k, v in d.items():
-        if k.startswith("conv3x3_buf_kernel") or k.startswith("conv3x3_direct_kernel"):
+    for k, v in d.get("kernels", {}).items():
+        if k.startswith("conv3x3_buf_kernel") or k.startswith("conv3x3_stem_kernel"):
             tot += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
             n += v["dispatches"]
-    return tot / n if n else None
+    return (tot / n if n else None), f"{PMC_PROFILE} (collected on {d.get('git_head', '?')}, {d.get('command', '?')})"
 
 
 def main():
@@ -179,12 +183,16 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * 2 * B * args.steps / dt             # burn-in step: label_q + label_k = 2B images as well
+        srt = sorted(step_ms)
+        median = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        traffic, traffic_src = pmc_traffic()
         conv = prof.get("conv3x3_mfma", {"ms": 0.0, "flops": 0.0, "calls": 0})
         ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         out = {
             "metric": ("student-only train-step img/s at 1333x800" if args.student_only else
                        "teacher-student train-step img/s at 1333x800"), "value": value, "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "ms_per_step_median": median, "value_at_median": world * 2 * B / (median * 1e-3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[1]: final_c2f.yaml (K=8) student-only supervised fwd/bwd + clip + SGD, "
                                     f"per-GPU {2 * B} synthetic {W}x{H} images (strong + weak view of {B} labelled), random init"
@@ -193,9 +201,12 @@ def main():
                                     f"{B} labelled + {B} unlabelled synthetic {W}x{H} images, BURN_UP_STEP=0, random init"),
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic(),
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, committed profile)",
-                         "kernel": "conv3x3_buf_kernel<BM,NWAVE> (all 3x3 conv fwd + dgrad launches)", "calls": conv["calls"],
+                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["calls"], 1),
+                         "kernel": "conv3x3_buf_kernel<BM,NWAVE> + conv3x3_stem_kernel (all 3x3 conv fwd + dgrad launches)",
+                         "calls": conv["calls"],
                          "avg_launch_ms": conv["ms"] / max(conv["calls"], 1),
                          "flops_per_launch_avg": conv["flops"] / max(conv["calls"], 1)},
             "kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12)

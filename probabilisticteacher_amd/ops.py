@@ -65,22 +65,25 @@ def profile_start() -> None:
 
 
 def profile_stop() -> dict:
-    """Synchronise and return {kernel: {"ms", "flops", "calls"}} accumulated since profile_start()."""
+    """Synchronise and return {kernel: {"ms", "flops", "bytes", "calls"}} accumulated since profile_start()."""
     global _PROF
     rec, _PROF = _PROF or [], None
     torch.cuda.synchronize()
     out = {}
-    for name, flops, e0, e1 in rec:
-        d = out.setdefault(name, {"ms": 0.0, "flops": 0.0, "calls": 0})
+    for name, flops, nbytes, e0, e1 in rec:
+        d = out.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "calls": 0})
         d["ms"] += e0.elapsed_time(e1)
         d["flops"] += flops
+        d["bytes"] += nbytes
         d["calls"] += 1
     return out
 
 
 class _prof:
-    def __init__(self, name, flops=0.0):
-        self.name, self.flops = name, float(flops)
+    """flops / nbytes = ALGORITHMIC work of the launch group (every operand read once, every result written once)."""
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, float(flops), float(nbytes)
 
     def __enter__(self):
         if _PROF is not None:
@@ -92,7 +95,7 @@ class _prof:
     def __exit__(self, *exc):
         if _PROF is not None:
             self.e1.record()
-            _PROF.append((self.name, self.flops, self.e0, self.e1))
+            _PROF.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
         return False
 
 
@@ -111,7 +114,8 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     _chk(x, name="conv input")
     n, cin, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
-    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n):
+    nbytes = 4.0 * (n * h * w * (cin + cout * (2 if epilogue == 3 else 1)) + 9 * cin * cout)
+    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, nbytes):
         _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
                   epilogue, _stream())
     return y
@@ -124,7 +128,7 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     cout = weight.shape[0]
     wp = conv3x3_pack(_chk(weight.contiguous()), 0)
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
-    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n):
+    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, 4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout)):
         _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None, _ptr(y), n, cin, cout, h,
                   w, 4, _stream())
     return y
