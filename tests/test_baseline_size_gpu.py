@@ -220,50 +220,70 @@ def _spread(params, teacher=False):
     p = {k: v.clone() for k, v in params.items()}
     p["proposal_generator.rpn_head.objectness_logits.weight"] *= 30.0
     if teacher:
-        p["roi_heads.box_predictor.cls_score.weight"] *= 25.0
+        p["roi_heads.box_predictor.cls_score.weight"] *= 3.0
         p["roi_heads.box_predictor.cls_score.bias"][-1] += 2.0          # background-heavy: few candidates above 0.05
     return p
 
 
 class _ProposalLog:
-    """records the per-image outputs of find_top_rpn_proposals on both sides (the one index-producing stage whose
-    exact-threshold decisions can differ between fp32 implementations)"""
+    """The proposal stage is the one place where the two sides cannot be expected to agree END TO END at this size: 12 000
+    fp32 scores per image are denser than the accumulated rounding differences of a 14-layer conv stack (~1e-5 relative), so
+    adjacent ranks swap, and a single swap re-orders the proposal list and with it the position-indexed ROI sample -- on any
+    two fp32 implementations (cuDNN vs oneDNN as much as MFMA vs oneDNN).  `find_top_rpn_proposals` itself is verified
+    exactly on identical inputs (tests/test_functions_gpu.py).  Here the oracle's calls are therefore answered with the
+    proposals the HIP run produced (in call order), so that every later stage is compared on identical proposals; the
+    oracle's own proposals are still computed and compared with the HIP ones as SETS."""
 
     def __init__(self, monkeypatch):
         from probabilisticteacher_amd.modeling import rpn as hip_rpn
-        self.hip, self.ref = [], []
+        self.hip, self.ref, self.calls = [], [], []
         f_hip, f_ref = hip_rpn.find_top_rpn_proposals, opt.find_top_rpn_proposals
 
         def w_hip(*a, **k):
             out = f_hip(*a, **k)
-            self.hip += [o.proposal_boxes.tensor.cpu() for o in out]
+            self.calls.append([(o.proposal_boxes.tensor.cpu(), o.objectness_logits.cpu(), o.image_size) for o in out])
+            self.hip += [c[0] for c in self.calls[-1]]
             return out
 
         def w_ref(*a, **k):
-            out = f_ref(*a, **k)
-            self.ref += [o.proposal_boxes.tensor.clone() for o in out]
+            own = f_ref(*a, **k)
+            self.ref += [o.proposal_boxes.tensor.clone() for o in own]
+            rec = self.calls.pop(0)
+            assert len(rec) == len(own), "the two sides call the proposal stage in the same order"
+            out = []
+            for boxes, logits, size in rec:
+                r = opt.FreeInstances(size)
+                r.proposal_boxes, r.objectness_logits = d2.Boxes(boxes.clone()), logits.clone()
+                out.append(r)
             return out
         monkeypatch.setattr(hip_rpn, "find_top_rpn_proposals", w_hip)
         monkeypatch.setattr(opt, "find_top_rpn_proposals", w_ref)
 
-    def identical(self):
-        return len(self.hip) == len(self.ref) and all(torch.equal(a, b) for a, b in zip(self.hip, self.ref))
+    def check_sets(self):
+        """the oracle's own proposals vs the HIP ones, order-insensitive: same count (+-1 %) and most of the boxes present"""
+        assert len(self.hip) == len(self.ref) and not self.calls
+        out = []
+        for a, b in zip(self.hip, self.ref):
+            assert abs(len(a) - len(b)) <= max(2, len(b) // 100), f"proposal count {len(a)} vs {len(b)}"
+            za, zb = np.zeros(len(a), np.int64), np.zeros(len(b), np.int64)
+            frac, _ = match_detections(a, za, b, zb, box_tol=5e-3)
+            # greedy NMS amplifies a rank swap into a different survivor set; with random-init features (densely packed scores)
+            # 91-99.8 % of the survivors coincide at this size.  The stage's exactness is pinned on identical inputs in
+            # tests/test_functions_gpu.py; this bound only guards against gross disagreement.
+            assert frac >= 0.85, f"rpn proposals matched {frac:.3f}"
+            n = min(len(a), len(b))
+            rows = ((a[:n] - b[:n]).abs() <= 1e-2).all(dim=1)
+            out.append(f"{len(a)}/{len(b)} boxes, {frac:.4f} in common, first row that differs: "
+                       f"{int((~rows).nonzero()[0]) if not bool(rows.all()) else -1}")
+        return "; ".join(out)
 
-    def summary(self):
-        same = sum(int(a.shape == b.shape and torch.equal(a, b)) for a, b in zip(self.hip, self.ref))
-        return f"{same}/{len(self.ref)} images with identical proposal lists"
 
-
-def _compare_step(m, om, exact, tr, state, params, sup_keys, unsup_keys, tag):
-    """exact = both sides produced the same proposal lists, hence the same sampled ROIs: every loss must then agree to 1e-4
-    (north_star).  Otherwise (an NMS / rank decision on fp32 scores that differ in the last ulp shifted the proposal list,
-    and with it the position-indexed ROI sample) the RPN losses still agree to 1e-4 -- the anchor sample is drawn over the
-    fixed 37 350 anchors -- while the ROI-head losses are only statistically equal."""
-    for k in sup_keys + unsup_keys:
-        roi = k.startswith("loss_cls") or k.startswith("loss_box_reg")
-        close(torch.tensor(m[k]), torch.tensor(om[k]), 1e-4 if (exact or not roi) else 5e-2, 1e-6, f"{tag} {k}")
-    if not exact:
-        return
+def _compare_step(m, om, tr, state, params, keys, tag):
+    """both sides saw the same proposals and the same sampler keys: every loss to 1e-4 (north_star), the gradient norm,
+    the updated parameters"""
+    for k in keys:
+        assert math.isfinite(om[k]), f"{tag} {k}: the test inputs must keep every loss finite (oracle: {om[k]})"
+        close(torch.tensor(m[k]), torch.tensor(om[k]), 1e-4, 1e-6, f"{tag} {k}")
     close(torch.tensor(m["total_loss"]), torch.tensor(om["total_loss"]), 1e-4, 1e-6, f"{tag} total_loss")
     close(torch.tensor(m["grad_norm"]), torch.tensor(om["grad_norm"]), 1e-3, 1e-6, f"{tag} grad_norm")
     sd = tr.model.state_dict()
@@ -292,7 +312,7 @@ def test_baseline_config1_supervised_step_1333x800_vs_oracle(monkeypatch, capsys
     _load(tr.model_teacher, params)
     recs, orecs = _records(torch.Generator().manual_seed(3), 2, 800, 1333, K)
     log = _ProposalLog(monkeypatch)
-    kp = opt.KeyedPerm(51, strict=False)
+    kp = opt.KeyedPerm(51)
     sampling.set_key_source(keyed_perm_source(kp))
     try:
         m = tr.run_step(([recs[0]], [recs[1]], [recs[0]], [recs[1]]))
@@ -303,10 +323,9 @@ def test_baseline_config1_supervised_step_1333x800_vs_oracle(monkeypatch, capsys
              "bufs": {}, "iter": 0}
     om = opt.run_step(ocfg, state, ([orecs[0]], [orecs[1]], [orecs[0]], [orecs[1]]), {"label": ratios, "unlabel": []},
                       perm_fn=kp)
-    exact = log.identical() and not kp.mismatch
     with capsys.disabled():
-        print(f"\n[configs[1] 1333x800] {log.summary()}; exact path: {exact}; losses HIP {m} oracle {om}")
-    _compare_step(m, om, exact, tr, state, params, ["loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"], [], "configs[1]")
+        print(f"\n[configs[1] 1333x800] proposals: {log.check_sets()}; losses HIP {m} oracle {om}")
+    _compare_step(m, om, tr, state, params, ["loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"], "configs[1]")
 
 
 def test_baseline_config2_full_mutual_learning_step_1333x800_vs_oracle(monkeypatch, capsys):
@@ -344,7 +363,7 @@ def test_baseline_config2_full_mutual_learning_step_1333x800_vs_oracle(monkeypat
     lab, olab = _records(g, 2, 800, 1333, K)            # label_q[0], label_k[0]
     unl, ounl = _records(g, 2, 800, 1333, K)            # unlabel_q[0], unlabel_k[0] (their ground truth is dropped)
     log = _ProposalLog(monkeypatch)
-    kp = opt.KeyedPerm(61, strict=False)
+    kp = opt.KeyedPerm(61)
     sampling.set_key_source(keyed_perm_source(kp))
     try:
         m = tr.run_step(([lab[0]], [lab[1]], [unl[0]], [unl[1]]))
@@ -364,24 +383,20 @@ def test_baseline_config2_full_mutual_learning_step_1333x800_vs_oracle(monkeypat
     tsd = tr.model_teacher.state_dict()
     for k in PROBES:
         assert torch.equal(tsd[k].cpu(), params[k]) and torch.equal(state["teacher"][k], params[k]), "EMA copy " + k
-    # teacher pseudo labels, HIP vs oracle
-    same_teacher_props = len(log.hip) >= 1 and torch.equal(log.hip[0], log.ref[0])
+    # teacher pseudo labels, HIP vs oracle: same proposals in, so the detections must be the same boxes (order-insensitive:
+    # two detections whose rescored scores differ in the last ulp may swap ranks)
     for mine, ref in zip(tr.mine, state["last_pseudo"]):
-        assert 0 < len(ref) <= 100
-        if same_teacher_props:
-            assert len(mine) == len(ref)
-            close(mine.pseudo_boxes.tensor.cpu(), ref.pseudo_boxes.tensor, 1e-5, 1e-3, "pseudo boxes")
-            close(mine.scores_logists.cpu(), ref.scores_logists, 1e-3, 5e-4, "pseudo logits")
-            close(mine.boxes_sigma.cpu(), ref.boxes_sigma, 1e-3, 5e-4, "pseudo sigma")
-        else:
-            zero_a, zero_b = np.zeros(len(mine), np.int64), np.zeros(len(ref), np.int64)
-            frac, idx = match_detections(mine.pseudo_boxes.tensor.cpu(), zero_a, ref.pseudo_boxes.tensor, zero_b, box_tol=5e-2)
-            assert abs(len(mine) - len(ref)) <= max(2, len(ref) // 20) and frac >= 0.95, f"pseudo boxes matched {frac:.3f}"
+        assert 0 < len(ref) <= 100 and len(mine) == len(ref)
+        zero = np.zeros(len(ref), np.int64)
+        frac, idx = match_detections(mine.pseudo_boxes.tensor.cpu(), zero, ref.pseudo_boxes.tensor, zero, box_tol=5e-3)
+        assert frac >= 0.97, f"pseudo boxes matched {frac:.3f}"
+        ok = idx >= 0
+        close(mine.scores_logists.cpu()[idx[ok]], ref.scores_logists[ok], 1e-3, 5e-4, "pseudo logits")
+        close(mine.boxes_sigma.cpu()[idx[ok]], ref.boxes_sigma[ok], 1e-3, 5e-4, "pseudo sigma")
     sup = [k + "_sup" for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg")]
     unsup = [k + "_unsup" for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg")]
     assert set(sup + unsup) <= set(m) and set(sup + unsup) <= set(om)
-    exact = log.identical() and not kp.mismatch
     with capsys.disabled():
-        print(f"\n[configs[2] 1333x800] {log.summary()}; exact path: {exact}; pseudo labels {[len(p) for p in tr.mine]}; "
+        print(f"\n[configs[2] 1333x800] proposals: {log.check_sets()}; pseudo labels {[len(p) for p in tr.mine]}; "
               f"losses HIP {m} oracle {om}")
-    _compare_step(m, om, exact, tr, state, params, sup, unsup, "configs[2]")
+    _compare_step(m, om, tr, state, params, sup + unsup, "configs[2]")
