@@ -287,6 +287,23 @@ int ptmi_preprocess_batched(const int64_t* desc, float* out, int n, int hmax, in
 int ptmi_shrink_paste_batched(const int64_t* desc, int n, int64_t max_elems, int m0, int m1, int m2,
                               ptmi_stream_t s);
 
+/* ------------------------------------------------------------------ strong augmentation on the device
+ * replaces the per-image PIL / torchvision work of the two-crop mapper: pt/data/detection_utils.py:38-60
+ * (ColorJitter(0.4,0.4,0.4,0.1), RandomGrayscale, GaussianBlur, Solarize), pt/data/transforms/augmentation_impl.py:21-53,
+ * applied at pt/data/dataset_mapper.py:151-159.  Byte-exact with Pillow (oracle/csrc/ref_aug.c).  Planar uint8 (3,H,W)
+ * images, batched through a DEVICE table of 8 int64 words per image: [src, dst, h, w, p4, p5, p6, p7].
+ *   gray_sum : sums_out[i] = sum of convert("L") grey levels of image i (ImageStat, for ImageEnhance.Contrast)
+ *   color    : p4 = op (0 copy, 1 brightness, 2 contrast, 3 saturation, 4 hue, 5 grayscale, 6 solarize); p5 = the float
+ *              enhancement factor (its bit pattern); p6 = hue shift in 1/256 turns / solarize threshold; contrast reads
+ *              gray_sums[i].  src == dst is allowed.
+ *   box_blur : one pass of Pillow's extended box blur (GaussianBlur = 3 horizontal + 3 vertical passes):
+ *              p4 = 0 along x / 1 along y, p5 = integer radius, p6 = ww, p7 = fw (24-bit fixed-point weights).  src != dst.
+ *   hflip    : p4 = 1 flips the image left-right (D2 RandomFlip), 0 copies.  src != dst. */
+int ptmi_aug_gray_sum_batched(const int64_t* desc, int n, int64_t max_hw, uint64_t* sums_out, ptmi_stream_t s);
+int ptmi_aug_color_batched(const int64_t* desc, int n, int64_t max_hw, const uint64_t* gray_sums, ptmi_stream_t s);
+int ptmi_aug_box_blur_batched(const int64_t* desc, int n, int64_t max_elems, ptmi_stream_t s);
+int ptmi_aug_hflip_batched(const int64_t* desc, int n, int64_t max_elems, ptmi_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,10 @@ SIGNATURES = {
     "ptmi_shrink_paste": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_preprocess_batched": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp]),
     "ptmi_shrink_paste_batched": (_i, [_vp, _i, _i64, _i, _i, _i, _vp]),
+    "ptmi_aug_gray_sum_batched": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "ptmi_aug_color_batched": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "ptmi_aug_box_blur_batched": (_i, [_vp, _i, _i64, _vp]),
+    "ptmi_aug_hflip_batched": (_i, [_vp, _i, _i64, _vp]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libptmi355.so")
 SOURCES = ["abi.cpp", "conv.hip", "gemm.hip", "misc.hip", "boxes.hip", "nms.hip", "sort.hip", "roi_align.hip",
-           "losses.hip"]
+           "losses.hip", "augment.hip"]
 # -ffp-contract=off: index-producing kernels (IoU, NMS, matcher) must evaluate fp32 expressions exactly as the
 # CPU reference does.  -munsafe-fp-atomics: hardware fp32 atomic add for the ROIAlign backward scatter.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",

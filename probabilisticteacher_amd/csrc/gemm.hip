@@ -190,25 +190,41 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_buf_kernel(
             acc11 = mfma32(a1[j], b1[j], acc11);
         }
     }
-    // C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m)
+    // Epilogue.  C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m).  Every access is a raw-buffer
+    // instruction on a descriptor over this tile's rows [m0, min(m0 + 128, M)): the per-lane byte offset (column, + 4 rows
+    // for the upper lane half) is computed once, the row advance is a scalar offset, rows >= M fall outside the descriptor
+    // and columns >= N carry offset 0xFFFFFFFF -- both are dropped by the range check.  (The straightforward version, 64-bit
+    // address arithmetic and two bounds tests per element, cost as much as a third of a K = 1024 tile: fc1's dX.)
+    const int rows_here = (M - m0) < BMN ? (M - m0) : BMN;
+    const __amdgpu_buffer_rsrc_t rc = ptmi_rsrc(C + (size_t)m0 * ldc, (unsigned)rows_here * (unsigned)ldc * 4u);
+    const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias_mode ? bias : C, bias_mode == 1 ? (unsigned)M * 4u
+                                                                          : (bias_mode == 2 ? (unsigned)N * 4u : 0u));
+    const int half4 = 4 * (lane >> 5);
+    unsigned pv[2];
+    float bn_[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = n0 + wn * 64 + q * 32 + (lane & 31);
+        pv[q] = n < N ? (unsigned)(half4 * ldc + n) * 4u : 0xFFFFFFFFu;
+        bn_[q] = (bias_mode == 2) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, n < N ? n * 4 : -1, 0, 0)) : 0.f;
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int n = n0 + wn * 64 + q * 32 + (lane & 31);
-            if (n >= N) continue;
-            const float bn_ = (bias_mode == 2) ? bias[n] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 64 + s * 32 + (r & 3) + 8 * (r >> 2);          // wave-uniform row inside the tile
+            const int soff = row * ldc * 4;
+            float bm = 0.f;
+            if (bias_mode == 1)
+                bm = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rbias, half4 * 4, (m0 + row) * 4, 0));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m >= M) continue;
+            for (int q = 0; q < 2; ++q) {
                 float v = (s == 0) ? (q == 0 ? acc00[r] : acc01[r]) : (q == 0 ? acc10[r] : acc11[r]);
-                if (bias_mode == 1) v += bias[m];
-                else if (bias_mode == 2) v += bn_;
-                float* dst = C + (size_t)m * ldc + n;
-                if (accumulate) v += *dst;
+                if (bias_mode == 1) v += bm;
+                else if (bias_mode == 2) v += bn_[q];
+                if (accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, (int)pv[q], soff, 0));
                 if (relu) v = fmaxf(v, 0.f);
-                *dst = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, (int)pv[q], soff, 0);
             }
         }
     }
@@ -273,8 +289,9 @@ int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, i
     hipStream_t st = (hipStream_t)s;
     // A k-fast  <=> stored (M,K) row-major (ta == 0);  B k-fast <=> stored (N,K) (tb == 1)
     const bool ak = (ta == 0), bk = (tb != 0);
-    PTMI_CHECK_ARG((int64_t)128 * lda * 4 < (1ll << 31) && (int64_t)128 * ldb * 4 < (1ll << 31),
-                   "gemm_f32: leading dimension too large for 32-bit buffer offsets (lda=%d ldb=%d)", lda, ldb);
+    PTMI_CHECK_ARG((int64_t)128 * lda * 4 < (1ll << 31) && (int64_t)128 * ldb * 4 < (1ll << 31) &&
+                       (int64_t)128 * ldc * 4 < (1ll << 31),
+                   "gemm_f32: leading dimension too large for 32-bit buffer offsets (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
 #define L(AK_, BK_)                                                                                               \
     hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_, 32>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, ldc, \
                        bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN)

@@ -561,11 +561,60 @@ def gen_solver_checkpoint():
     save("solver_checkpoint", **out)
 
 
+def gen_augment():
+    """Strong-augmentation fixtures.  GaussianBlur and Solarize are the REFERENCE's own classes
+    (pt/data/transforms/augmentation_impl.py) run on a PIL image with `random.uniform` pinned to a fixed sigma; the
+    ColorJitter / RandomGrayscale steps are the PIL calls torchvision 0.8.2's functional_pil makes (torchvision itself is
+    not installable here), executed by the real Pillow of this image (oracle/augment.py pil_*)."""
+    import importlib.util
+    from oracle import augment as A
+    spec = importlib.util.spec_from_file_location("ref_augmentation_impl", os.path.join(REF, "pt/data/transforms/augmentation_impl.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    img = synth_image(77, 37, 53)
+    # smooth structure on top of the noise, so that blur / contrast see realistic gradients
+    yy, xx = np.mgrid[0:37, 0:53]
+    base = (96 + 80 * np.sin(xx / 7.0) * np.cos(yy / 5.0)).astype(np.int32)
+    img = torch.from_numpy(np.clip(base[None] + (img.numpy().astype(np.int32) - 128) // 3, 0, 255).astype(np.uint8))
+    out = {"image": img}
+    for tag, sigma in (("a", 0.4), ("b", 1.7), ("c", 2.0)):
+        blur = ref.GaussianBlur([0.1, 2.0])
+        orig = ref.random.uniform
+        ref.random.uniform = lambda a, b, s=sigma: s
+        try:
+            out[f"blur_{tag}"] = A._from_pil(blur(A._to_pil(img)))
+        finally:
+            ref.random.uniform = orig
+        out[f"blur_{tag}_sigma"] = np.asarray([sigma])
+    sol = ref.Solarize(threshold=0.5)
+    out["solarize"] = A._from_pil(sol(A._to_pil(img)))
+    out["solarize_threshold"] = np.asarray([sol.threshold])
+    for name, fn, vals in (("brightness", A.pil_brightness, (0.7, 1.3)), ("contrast", A.pil_contrast, (0.65, 1.35)),
+                           ("saturation", A.pil_saturation, (0.6, 1.4)), ("hue", A.pil_hue, (-0.07, 0.09))):
+        for j, v in enumerate(vals):
+            out[f"{name}_{j}"] = fn(img, v)
+            out[f"{name}_{j}_factor"] = np.asarray([v])
+    out["gray"] = A.pil_gray(img)
+    # one whole chain: jitter in the order saturation, hue, brightness, contrast -> grayscale off -> blur -> solarize
+    x = A.pil_saturation(img, 1.25)
+    x = A.pil_hue(x, 0.04)
+    x = A.pil_brightness(x, 0.8)
+    x = A.pil_contrast(x, 1.2)
+    ref.random.uniform = lambda a, b: 1.1
+    try:
+        x = A._from_pil(ref.GaussianBlur([0.1, 2.0])(A._to_pil(x)))
+    finally:
+        ref.random.uniform = orig
+    out["chain"] = A._from_pil(sol(A._to_pil(x)))
+    out["chain_params"] = np.asarray([1.25, 0.04, 0.8, 1.2, 1.1, sol.threshold])
+    save("augment", **out)
+
+
 def main():
     install_stubs()
     torch.Tensor.cuda = lambda self, *a, **k: self   # anchor_generator.py:69 hard-codes .cuda()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["codec", "pieces", "model", "step", "solver"]
+    which = sys.argv[1:] or ["codec", "pieces", "model", "step", "solver", "augment"]
     if "codec" in which:
         gen_box_codec()
     if "pieces" in which:
@@ -577,6 +626,8 @@ def main():
         gen_run_step()
     if "solver" in which:
         gen_solver_checkpoint()
+    if "augment" in which:
+        gen_augment()
 
 
 if __name__ == "__main__":
