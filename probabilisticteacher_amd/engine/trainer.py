@@ -223,6 +223,26 @@ class PTrainer:
         m["data_time"] = data_time
         self.last_metrics = m
 
+    # ------------------------------------------------------------------ evaluation (trainer.py:127-137, 529-542)
+    @classmethod
+    def build_evaluator(cls, cfg, class_names, is_2007: bool = False):
+        """trainer.py:127-137: TEST.EVALUATOR selects the evaluator; the VOC protocol ("VOCeval", the README's mAP50
+        tables) is implemented (probabilisticteacher_amd/evaluation.py); COCOeval needs pycocotools and is not."""
+        from ..evaluation import PascalVOCDetectionEvaluator
+        if cfg.TEST.EVALUATOR == "VOCeval":
+            return PascalVOCDetectionEvaluator(class_names, is_2007=is_2007)
+        if cfg.TEST.EVALUATOR == "COCOeval":
+            raise NotImplementedError("TEST.EVALUATOR=COCOeval needs pycocotools; use VOCeval")
+        raise ValueError("Unknown test evaluator.")
+
+    @classmethod
+    def test(cls, cfg, model, data_loader, class_names, is_2007: bool = False):
+        """DefaultTrainer.test for one dataset: eval-mode inference over `data_loader` (batches of records with ground
+        truth) + the evaluator; returns {"bbox": {"AP", "AP50", "AP75"}, ...}.  The reference's eval hooks call this for
+        the student (results suffixed `_student`) and the teacher (trainer.py:529-542)."""
+        from ..evaluation import inference_on_dataset
+        return inference_on_dataset(model, data_loader, cls.build_evaluator(cfg, class_names, is_2007))
+
     # ------------------------------------------------------------------ trainer shell (trainer.py:466-547)
     def resume_or_load(self, resume: bool = False):
         """trainer.py:466-496: weights (resume=False) or weights + optimiser + iteration (resume=True) from

@@ -286,3 +286,34 @@ def test_vgg_pretrained_key_map_matches_the_reference(tmp_path):
     for mk, sk in zip(z["vgg_model_keys"], z["vgg_source_keys"]):
         assert float(got[str(mk)].flatten()[0]) == val[str(sk)], f"{mk} <- {sk}"
     assert [n for n, p in bb.named_parameters() if not p.requires_grad] == list(z["vgg_frozen"])
+
+
+def test_voc_evaluator_known_answers():
+    """VOC protocol (D2 PascalVOCDetectionEvaluator as wired at reference trainer.py:127-137): hand-computed cases --
+    greedy matching in score order, duplicate detections are false positives, 'difficult' objects are ignored, the +1
+    inclusive IoU, 1-based text round trip, area-rule AP vs the 11-point rule, AP50 / AP75 / AP averaging."""
+    import numpy as np
+    from probabilisticteacher_amd.evaluation import PascalVOCDetectionEvaluator, voc_ap, voc_eval
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    assert abs(voc_ap(np.array([0.5, 1.0]), np.array([1.0, 2 / 3])) - (0.5 * 1.0 + 0.5 * 2 / 3)) < 1e-12
+    assert abs(voc_ap(np.array([0.5, 1.0]), np.array([1.0, 2 / 3]), True) - (6 * 1.0 + 5 * 2 / 3) / 11) < 1e-12
+    gts = {0: {"bbox": [[11, 11, 50, 50], [61, 61, 100, 100]], "difficult": [False, True]}, 1: {"bbox": [[1, 1, 20, 20]], "difficult": [False]}}
+    dets = [(0, 0.9, 11, 11, 50, 50), (0, 0.8, 12, 12, 50, 50), (0, 0.7, 61, 61, 100, 100), (1, 0.6, 100, 100, 120, 120), (1, 0.5, 1, 1, 20, 21)]
+    rec, prec, ap = voc_eval(dets, gts, 0.5)
+    # tp fp(dup) ignored(difficult) fp tp ; npos = 2
+    assert rec.tolist() == [0.5, 0.5, 0.5, 0.5, 1.0] and np.allclose(prec, [1, 0.5, 0.5, 1 / 3, 0.5])
+    assert abs(ap - (0.5 * 1.0 + 0.5 * 0.5)) < 1e-12
+    # inclusive IoU: boxes [1,1,10,10] vs [1,1,10,20] -> 100 / 200 = 0.5 exactly: NOT a match at threshold 0.5 (strict >)
+    assert voc_eval([(0, 1.0, 1, 1, 10, 20)], {0: {"bbox": [[1, 1, 10, 10]], "difficult": [False]}}, 0.5)[2] == 0.0
+    ev = PascalVOCDetectionEvaluator(["car", "person"])
+    gt = FreeInstances((100, 100))
+    gt.gt_boxes, gt.gt_classes = Boxes(torch.tensor([[10.0, 10.0, 50.0, 50.0], [60.0, 20.0, 90.0, 80.0]])), torch.tensor([0, 1])
+    det = FreeInstances((100, 100))
+    det.pred_boxes = Boxes(torch.tensor([[10.0, 10.0, 50.0, 50.0], [60.0, 20.0, 90.0, 70.0], [0.0, 0.0, 5.0, 5.0]]))
+    det.scores, det.pred_classes = torch.tensor([0.9, 0.8, 0.3]), torch.tensor([0, 1, 1])
+    ev.process([{"image_id": 7, "instances": gt}], [{"instances": det}])
+    res = ev.evaluate()
+    # car: perfect at every threshold (AP 100).  person: IoU = (31*51)/(31*61) = 0.836 -> hit for thresholds <= 0.80
+    assert res["per_class_AP50"] == {"car": 100.0, "person": 100.0}
+    assert abs(res["bbox"]["AP50"] - 100.0) < 1e-9 and abs(res["bbox"]["AP75"] - 100.0) < 1e-9
+    assert abs(res["bbox"]["AP"] - (100.0 * 10 + 100.0 * 7) / 20) < 1e-9

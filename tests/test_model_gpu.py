@@ -488,3 +488,44 @@ def test_baseline_config0_800x600_supervised_step_vs_oracle():
         ref = state["student"][k].detach()
         assert not torch.equal(ref, params[k]), k + " must have been updated"
         close(sd[k].cpu(), ref, 1e-4, 1e-5 * float(ref.abs().max()) + 1e-7, "configs[0] updated " + k)
+
+
+def test_voc_evaluation_of_the_eval_path_matches_the_oracle_detections():
+    """SURVEY.md 8f-2 end to end: `PTrainer.test` = eval-mode inference (rcnn.py:33-34) + the VOC evaluator
+    (trainer.py:127-137) on a few labelled synthetic records, against the same evaluator fed with the CPU oracle's
+    detections: AP / AP50 / AP75 agree (score ranks that differ in the last ulp can move a detection across a precision
+    step: 2 points of tolerance)."""
+    from probabilisticteacher_amd import modeling
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.evaluation import PascalVOCDetectionEvaluator
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    K = 8
+    cfg = setup_cfg("configs/pt/final_c2f.yaml", ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "", "TEST.EVALUATOR", "VOCeval"])
+    ocfg = opt.Cfg(num_classes=K)
+    params = opt.golden_params(ocfg, 9)
+    model = modeling.build_model(cfg).train()
+    _load_params(model, params)
+    g = torch.Generator().manual_seed(3)
+    batches = []
+    for bi in range(2):
+        recs = []
+        for i in range(2):
+            h, w = 96 + 16 * i, 128
+            img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+            xy = torch.rand(3, 2, generator=g) * torch.tensor([60.0, 40.0])
+            gt = FreeInstances((h, w))
+            gt.gt_boxes, gt.gt_classes = Boxes(torch.cat([xy, xy + 20 + torch.rand(3, 2, generator=g) * 30], 1)), torch.randint(0, K, (3,), generator=g)
+            recs.append({"image": img, "height": h, "width": w, "image_id": 10 * bi + i, "instances": gt})
+        batches.append(recs)
+    names = [f"c{i}" for i in range(K)]
+    res = PTrainer.test(cfg, model, batches, names)
+    assert model.training, "the previous mode is restored"
+    ev = PascalVOCDetectionEvaluator(names)
+    for recs in batches:
+        ev.process(recs, opt.model_inference(ocfg, params, [{k: v for k, v in r.items() if k != "instances"} for r in recs]))
+    ref = ev.evaluate()
+    for k in ("AP", "AP50", "AP75"):
+        assert np.isfinite(res["bbox"][k]) and abs(res["bbox"][k] - ref["bbox"][k]) <= 2.0, (k, res["bbox"], ref["bbox"])
+    with pytest.raises(ValueError):
+        PTrainer.build_evaluator(setup_cfg("configs/pt/final_c2f.yaml", ["TEST.EVALUATOR", "nope"]), names)

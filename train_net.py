@@ -61,7 +61,17 @@ def main():
               f"missing {len(inc.missing_keys)}, unexpected {len(inc.unexpected_keys)}, wrong shape {len(inc.incorrect_shapes)}",
               flush=True)
     if args.eval_only:
-        raise SystemExit("--eval-only needs a dataset + evaluator (pt/engine/trainer.py:127-137); not part of this build yet")
+        # reference train_net.py:60-75: evaluate the STUDENT of the loaded ensemble; here on synthetic labelled batches
+        n_batches = args.max_iter or 4
+        loader = (next(trainer._data_iter)[1] for _ in range(n_batches))         # the weak labelled views
+        names = [f"class{i}" for i in range(cfg.MODEL.ROI_HEADS.NUM_CLASSES)]
+        ecfg = cfg.clone()
+        ecfg.defrost()
+        ecfg.TEST.EVALUATOR = "VOCeval"
+        res = PTrainer.test(ecfg, trainer.model, loader, names)
+        if rank == 0:
+            print({k: v for k, v in res.items() if k == "bbox"}, flush=True)
+        return
     trainer.train(max_iter=args.max_iter)                      # periodic checkpoints, metrics.json, model_final.pth
     if world > 1:
         dist.destroy_process_group()
