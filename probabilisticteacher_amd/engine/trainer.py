@@ -26,6 +26,8 @@ class PTrainer:
         initialised process group; the sum over one rank is the identity (single-GPU validation of the DDP path)."""
         self.cfg = cfg
         check_optimizer_options(cfg)
+        # reference trainer.py:98 (cfg.SOLVER.AMP.ENABLED): mixed precision for the conv / FC GEMMs (see ops.py)
+        ops.set_operand_rounding("bf16" if cfg.SOLVER.AMP.ENABLED else None)
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.model = build_model(cfg)                  # student
         self.model_teacher = build_model(cfg)          # teacher (per-rank replica, never all-reduced)

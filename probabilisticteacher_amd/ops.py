@@ -99,6 +99,30 @@ class _prof:
         return False
 
 
+# ============================================================================ operand rounding (SOLVER.AMP.ENABLED)
+# BASELINE.json configs[4] ("mixed bf16 convs + fp32 loss"; the reference's AMP flag, pt/engine/trainer.py:98): the
+# conv / FC GEMM operands -- activations, weights and, in backward, the incoming gradients -- are rounded to bf16
+# (round-to-nearest-even), products are accumulated in fp32 and results stay fp32; losses, box codec, NMS, optimiser
+# are untouched.  This is the NUMERICS of a bf16-input / fp32-accumulate MFMA path (a bf16 x bf16 product is exact in
+# fp32), executed on the fp32 kernels: it defines and tests the behaviour (loss-curve parity against the fp32 run,
+# tools/loss_curve_parity.py) ahead of native v_mfma_f32_32x32x16_bf16 kernels, and brings NO speed-up.  Never enabled
+# by bench.py (the headline metric is fp32).
+_OPERAND_ROUNDING = None
+
+
+def set_operand_rounding(mode: Optional[str]) -> None:
+    global _OPERAND_ROUNDING
+    if mode not in (None, "bf16"):
+        raise ValueError(f"unknown operand rounding {mode!r}")
+    _OPERAND_ROUNDING = mode
+
+
+def _rnd(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if _OPERAND_ROUNDING is None or t is None:
+        return t
+    return t.to(torch.bfloat16).to(F32)
+
+
 # ============================================================================ conv 3x3
 def conv3x3_pack(w: torch.Tensor, mode: int) -> torch.Tensor:
     _chk(w, name="conv weight")
@@ -123,10 +147,10 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
 
 def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     """conv3x3 + bias + ReLU + MaxPool(2,2) in ONE kernel (epilogue 4); inference-only (no autograd state)."""
-    x = _chk(x.contiguous(), name="conv input")
+    x = _chk(_rnd(x).contiguous(), name="conv input")
     n, cin, h, w = x.shape
     cout = weight.shape[0]
-    wp = conv3x3_pack(_chk(weight.contiguous()), 0)
+    wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0)
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
     with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, 4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout)):
         _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None, _ptr(y), n, cin, cout, h,
@@ -148,8 +172,8 @@ class _Conv3x3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu: bool):
-        x = _chk(x.contiguous(), name="conv input")
-        weight = _chk(weight.contiguous(), name="conv weight")
+        x = _chk(_rnd(x).contiguous(), name="conv input")
+        weight = _chk(_rnd(weight).contiguous(), name="conv weight")
         bias = _chk(bias.contiguous(), name="conv bias")
         wp = conv3x3_pack(weight, 0)
         y = conv3x3_raw(x, wp, bias, None, weight.shape[0], 1 if relu else 0)
@@ -161,7 +185,7 @@ class _Conv3x3(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dy = _chk(dy.contiguous(), name="conv grad")
-        dz = relu_bwd(dy, y) if ctx.relu else dy
+        dz = _rnd(relu_bwd(dy, y) if ctx.relu else dy)
         n, cin, h, w = x.shape
         cout = weight.shape[0]
         dx = dw = db = None
@@ -272,6 +296,10 @@ class _VGGBlock(torch.autograd.Function):
 
 def vgg_block(x, pool: bool, params):
     """params = [w1, b1, w2, b2, ...]."""
+    if _OPERAND_ROUNDING is not None:          # layer by layer: every conv rounds its own operands
+        for j in range(len(params) // 2):
+            x = conv3x3(x, params[2 * j], params[2 * j + 1], True)
+        return maxpool2x2(x) if pool else x
     return _VGGBlock.apply(x, pool, *params)
 
 
@@ -305,8 +333,8 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu: bool):
-        x = _chk(x.contiguous(), name="linear input")
-        weight = _chk(weight.contiguous())
+        x = _chk(_rnd(x).contiguous(), name="linear input")
+        weight = _chk(_rnd(weight).contiguous())
         bias = _chk(bias.contiguous())
         r, k = x.shape
         nout = weight.shape[0]
@@ -319,7 +347,7 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dy = _chk(dy.contiguous())
-        dz = relu_bwd(dy, y) if ctx.relu else dy
+        dz = _rnd(relu_bwd(dy, y) if ctx.relu else dy)
         r, k = x.shape
         nout = weight.shape[0]
         dx = dw = db = None
@@ -344,10 +372,10 @@ class _Conv1x1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        x = _chk(x.contiguous())
+        x = _chk(_rnd(x).contiguous())
         n, ci, h, w = x.shape
         co = weight.shape[0]
-        w2 = _chk(weight.reshape(co, ci).contiguous())
+        w2 = _chk(_rnd(weight).reshape(co, ci).contiguous())
         hw = h * w
         y = torch.empty((n, co, h, w), dtype=F32, device=x.device)
         gemm(w2, x, co, hw, ci, ci, hw, 0, 0, bias=_chk(bias.contiguous()), bias_mode=1, out=y, batch=n, stride_a=0,
@@ -359,7 +387,7 @@ class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w2 = ctx.saved_tensors
-        dy = _chk(dy.contiguous())
+        dy = _chk(_rnd(dy).contiguous())
         n, ci, h, w = x.shape
         co, hw = w2.shape[0], h * w
         dx = dw = db = None

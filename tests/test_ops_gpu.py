@@ -692,3 +692,45 @@ def test_sample_by_keys_equals_reference_subsample_labels(ops):
         rf, rb = d2.subsample_labels(cls, 512, 0.25, K, kp)
         assert cnt[i] == [len(rf), len(rb)], (i, cnt[i], len(rf), len(rb))
         assert torch.equal(fg[i, :cnt[i][0]].cpu(), rf) and torch.equal(bg[i, :cnt[i][1]].cpu(), rb), i
+
+
+def test_bf16_operand_rounding_mode(ops):
+    """SOLVER.AMP.ENABLED (BASELINE configs[4] numerics): conv / FC operands and incoming gradients rounded to bf16, fp32
+    accumulation, fp32 results == the fp32 op applied to bf16-rounded tensors."""
+    gen = g(99)
+    rb = lambda t: t.to(torch.bfloat16).float()
+    x = torch.randn(2, 24, 17, 29, generator=gen)
+    wt = torch.randn(40, 24, 3, 3, generator=gen) * 0.1
+    b = torch.randn(40, generator=gen) * 0.1
+    gy = torch.randn(2, 40, 17, 29, generator=gen)
+    xr, wr, br = rb(x).requires_grad_(), rb(wt).requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yr.backward(rb(gy))
+    lx = torch.randn(70, 300, generator=gen)
+    lw = torch.randn(50, 300, generator=gen) * 0.05
+    lb = torch.randn(50, generator=gen)
+    lg = torch.randn(70, 50, generator=gen)
+    lxr, lwr = rb(lx).requires_grad_(), rb(lw).requires_grad_()
+    lyr = F.linear(lxr, lwr, lb)
+    lyr.backward(rb(lg))
+    ops.set_operand_rounding("bf16")
+    try:
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, wt, b))
+        yd = ops.conv3x3(xd, wd, bd, False)
+        yd.backward(gy.to(DEV))
+        lxd, lwd, lbd = (t.to(DEV).requires_grad_() for t in (lx, lw, lb))
+        lyd = ops.linear(lxd, lwd, lbd, False)
+        lyd.backward(lg.to(DEV))
+    finally:
+        ops.set_operand_rounding(None)
+    close(yd, yr, 1e-4, 1e-4, "bf16-mode conv fwd")
+    close(xd.grad, xr.grad, 1e-4, 2e-4, "bf16-mode conv dgrad")
+    close(wd.grad, wr.grad, 1e-4, 1e-3, "bf16-mode conv wgrad")
+    close(lyd, lyr, 1e-4, 1e-4, "bf16-mode linear fwd")
+    close(lxd.grad, lxr.grad, 1e-4, 1e-4, "bf16-mode linear dx")
+    close(lwd.grad, lwr.grad, 1e-4, 1e-3, "bf16-mode linear dw")
+    # and it really is a different result than fp32 (the rounding is applied)
+    y32 = ops.conv3x3(x.to(DEV), wt.to(DEV), b.to(DEV), False)
+    assert float((y32 - yd.detach()).abs().max()) > 1e-3
+    with pytest.raises(ValueError):
+        ops.set_operand_rounding("fp8")
