@@ -81,3 +81,58 @@ def test_metrics_all_gather_on_rccl(rccl_world1):
     out = torch.empty(26, device=DEV)
     dist.all_gather_into_tensor(out, v)
     assert torch.equal(out, v)
+
+
+def test_checkpoint_resume_is_bitwise_on_gpu(tmp_path):
+    """f3/f4 on the device: train 4 iterations straight through vs train 2, write a checkpoint (reference file format:
+    EnsembleTSModel keys, per-parameter SGD state, iteration = last finished), build a FRESH trainer, resume_or_load(resume)
+    and train 2 more -- parameters, teacher, momentum and metrics must be bitwise identical (burn-in -> EMA copy -> mutual
+    learning boundary included: BURN_UP_STEP = 2 sits exactly at the resume point)."""
+    from probabilisticteacher_amd import checkpoint
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.modeling import sampling
+    from bench import synth_records
+    out = str(tmp_path)
+    base = ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", 2, "SOLVER.IMG_PER_BATCH_LABEL", 2,
+            "SOLVER.IMG_PER_BATCH_UNLABEL", 2, "SOLVER.CHECKPOINT_PERIOD", 2, "OUTPUT_DIR", out]
+    cfg = setup_cfg("configs/pt/final_c2f.yaml", base)
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    gen = torch.Generator().manual_seed(9)
+    batches = [tuple(synth_records(gen, 2, 256, 384, K, DEV) for _ in range(4)) for _ in range(4)]
+
+    def run(trainer, its, seed_base):
+        ms = []
+        for it in its:
+            rr = iter([0.6 + 0.05 * j for j in range(8)])
+            trainer._ratio_fn = lambda: next(rr)
+            kg = torch.Generator().manual_seed(seed_base + it)
+            sampling.set_key_source(lambda labels, sizes, bg: torch.rand(labels.shape, generator=kg))
+            try:
+                ms.append(trainer.run_step(batches[it]))
+            finally:
+                sampling.set_key_source(None)
+        return ms
+
+    torch.manual_seed(0)
+    a = PTrainer(cfg)
+    ma = run(a, range(4), 100)
+    torch.manual_seed(0)
+    b = PTrainer(cfg)
+    mb = run(b, range(2), 100)
+    path = checkpoint.PeriodicCheckpointer(b, cfg.SOLVER.CHECKPOINT_PERIOD, 4).step(1)
+    assert path.endswith("model_0000001.pth")
+    torch.manual_seed(123)                                    # a differently initialised trainer: everything must come from the file
+    c = PTrainer(setup_cfg("configs/pt/final_c2f.yaml", base))
+    assert not torch.equal(c.student.flat, b.student.flat)
+    inc = c.resume_or_load(resume=True)                       # MODEL.WEIGHTS empty -> OUTPUT_DIR/last_checkpoint
+    assert inc is not None and not inc.missing_keys and not inc.incorrect_shapes and c.iter == c.start_iter == 2
+    assert torch.equal(c.student.flat, b.student.flat) and torch.equal(c.teacher.flat, b.teacher.flat)
+    assert torch.equal(c.momentum_buf, b.momentum_buf) and not c._first_step
+    mc = run(c, range(2, 4), 100)
+    for x, y in zip(ma[2:], mc):
+        for k in x:
+            if k != "data_time":
+                assert x[k] == y[k] or (x[k] != x[k] and y[k] != y[k]), f"metric {k}: {x[k]} vs {y[k]}"
+    assert torch.equal(a.student.flat, c.student.flat) and torch.equal(a.teacher.flat, c.teacher.flat)
+    assert torch.equal(a.momentum_buf, c.momentum_buf)

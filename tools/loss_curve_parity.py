@@ -124,19 +124,41 @@ def main():
             om = opt.run_step(ocfg, state, ob, {"label": r_lab, "unlabel": r_unl}, perm_fn=kp)
             t_ora += time.perf_counter() - t0
             ora_curve.append(om)
+        if os.environ.get("PARITY_VERBOSE") and it >= a.burn - 1:
+            print(it, {k: round(v, 5) for k, v in m.items() if k != "data_time"}, flush=True)
+            if not a.no_oracle:
+                print(it, "oracle", {k: round(v, 5) for k, v in om.items()}, flush=True)
         if it % 25 == 0 or it == a.iters - 1:
             print(f"it {it:4d} hip total {m['total_loss']:.5f}" + ("" if a.no_oracle else f"  oracle total {om['total_loss']:.5f}"),
                   flush=True)
+    def finite_total(m):
+        """sum of the finite loss terms: `loss_box_reg_unsup` is NaN by construction (mean over an empty tensor,
+        fast_rcnn.py:262) whenever the teacher labels every matched ROI background -- reported, but no gradient flows"""
+        return float(sum(v for k, v in m.items() if k[:4] == "loss" and np.isfinite(v)))
+
+    def nan_keys(m):
+        return sorted(k for k, v in m.items() if k[:4] == "loss" and not np.isfinite(v))
+
     out = {"config": "final_s2c.yaml (K=1)" + (", bf16-rounded conv/FC operands" if a.bf16 else ", fp32"),
            "iters": a.iters, "burn_up_step": a.burn, "batch": [a.batch, a.batch], "image": [a.height, a.width],
-           "hip_total_loss": [float(m["total_loss"]) for m in hip_curve], "hip_seconds": t_hip}
+           "hip_finite_total_loss": [finite_total(m) for m in hip_curve], "hip_seconds": t_hip,
+           "hip_grad_norm_finite": bool(all(np.isfinite(m["grad_norm"]) for m in hip_curve)),
+           "hip_nan_terms": sorted({k for m in hip_curve for k in nan_keys(m)})}
+    if a.iters >= 2 * a.window:
+        hs = smooth(out["hip_finite_total_loss"], a.window)
+        out["hip_smoothed"] = {"window": a.window, "first": float(hs[0]), "at_burn": float(hs[min(a.burn, len(hs) - 1)]),
+                               "last": float(hs[-1])}
     if not a.no_oracle:
-        h = np.array([m["total_loss"] for m in hip_curve])
-        o = np.array([m["total_loss"] for m in ora_curve])
-        out["oracle_total_loss"] = o.tolist()
+        h = np.array(out["hip_finite_total_loss"])
+        o = np.array([finite_total(m) for m in ora_curve])
+        out["oracle_finite_total_loss"] = o.tolist()
         out["oracle_seconds"] = t_ora
+        out["oracle_grad_norm_finite"] = bool(all(np.isfinite(m["grad_norm"]) for m in ora_curve))
+        out["oracle_nan_terms"] = sorted({k for m in ora_curve for k in nan_keys(m)})
         first = min(5, a.iters)
         out["first_iters_rel_diff"] = (np.abs(h[:first] - o[:first]) / np.abs(o[:first])).tolist()
+        out["nan_term_rate"] = {"hip": float(np.mean([bool(nan_keys(m)) for m in hip_curve])),
+                                "oracle": float(np.mean([bool(nan_keys(m)) for m in ora_curve]))}
         if a.iters >= 2 * a.window:
             hs, os_ = smooth(h, a.window), smooth(o, a.window)
             rel = np.abs(hs - os_) / np.abs(os_)
@@ -144,8 +166,14 @@ def main():
             out["smoothed_rel_diff_max"] = float(rel.max())
             out["smoothed_rel_diff_mean"] = float(rel.mean())
             out["final_window_mean"] = {"hip": float(hs[-1]), "oracle": float(os_[-1])}
-        fin = np.isfinite(h).all() and np.isfinite(o).all()
-        out["all_finite"] = bool(fin)
+            per_key = {}
+            for k in sorted({k for m in hip_curve for k in m if k[:4] == "loss"}):
+                hk = np.array([m.get(k, np.nan) for m in hip_curve], np.float64)
+                ok_ = np.array([m.get(k, np.nan) for m in ora_curve], np.float64)
+                msk = np.isfinite(hk) & np.isfinite(ok_)
+                if msk.sum() >= a.window:
+                    per_key[k] = {"hip_mean": float(hk[msk].mean()), "oracle_mean": float(ok_[msk].mean())}
+            out["per_term_mean_over_common_finite_iters"] = per_key
     s = json.dumps(out)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
