@@ -78,11 +78,15 @@ int ptmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int 
  * ta: 0 -> A stored (M,K) row-major with leading dim lda; 1 -> stored (K,M).
  * tb: 0 -> B stored (K,N) row-major with leading dim ldb; 1 -> stored (N,K).
  * bias_mode: 0 none, 1 per-row (M), 2 per-column (N).  batch strides in elements.
- * fp32 on v_mfma_f32_32x32x2_f32; k-ordered accumulation (deterministic). */
+ * fp32 on v_mfma_f32_32x32x2_f32; k-ordered accumulation (deterministic).
+ * ws / ws_floats: optional workspace of ptmi_gemm_ws_floats(m, n, k, batch) floats.  With it, shapes with few 128x128
+ * tiles and a long K (the box head's weight gradients) or a tile count just above a multiple of the chip's workgroup
+ * slots run split-K: K slices into ws, summed in a fixed order (still deterministic).  NULL / 0 = never split. */
+int64_t ptmi_gemm_ws_floats(int m, int n, int k, int batch);
 int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, int m, int n,
                   int k, int lda, int ldb, int ldc, int ta, int tb, int bias_mode, int relu,
                   int accumulate, int batch, int64_t stride_a, int64_t stride_b,
-                  int64_t stride_c, ptmi_stream_t s);
+                  int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s);
 /* column sums: out[j] (+)= sum_i a[i][j]  (bias gradients), a is (rows, cols) row-major. */
 int ptmi_colsum(const float* a, float* out, int rows, int cols, int accumulate, ptmi_stream_t s);
 /* row sums over the inner dim: out[i] (+)= sum_j a[i][j] for each of `batch` slabs summed. */

@@ -137,7 +137,7 @@ template <bool AK, bool BKF, int BKT>
 __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_buf_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc, int bias_mode, int relu,
-    int accumulate, int64_t sa, int64_t sb, int64_t sc, int tilesN)
+    int accumulate, int64_t sa, int64_t sb, int64_t sc, int tilesN, int kChunk, float* __restrict__ partial)
 {
     using Cfg = TileCfg<BKT>;
     constexpr int OPF = Cfg::OP_FLOATS, HK = Cfg::HK;
@@ -151,6 +151,17 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_buf_kernel(
     B += (size_t)b * sb;
     C += (size_t)b * sc;
     const int wm = wave >> 1, wn = wave & 1;
+    // split-K (blockIdx.z = slice, kChunk = its K extent, a multiple of the stage depth): the slice's partial product goes,
+    // without bias / ReLU / accumulate, to partial[z][M][N]; gemm_splitk_reduce_kernel sums the slices in a fixed order
+    if (partial) {
+        const int kbeg = blockIdx.z * kChunk;
+        A += AK ? (size_t)kbeg : (size_t)kbeg * lda;
+        B += BKF ? (size_t)kbeg : (size_t)kbeg * ldb;
+        K = (K - kbeg) < kChunk ? (K - kbeg) : kChunk;
+        C = partial + (size_t)blockIdx.z * M * N;
+        ldc = N;
+        bias_mode = relu = accumulate = 0;
+    }
 
     OpTile<AK, BKT> ta;
     OpTile<BKF, BKT> tb;
@@ -230,6 +241,52 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_buf_kernel(
     }
 }
 
+// C = (accumulate ? C : 0) + sum_z partial[z] (z ascending: deterministic) + bias, ReLU -- the epilogue of a split-K GEMM
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C,
+                                                                 const float* __restrict__ bias, int M, int N, int ldc,
+                                                                 int S, int bias_mode, int relu, int accumulate)
+{
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+        float v = partial[i];
+        for (int z = 1; z < S; ++z) v += partial[(int64_t)z * total + i];
+        if (bias_mode == 1) v += bias[m];
+        else if (bias_mode == 2) v += bias[n];
+        float* dst = C + (int64_t)m * ldc + n;
+        if (accumulate) v += *dst;
+        if (relu) v = fmaxf(v, 0.f);
+        *dst = v;
+    }
+}
+
+// Split-K factor for an (M, N, K) GEMM.  A 128 x 128 tile is one workgroup and two workgroups share a CU (512 slots), so
+//   * few tiles and a long K -- the weight gradients of the box head: fc2 dW = 64 tiles, cls/bbox dW = 8 tiles, K = 16 384
+//     ROIs -- run as ONE round whose length is set by K alone (0.9 ms for 34 GFLOP), and
+//   * a tile count just above a multiple of 512 -- fc1 dW: 1568 tiles = 3.06 rounds -- idles the chip for most of its last
+//     round (77 % utilisation).
+// Cost model: rounds(S) x slice length + the traffic of writing / re-reading S partial outputs; S = 1 keeps the plain path.
+int pick_splitk(int m, int n, int k, int batch)
+{
+    if (batch > 1 || k < 1024) return 1;
+    const int64_t tiles = (int64_t)cdiv(m, BMN) * cdiv(n, BMN);
+    const double P = 512.0;
+    const double step_us = 3.4;                          // one 32-deep K step of a workgroup sharing its CU with another
+    const double bw = 4.0e6;                             // bytes per microsecond for the partial buffers (~4 TB/s)
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+    int best = 1;
+    double best_t = 1e30;
+    for (int S : cand) {
+        const int chunk = cdiv(cdiv(k, S), 32) * 32;
+        if (S > 1 && (chunk < 256 || (int64_t)(S - 1) * chunk >= k)) continue;
+        const double rounds = (double)((tiles * S + (int64_t)P - 1) / (int64_t)P);
+        double t = rounds * (chunk / 32.0) * step_us;
+        if (S > 1) t += 5.0 + (2.0 * S + 1.0) * (double)m * n * 4.0 / bw;
+        if (t < best_t * 0.97) { best_t = t; best = S; }     // prefer the smaller factor unless the gain is real
+    }
+    return best;
+}
+
 // out[j] (+)= sum_i a[i][j]: a workgroup owns 16 columns; 16 row-partitions are reduced through LDS in a
 // fixed order (deterministic).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, float* __restrict__ out,
@@ -277,30 +334,49 @@ __global__ __launch_bounds__(256) void rowsum_batched_kernel(const float* __rest
 
 extern "C" {
 
+int64_t ptmi_gemm_ws_floats(int m, int n, int k, int batch)
+{
+    const int S = pick_splitk(m, n, k, batch);
+    return S > 1 ? (int64_t)S * m * n : 0;
+}
+
 int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, int m, int n, int k, int lda,
                   int ldb, int ldc, int ta, int tb, int bias_mode, int relu, int accumulate, int batch,
-                  int64_t stride_a, int64_t stride_b, int64_t stride_c, ptmi_stream_t s)
+                  int64_t stride_a, int64_t stride_b, int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(a && b && c && m >= 0 && n >= 0 && k > 0 && batch > 0, "gemm_f32: bad args");
     PTMI_CHECK_ARG(bias_mode == 0 || bias, "gemm_f32: bias missing");
     if (m == 0 || n == 0) return 0;
     const int tilesM = cdiv(m, BMN), tilesN = cdiv(n, BMN);
-    dim3 grid((unsigned)(tilesM * tilesN), (unsigned)batch), block(256);
     hipStream_t st = (hipStream_t)s;
     // A k-fast  <=> stored (M,K) row-major (ta == 0);  B k-fast <=> stored (N,K) (tb == 1)
     const bool ak = (ta == 0), bk = (tb != 0);
     PTMI_CHECK_ARG((int64_t)128 * lda * 4 < (1ll << 31) && (int64_t)128 * ldb * 4 < (1ll << 31) &&
                        (int64_t)128 * ldc * 4 < (1ll << 31),
                    "gemm_f32: leading dimension too large for 32-bit buffer offsets (lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    // split-K only with a workspace of the size ptmi_gemm_ws_floats() asks for (callers that pass none get the plain path)
+    int S = pick_splitk(m, n, k, batch);
+    if (S > 1 && (!ws || ws_floats < (int64_t)S * m * n)) S = 1;
+    PTMI_CHECK_ARG(S == 1 || (int64_t)128 * n * 4 < (1ll << 31), "gemm_f32: n too large for the split-K partials");
+    const int chunk = S > 1 ? cdiv(cdiv(k, S), 32) * 32 : k;
+    float* partial = S > 1 ? ws : nullptr;
+    dim3 grid((unsigned)(tilesM * tilesN), (unsigned)batch, (unsigned)S), block(256);
 #define L(AK_, BK_)                                                                                               \
     hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_, 32>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, ldc, \
-                       bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN)
+                       bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN, chunk, partial)
     if (ak && bk) L(true, true);
     else if (ak && !bk) L(true, false);
     else if (!ak && bk) L(false, true);
     else L(false, false);
 #undef L
     PTMI_LAUNCH_CHECK("gemm_f32");
+    if (S > 1) {
+        int64_t blocks = ((int64_t)m * n + 1023) / 1024;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, partial, c, bias, m, n, ldc,
+                           S, bias_mode, relu, accumulate);
+        PTMI_LAUNCH_CHECK("gemm_splitk_reduce");
+    }
     return 0;
 }
 

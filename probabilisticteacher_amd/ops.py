@@ -313,9 +313,11 @@ def gemm(a, b, m, n, k, lda, ldb, ta, tb, bias=None, bias_mode=0, relu=False, ou
     ldc = n if ldc is None else ldc
     if m == 0 or n == 0:
         return out
+    nws = _lib.load().ptmi_gemm_ws_floats(m, n, k, batch)                   # > 0: this shape runs split-K
+    ws = _ws("gemm", nws * 4, a.device) if nws else None
     with _prof("gemm_f32", 2.0 * m * n * k * batch):
         _lib.call("ptmi_gemm_f32", _ptr(a), _ptr(b), _ptr(out), _ptr(bias), m, n, k, lda, ldb, ldc, ta, tb, bias_mode,
-                  int(relu), int(accumulate), batch, stride_a, stride_b, stride_c, _stream())
+                  int(relu), int(accumulate), batch, stride_a, stride_b, stride_c, _ptr(ws), int(nws), _stream())
     return out
 
 

@@ -157,6 +157,36 @@ def test_gemm_all_layouts(ops, ta, tb, m, n, k):
     assert torch.equal(out, out2), "gemm must be bitwise reproducible"
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(200, 300, 5000), (9, 130, 4099), (1024, 1024, 2048 + 13)])
+def test_gemm_split_k(ops, ta, tb, m, n, k):
+    """shapes for which ptmi_gemm_ws_floats() asks for a workspace run split-K (few tiles, long K: the box head's weight
+    gradients): all four layouts, ragged K slices, bias / ReLU / accumulate applied by the fixed-order reduction, bitwise
+    reproducible, and equal (to rounding) to the unsplit kernel that runs when no workspace is passed"""
+    from probabilisticteacher_amd import _lib
+    nws = _lib.load().ptmi_gemm_ws_floats(m, n, k, 1)
+    assert nws >= 2 * m * n, "this shape is meant to split"
+    gen = g(m + n + k + 2 * ta + tb)
+    a = torch.randn(*((k, m) if ta else (m, k)), generator=gen)
+    b = torch.randn(*((n, k) if tb else (k, n)), generator=gen)
+    bias = torch.randn(n, generator=gen)
+    c0 = torch.randn(m, n, generator=gen)
+    am, bm = (a.t() if ta else a), (b.t() if tb else b)
+    ref = torch.relu(am.double() @ bm.double() + bias.double() + c0.double()).float()
+    ad, bd, biasd = a.to(DEV).contiguous(), b.to(DEV).contiguous(), bias.to(DEV)
+    out = ops.gemm(ad, bd, m, n, k, a.shape[1], b.shape[1], ta, tb, bias=biasd, bias_mode=2, relu=True, out=c0.to(DEV), accumulate=True)
+    close(out, ref, 1e-4, 2e-4 * math.sqrt(k / 1000.0), f"split-K gemm ta={ta} tb={tb}")
+    out2 = ops.gemm(ad, bd, m, n, k, a.shape[1], b.shape[1], ta, tb, bias=biasd, bias_mode=2, relu=True, out=c0.to(DEV), accumulate=True)
+    assert torch.equal(out, out2), "split-K gemm must be bitwise reproducible"
+    # the same call without a workspace: plain kernel
+    call, _p, _stream = _raw()
+    plain = c0.to(DEV)
+    call("ptmi_gemm_f32", _p(ad), _p(bd), _p(plain), _p(biasd), m, n, k, a.shape[1], b.shape[1], n, ta, tb, 2, 1, 1, 1, 0, 0, 0,
+         None, 0, _stream())
+    close(plain, ref, 1e-4, 2e-4 * math.sqrt(k / 1000.0), "unsplit gemm")
+    close(out, plain, 1e-5, 2e-4 * math.sqrt(k / 1000.0), "split vs unsplit (summation order differs)")
+
+
 def test_conv1x1(ops):
     gen = g(17)
     x = torch.randn(3, 96, 13, 21, generator=gen)
