@@ -58,32 +58,46 @@ class DeviceTwoCropMapper:
         return out
 
 
+class _Stream:
+    """one of the two record streams: two aspect-ratio buckets of (strong, weak) pairs and the bucket being filled"""
+
+    def __init__(self, batch_size: int):
+        self.batch_size = batch_size
+        self.buckets = ([], [])            # index 0: landscape (w > h), 1: portrait / square
+        self.current = self.buckets[0]
+
+    def offer(self, pair) -> None:
+        if len(self.current) == self.batch_size:       # a full batch is waiting for the other stream: drop the pair
+            return
+        strong = pair[0]
+        self.current = self.buckets[0 if strong["width"] > strong["height"] else 1]
+        self.current.append(pair)
+
+    def ready(self) -> bool:
+        return len(self.current) == self.batch_size
+
+    def take(self):
+        strong, weak = [p[0] for p in self.current], [p[1] for p in self.current]
+        del self.current[:]
+        return strong, weak
+
+
 class AspectRatioGroupedSemiSupDatasetTwoCrop:
-    """pt/data/common.py:106-180: two streams of (strong, weak) record pairs -> batches
-    (label_strong, label_weak, unlabel_strong, unlabel_weak), images with w > h and w <= h kept in separate buckets."""
+    """pt/data/common.py:106-180 (same name, same iteration contract): consumes a labelled and an unlabelled stream of
+    (strong, weak) record pairs in lock step and yields (label_strong, label_weak, unlabel_strong, unlabel_weak) whenever
+    BOTH streams have a full bucket; images with w > h and w <= h never share a batch (less padding).  As in the
+    reference, a stream whose batch is already full ignores its incoming pairs until the other one catches up."""
 
     def __init__(self, dataset: Tuple[Iterable, Iterable], batch_size: Tuple[int, int]):
         self.label_dataset, self.unlabel_dataset = dataset
         self.batch_size_label, self.batch_size_unlabel = batch_size
-        self._label_buckets = [[] for _ in range(2)]
-        self._label_buckets_key = [[] for _ in range(2)]
-        self._unlabel_buckets = [[] for _ in range(2)]
-        self._unlabel_buckets_key = [[] for _ in range(2)]
 
     def __iter__(self):
-        label_bucket, unlabel_bucket = [], []
-        label_key, unlabel_key = [], []
-        for d_label, d_unlabel in zip(self.label_dataset, self.unlabel_dataset):
-            if len(label_bucket) != self.batch_size_label:
-                bid = 0 if d_label[0]["width"] > d_label[0]["height"] else 1
-                label_bucket, label_key = self._label_buckets[bid], self._label_buckets_key[bid]
-                label_bucket.append(d_label[0])
-                label_key.append(d_label[1])
-            if len(unlabel_bucket) != self.batch_size_unlabel:
-                bid = 0 if d_unlabel[0]["width"] > d_unlabel[0]["height"] else 1
-                unlabel_bucket, unlabel_key = self._unlabel_buckets[bid], self._unlabel_buckets_key[bid]
-                unlabel_bucket.append(d_unlabel[0])
-                unlabel_key.append(d_unlabel[1])
-            if len(label_bucket) == self.batch_size_label and len(unlabel_bucket) == self.batch_size_unlabel:
-                yield (label_bucket[:], label_key[:], unlabel_bucket[:], unlabel_key[:])
-                del label_bucket[:], label_key[:], unlabel_bucket[:], unlabel_key[:]
+        lab, unl = _Stream(self.batch_size_label), _Stream(self.batch_size_unlabel)
+        for pair_l, pair_u in zip(self.label_dataset, self.unlabel_dataset):
+            lab.offer(pair_l)
+            unl.offer(pair_u)
+            if lab.ready() and unl.ready():
+                ls, lw = lab.take()
+                us, uw = unl.take()
+                yield ls, lw, us, uw

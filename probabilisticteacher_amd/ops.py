@@ -41,8 +41,9 @@ _WS = {}
 
 
 def _ws(name: str, nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device scratch buffers (kernels are stream-ordered, so reuse is safe)."""
-    key = (name, device.index)
+    """Grow-only scratch buffers, one set per (device, stream): kernels of one stream are ordered, so reuse within it is
+    safe; work on another stream (a teacher forward on its own stream, say) gets its own buffers instead of racing."""
+    key = (name, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
