@@ -145,3 +145,138 @@ def test_roi_inference_edge_cases():
     deltas[17, 9] = float("nan")
     scores[420, 2] = float("nan")                          # image 1, ROI 20: probabilities are NaN
     _check_inference(K, scores, deltas, pg, po, ocfg)
+
+
+def _gt_instances(gen, counts, sizes, K, with_pseudo=False):
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    hip, ora = [], []
+    for m, (h, w) in zip(counts, sizes):
+        b = _rand_boxes(gen, m, h, w, lo=24.0, hi=0.35)
+        b[:, 0::2].clamp_(0, w)
+        b[:, 1::2].clamp_(0, h)
+        a, o = FreeInstances((h, w)), opt.FreeInstances((h, w))
+        if with_pseudo:
+            lg, sg = torch.randn(m, K + 1, generator=gen), torch.randn(m, 4, generator=gen)
+            a.pseudo_boxes, a.scores_logists, a.boxes_sigma = Boxes(b.to(DEV)), lg.to(DEV), sg.to(DEV)
+            o.pseudo_boxes, o.scores_logists, o.boxes_sigma = d2.Boxes(b.clone()), lg.clone(), sg.clone()
+        else:
+            cls = torch.randint(0, K, (m,), generator=gen)
+            a.gt_boxes, a.gt_classes = Boxes(b.to(DEV)), cls.to(DEV)
+            o.gt_boxes, o.gt_classes = d2.Boxes(b.clone()), cls.clone()
+        hip.append(a)
+        ora.append(o)
+    return hip, ora
+
+
+def _proposals(gen, counts, sizes, gts):
+    """proposal lists as the RPN hands them over: some proposals are jittered copies of ground-truth boxes (IoU around
+    the 0.5 threshold), the rest random"""
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    hip, ora = [], []
+    for c, (h, w), g in zip(counts, sizes, gts):
+        b = _rand_boxes(gen, c, h, w, lo=16.0, hi=0.4)
+        if len(g):
+            k = c // 3
+            src = g[torch.randint(0, len(g), (k,), generator=gen)]
+            b[:k] = src + torch.randn(k, 4, generator=gen) * (src[:, 2:] - src[:, :2]).repeat(1, 2) * 0.12
+        b[:, 0::2].clamp_(0, w)
+        b[:, 1::2].clamp_(0, h)
+        b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
+        lg = torch.randn(c, generator=gen)
+        a, o = FreeInstances((h, w)), opt.FreeInstances((h, w))
+        a.proposal_boxes, a.objectness_logits = Boxes(b.to(DEV)), lg.to(DEV)
+        o.proposal_boxes, o.objectness_logits = d2.Boxes(b.clone()), lg.clone()
+        hip.append(a)
+        ora.append(o)
+    return hip, ora
+
+
+def test_label_and_sample_proposals_identical_inputs_baseline_size():
+    """a18 as a FUNCTION (roi_heads.py:192-291): supervised (GT append, Matcher(0.5), class assignment, 512 @ 25 % keyed
+    sample) and unsupervised (matched-label-1 proposals with their pseudo box / teacher logits / sigma) on identical
+    proposals, 2 000 per image incl. an image without ground truth: every output field EXACTLY equal, in the same order."""
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.modeling.roi_heads import GuassianROIHead
+    from probabilisticteacher_amd.modeling.backbone import ShapeSpec
+    from tests.helpers import keyed_perm_source
+    K = 8
+    gen = torch.Generator().manual_seed(23)
+    sizes = [(800, 1333), (800, 1200), (768, 1333)]
+    counts = [2000, 1987, 2000]
+    head = GuassianROIHead(_cfg(K), {"vgg_block5": ShapeSpec(channels=512, stride=16)})
+    ocfg = opt.Cfg(num_classes=K)
+    gt_h, gt_o = _gt_instances(gen, [7, 0, 12], sizes, K)
+    pr_h, pr_o = _proposals(gen, counts, sizes, [g.gt_boxes.tensor for g in gt_o])
+    kp = opt.KeyedPerm(5)
+    sampling.set_key_source(keyed_perm_source(kp))
+    try:
+        got = head.label_and_sample_proposals(pr_h, gt_h)
+    finally:
+        sampling.set_key_source(None)
+    kp.start_replay()
+    ref = opt.sample_proposals_sup(ocfg, pr_o, gt_o, kp)
+    assert not kp.replay
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert len(a) == len(b) == 512, f"image {i}: {len(a)} vs {len(b)}"
+        assert torch.equal(a.gt_classes.cpu(), b.gt_classes), f"image {i}: classes / order"
+        assert torch.equal(a.proposal_boxes.tensor.cpu(), b.proposal_boxes.tensor), f"image {i}: sampled boxes"
+        assert torch.equal(a.objectness_logits.cpu(), b.objectness_logits) and torch.equal(a.gt_boxes.tensor.cpu(), b.gt_boxes.tensor)
+    assert 0 < int((got[0].gt_classes < K).sum()) <= 128 and int((got[1].gt_classes < K).sum()) == 0
+    # unsupervised branch
+    ps_h, ps_o = _gt_instances(gen, [100, 3, 100], sizes, K, with_pseudo=True)
+    pr_h, pr_o = _proposals(gen, counts, sizes, [p.pseudo_boxes.tensor for p in ps_o])
+    got = head.label_and_sample_proposals(pr_h, ps_h, branch="unsupervised")
+    ref = opt.sample_proposals_unsup(ocfg, pr_o, ps_o)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert len(a) == len(b) and len(b) > 0, f"image {i}: {len(a)} vs {len(b)}"
+        assert torch.equal(a.proposal_boxes.tensor.cpu(), b.proposal_boxes.tensor), f"image {i}: kept proposals"
+        assert torch.equal(a.pseudo_boxes.tensor.cpu(), b.pseudo_boxes.tensor) and torch.equal(a.soft_label.cpu(), b.soft_label)
+        assert torch.equal(a.boxes_sigma.cpu(), b.boxes_sigma)
+
+
+def test_label_and_sample_anchors_identical_inputs_baseline_size():
+    """a12 as a FUNCTION (rpn.py:363-448): the labels the RPN losses see -- IoU + Matcher(0.3, 0.7) with the
+    low-quality rule over 37 350 anchors, keyed 256 @ 25 % subsample, matched boxes of the positives -- for a batch of
+    images (one without ground truth), and the unsupervised variant (positives only, soft labels of the matched pseudo box)."""
+    from probabilisticteacher_amd import ops
+    from probabilisticteacher_amd.modeling import sampling
+    from tests.helpers import keyed_perm_source
+    K = 8
+    gen = torch.Generator().manual_seed(29)
+    ocfg = opt.Cfg(num_classes=K)
+    anchors = opt.make_anchors(ocfg, {}, (50, 83), False)
+    assert anchors.shape == (37350, 4)
+    sizes = [(800, 1333)] * 3
+    gt_h, gt_o = _gt_instances(gen, [9, 0, 15], sizes, K)
+    kp = opt.KeyedPerm(3)
+    sampling.set_key_source(keyed_perm_source(kp))
+    try:
+        counts = [len(g.gt_boxes) for g in gt_h]
+        gt_all = torch.cat([g.gt_boxes.tensor for g in gt_h], 0)
+        midx, lab, _, gt_off, _ = ops.iou_match_batched(gt_all, counts, anchors.to(DEV), None, list(ocfg.rpn_iou_thresholds),
+                                                        [0, -1, 1], True)
+        lab = sampling.keyed_relabel(lab, ocfg.rpn_batch_size_per_image, ocfg.rpn_positive_fraction, 0)
+    finally:
+        sampling.set_key_source(None)
+    kp.start_replay()
+    rl, rm = opt.label_anchors_sup(ocfg, anchors, [g.gt_boxes.tensor for g in gt_o], kp)
+    for i in range(3):
+        assert torch.equal(lab[i].cpu().long(), rl[i].long()), f"image {i}: sampled anchor labels"
+        pos = (rl[i] == 1).nonzero().squeeze(1)
+        if len(pos):
+            mine = gt_all[(midx[i][pos.to(DEV)] + gt_off[i].long())].cpu()
+            assert torch.equal(mine, rm[i][pos]), f"image {i}: matched boxes of the positives"
+    assert int((lab[0] >= 0).sum()) == 256 and int((lab[1] == 1).sum()) == 0 and int((lab[1] == 0).sum()) == 256
+    # unsupervised: positives only
+    ps_h, ps_o = _gt_instances(gen, [100, 1, 37], sizes, K, with_pseudo=True)
+    counts = [len(p.pseudo_boxes) for p in ps_h]
+    pb_all = torch.cat([p.pseudo_boxes.tensor for p in ps_h], 0)
+    midx, lab, _, gt_off, _ = ops.iou_match_batched(pb_all, counts, anchors.to(DEV), None, list(ocfg.rpn_iou_thresholds),
+                                                    [0, -1, 1], True)
+    soft, masks, matched, sigmas = opt.label_anchors_unsup(ocfg, anchors, ps_o)
+    all_logits = torch.cat([p.scores_logists for p in ps_h], 0)
+    for i in range(3):
+        m = (lab[i] == 1).cpu()
+        assert torch.equal(m, masks[i]), f"image {i}: positive mask"
+        sel = midx[i][m.to(DEV)] + gt_off[i].long()
+        assert torch.equal(all_logits[sel].cpu(), soft[i]), f"image {i}: soft labels of the matched pseudo boxes"
