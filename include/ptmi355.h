@@ -307,6 +307,11 @@ int ptmi_aug_gray_sum_batched(const int64_t* desc, int n, int64_t max_hw, uint64
 int ptmi_aug_color_batched(const int64_t* desc, int n, int64_t max_hw, const uint64_t* gray_sums, ptmi_stream_t s);
 int ptmi_aug_box_blur_batched(const int64_t* desc, int n, int64_t max_elems, ptmi_stream_t s);
 int ptmi_aug_hflip_batched(const int64_t* desc, int n, int64_t max_elems, ptmi_stream_t s);
+/*   resize   : one pass of Pillow's Image.resize(..., BILINEAR) (D2 ResizeShortestEdge / ResizeTransform of the weak
+ *              augmentation, dataset_mapper.py:107-109; antialiasing triangle filter, 22-bit fixed-point coefficients):
+ *              p4 = output size along the pass, p5 = 0: (3,h,w) -> (3,h,p4), 1: (3,h,w) -> (3,p4,w).  A resize is the x pass
+ *              followed by the y pass (a pass whose size does not change is skipped).  Down-scaling factors up to 15. */
+int ptmi_aug_resize_pass_batched(const int64_t* desc, int n, int64_t max_out_elems, ptmi_stream_t s);
 
 #ifdef __cplusplus
 }

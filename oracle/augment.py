@@ -26,6 +26,8 @@ def _lib():
         lib.ptaug_box_weights.restype = None
         lib.ptaug_box_weights.argtypes = [f, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32),
                                           ctypes.POINTER(ctypes.c_uint32)]
+        lib.ptaug_resize_bilinear.restype = None
+        lib.ptaug_resize_bilinear.argtypes = [vp, vp, i, i, i, i, i]
         lib.ptaug_gray_mean.restype = i
         lib.ptaug_gray_mean.argtypes = [vp, i64]
         lib._aug_ready = True
@@ -57,6 +59,20 @@ def hue_shift(hue_factor: float) -> int:
 def c_hue(img, hue_factor): return _run("ptaug_hue", img, hue_shift(hue_factor))
 def c_solarize(img, thr=128): return _run("ptaug_solarize", img, int(thr))
 def c_blur(img, sigma): return _run("ptaug_gaussian_blur", img, float(sigma))
+
+
+def c_resize(img: torch.Tensor, nh: int, nw: int) -> torch.Tensor:
+    """Image.resize((nw, nh), Image.BILINEAR) on a planar uint8 (C, H, W) image (D2 ResizeTransform.apply_image)"""
+    img = img.contiguous()
+    assert img.dtype == torch.uint8 and img.dim() == 3
+    out = torch.empty((img.shape[0], nh, nw), dtype=torch.uint8)
+    _lib().ptaug_resize_bilinear(img.data_ptr(), out.data_ptr(), img.shape[0], img.shape[1], img.shape[2], nh, nw)
+    return out
+
+
+def pil_resize(img: torch.Tensor, nh: int, nw: int) -> torch.Tensor:
+    from PIL import Image
+    return _from_pil(_to_pil(img).resize((nw, nh), Image.BILINEAR))
 
 
 def c_box_weights(sigma: float):

@@ -188,3 +188,86 @@ void ptaug_gaussian_blur(const uint8_t* in, uint8_t* out, int h, int w, float ra
     }
     free(tmp);
 }
+
+/* Image.resize(size, Image.BILINEAR) as detectron2's ResizeTransform.apply_image calls it for uint8 images (the
+ * ResizeShortestEdge of the weak augmentation, pt/data/dataset_mapper.py:107-109): Pillow's Resample.c -- separable
+ * convolution with the triangle filter whose support grows with the down-scaling factor (antialiasing), coefficients
+ * normalised in double and rounded to 22-bit fixed point, horizontal pass first, uint8 intermediate, a pass is skipped when
+ * its size does not change.  Pinned against the live Pillow in tests/test_augment_cpu.py. */
+#define PT_PRECISION_BITS (32 - 8 - 2)
+
+static int resample_coeffs(int inSize, int outSize, int xx, int* xmin_out, int32_t* k /* >= ksize entries */)
+{
+    double scale = (double)inSize / outSize, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;
+    const double center = 0 + (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > inSize) xmax = inSize;
+    xmax -= xmin;
+    double w[64], ww = 0.0;
+    for (int x = 0; x < xmax; ++x) {
+        double t = (x + xmin - center + 0.5) * ss;
+        if (t < 0.0) t = -t;
+        w[x] = t < 1.0 ? 1.0 - t : 0.0;
+        ww += w[x];
+    }
+    for (int x = 0; x < xmax; ++x) {
+        double v = w[x];
+        if (ww != 0.0) v /= ww;
+        k[x] = v < 0 ? (int32_t)(-0.5 + v * (1 << PT_PRECISION_BITS)) : (int32_t)(0.5 + v * (1 << PT_PRECISION_BITS));
+    }
+    *xmin_out = xmin;
+    return xmax;
+}
+
+static inline uint8_t resample_clip8(int32_t v)
+{
+    v >>= PT_PRECISION_BITS;
+    return v < 0 ? 0 : (v > 255 ? 255 : (uint8_t)v);
+}
+
+/* one pass over planar (c, h, w) data: along x -> (c, h, out) or along y -> (c, out, w) */
+static void resample_pass(const uint8_t* in, uint8_t* out, int c, int h, int w, int outSize, int vertical)
+{
+    const int inSize = vertical ? h : w;
+    int32_t k[64];
+    for (int o = 0; o < outSize; ++o) {
+        int xmin;
+        const int n = resample_coeffs(inSize, outSize, o, &xmin, k);
+        for (int ch = 0; ch < c; ++ch) {
+            if (!vertical) {
+                for (int y = 0; y < h; ++y) {
+                    int32_t ss = 1 << (PT_PRECISION_BITS - 1);
+                    const uint8_t* row = in + ((int64_t)ch * h + y) * w + xmin;
+                    for (int x = 0; x < n; ++x) ss += row[x] * k[x];
+                    out[((int64_t)ch * h + y) * outSize + o] = resample_clip8(ss);
+                }
+            } else {
+                for (int x = 0; x < w; ++x) {
+                    int32_t ss = 1 << (PT_PRECISION_BITS - 1);
+                    for (int y = 0; y < n; ++y) ss += in[((int64_t)ch * h + xmin + y) * w + x] * k[y];
+                    out[((int64_t)ch * outSize + o) * w + x] = resample_clip8(ss);
+                }
+            }
+        }
+    }
+}
+
+void ptaug_resize_bilinear(const uint8_t* in, uint8_t* out, int c, int h, int w, int nh, int nw)
+{
+    if (nh == h && nw == w) { memcpy(out, in, (size_t)c * h * w); return; }
+    if (nw != w && nh != h) {
+        uint8_t* tmp = (uint8_t*)malloc((size_t)c * h * nw);
+        resample_pass(in, tmp, c, h, w, nw, 0);
+        resample_pass(tmp, out, c, h, nw, nh, 1);
+        free(tmp);
+    } else if (nw != w) {
+        resample_pass(in, out, c, h, w, nw, 0);
+    } else {
+        resample_pass(in, out, c, h, w, nh, 1);
+    }
+}

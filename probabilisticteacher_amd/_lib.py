@@ -73,6 +73,7 @@ SIGNATURES = {
     "ptmi_aug_color_batched": (_i, [_vp, _i, _i64, _vp, _vp]),
     "ptmi_aug_box_blur_batched": (_i, [_vp, _i, _i64, _vp]),
     "ptmi_aug_hflip_batched": (_i, [_vp, _i, _i64, _vp]),
+    "ptmi_aug_resize_pass_batched": (_i, [_vp, _i, _i64, _vp]),
 }
 
 _lib = None

@@ -161,6 +161,61 @@ __global__ __launch_bounds__(256) void aug_hflip_kernel(const int64_t* __restric
     }
 }
 
+// One pass of Pillow's Image.resize(..., BILINEAR) (Resample.c; D2 ResizeTransform of the weak augmentation,
+// dataset_mapper.py:107-109) along x (p5 = 0: (3,h,w) -> (3,h,p4)) or y (p5 = 1: (3,h,w) -> (3,p4,w)): triangle filter whose
+// support grows with the down-scaling factor, coefficients normalised in double and rounded to 22-bit fixed point, integer
+// accumulation from 2^21, >> 22, saturate.  Every thread recomputes the few coefficients of its output column / row with the
+// exact double expression tree of precompute_coeffs() (a table kernel would save ALU work nobody is waiting for).
+constexpr int RS_PRECISION_BITS = 32 - 8 - 2;
+constexpr int RS_MAX_TAPS = 32;             // ksize = 2 * ceil(scale) + 1: down-scaling factors up to 15
+
+__global__ __launch_bounds__(256) void aug_resize_pass_kernel(const int64_t* __restrict__ desc)
+{
+    const int64_t* d = desc + 8 * (int64_t)blockIdx.y;
+    const uint8_t* src = (const uint8_t*)d[0];
+    uint8_t* dst = (uint8_t*)d[1];
+    const int h = (int)d[2], w = (int)d[3], outSize = (int)d[4], vertical = (int)d[5];
+    const int inSize = vertical ? h : w;
+    const int oh = vertical ? outSize : h, ow = vertical ? w : outSize;
+    const int64_t total = 3ll * oh * ow;
+    double scale = (double)inSize / outSize, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;
+    const double ss = 1.0 / filterscale;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % ow);
+        const int oy = (int)((i / ow) % oh);
+        const int c = (int)(i / ((int64_t)ow * oh));
+        const int xx = vertical ? oy : ox;
+        const double center = 0 + (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > inSize) xmax = inSize;
+        xmax -= xmin;
+        if (xmax > RS_MAX_TAPS) xmax = RS_MAX_TAPS;        // (rejected on the host)
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) {
+            double t = (x + xmin - center + 0.5) * ss;
+            if (t < 0.0) t = -t;
+            ww += t < 1.0 ? 1.0 - t : 0.0;
+        }
+        const uint8_t* p = vertical ? src + ((int64_t)c * h + xmin) * w + ox : src + ((int64_t)c * h + oy) * w + xmin;
+        const int64_t st = vertical ? w : 1;
+        int acc = 1 << (RS_PRECISION_BITS - 1);
+        for (int x = 0; x < xmax; ++x) {
+            double t = (x + xmin - center + 0.5) * ss;
+            if (t < 0.0) t = -t;
+            double v = t < 1.0 ? 1.0 - t : 0.0;
+            if (ww != 0.0) v /= ww;
+            const int k = v < 0 ? (int)(-0.5 + v * (1 << RS_PRECISION_BITS)) : (int)(0.5 + v * (1 << RS_PRECISION_BITS));
+            acc += (int)p[x * st] * k;
+        }
+        acc >>= RS_PRECISION_BITS;
+        dst[i] = acc < 0 ? 0 : (acc > 255 ? 255 : (uint8_t)acc);
+    }
+}
+
 inline dim3 grid_for(int n, int64_t max_elems)
 {
     int64_t bx = (max_elems + 1023) / 1024;
@@ -211,6 +266,15 @@ int ptmi_aug_hflip_batched(const int64_t* desc, int n, int64_t max_elems, ptmi_s
     PTMI_CHECK_ARG(desc && n > 0 && n < 65536 && max_elems > 0, "aug_hflip_batched: bad args");
     hipLaunchKernelGGL(aug_hflip_kernel, grid_for(n, max_elems), dim3(256), 0, (hipStream_t)s, desc);
     PTMI_LAUNCH_CHECK("aug_hflip_batched");
+    return 0;
+}
+
+int ptmi_aug_resize_pass_batched(const int64_t* desc, int n, int64_t max_out_elems, ptmi_stream_t s)
+{
+    if (n == 0) return 0;
+    PTMI_CHECK_ARG(desc && n > 0 && n < 65536 && max_out_elems > 0, "aug_resize_pass_batched: bad args");
+    hipLaunchKernelGGL(aug_resize_pass_kernel, grid_for(n, max_out_elems), dim3(256), 0, (hipStream_t)s, desc);
+    PTMI_LAUNCH_CHECK("aug_resize_pass_batched");
     return 0;
 }
 

@@ -141,3 +141,41 @@ def hflip_batch(images: Sequence[torch.Tensor], flips: Sequence[bool]) -> List[t
     rows = [[im.data_ptr(), o.data_ptr(), im.shape[-2], im.shape[-1], int(bool(f)), 0, 0, 0] for im, o, f in zip(images, out, flips)]
     _launch("ptmi_aug_hflip_batched", rows, dev, max(im.numel() for im in images))
     return out
+
+
+def resize_shortest_edge_size(h: int, w: int, short_edge: int, max_size: int) -> Tuple[int, int]:
+    """D2 ResizeShortestEdge.get_transform: scale the short side to `short_edge`, cap the long side at `max_size`, round
+    half up.  Returns (new_h, new_w)."""
+    scale = short_edge * 1.0 / min(h, w)
+    newh, neww = (short_edge, scale * w) if h < w else (scale * h, short_edge)
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * scale, neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def resize_batch(images: Sequence[torch.Tensor], sizes: Sequence[Tuple[int, int]]) -> List[torch.Tensor]:
+    """Image.resize((new_w, new_h), Image.BILINEAR) of D2's ResizeTransform for a batch of planar uint8 images: the x pass
+    of all images in one launch, then the y pass (a pass that does not change the size is skipped, as in Pillow)."""
+    if not images:
+        return []
+    dev = images[0].device
+    cur = [_chk(im.contiguous(), torch.uint8, "image") for im in images]
+    for vertical in (0, 1):
+        rows, outs, idx = [], [], []
+        for i, (im, (nh, nw)) in enumerate(zip(cur, sizes)):
+            h, w = im.shape[-2:]
+            new = nh if vertical else nw
+            if new == (h if vertical else w):
+                continue
+            if math.ceil(max((h if vertical else w) / new, 1.0)) * 2 + 1 > 32:
+                raise ValueError(f"resize {h}x{w} -> {nh}x{nw}: down-scaling factor beyond the kernel's 32-tap window")
+            o = torch.empty((3, new, w) if vertical else (3, h, new), dtype=torch.uint8, device=dev)
+            rows.append([im.data_ptr(), o.data_ptr(), h, w, new, vertical, 0, 0])
+            outs.append(o)
+            idx.append(i)
+        if rows:
+            _launch("ptmi_aug_resize_pass_batched", rows, dev, max(o.numel() for o in outs))
+            for i, o in zip(idx, outs):
+                cur[i] = o
+    return cur

@@ -5,41 +5,57 @@ ResizeShortestEdge + RandomFlip) -> `image_weak_aug`; strong augmentation of a c
 (strong, weak) in the a0 record format ("image" uint8 (3,H,W), "instances" FreeInstances{gt_boxes, gt_classes}, height,
 width); pt/data/common.py:106-180 `AspectRatioGroupedSemiSupDatasetTwoCrop`.
 
-Scope: decoding and resizing stay on the host side of the boundary (the mapper takes the decoded image at training
-resolution); horizontal flip, the four strong augmentations and the batching run here, for a whole step's images at once."""
+Scope: image decoding stays on the host side of the boundary (the mapper takes the decoded uint8 image); the weak
+augmentation (ResizeShortestEdge = Pillow's antialiased bilinear resize, RandomFlip), the four strong augmentations and the
+batching run here, for a whole step's images at once."""
 import random
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 
 from ..structures import Boxes, FreeInstances
-from .augment import StrongParams, hflip_batch, sample_strong_params, strong_augment_batch
+from .augment import (StrongParams, hflip_batch, resize_batch, resize_shortest_edge_size, sample_strong_params,
+                      strong_augment_batch)
 
 
 class DeviceTwoCropMapper:
     """dataset dicts {"image": uint8 (3,H,W) tensor (any device), "boxes": (M,4) xyxy abs, "classes": (M,), "height",
     "width"} -> list of (strong record, weak record) pairs, as DatasetMapperTwoCropSeparate returns per image."""
 
-    def __init__(self, device, flip_prob: float = 0.5, seed: Optional[int] = None, min_box_side: float = 1e-5):
+    def __init__(self, device, flip_prob: float = 0.5, seed: Optional[int] = None, min_box_side: float = 1e-5,
+                 min_size_train: Sequence[int] = (), max_size_train: int = 1333):
+        """min_size_train / max_size_train = cfg.INPUT.MIN_SIZE_TRAIN / MAX_SIZE_TRAIN (sample_style "choice"); empty:
+        the images already have their training resolution."""
         self.device = torch.device(device)
         self.flip_prob = flip_prob
         self.rng = random.Random(seed)
         self.min_box_side = min_box_side
+        self.min_size_train, self.max_size_train = tuple(min_size_train), max_size_train
+
+    @classmethod
+    def from_config(cls, cfg, seed: Optional[int] = None):
+        return cls(cfg.MODEL.DEVICE, flip_prob=0.5 if cfg.INPUT.RANDOM_FLIP == "horizontal" else 0.0, seed=seed,
+                   min_size_train=cfg.INPUT.MIN_SIZE_TRAIN, max_size_train=cfg.INPUT.MAX_SIZE_TRAIN)
 
     def __call__(self, dataset_dicts: Sequence[Dict], params: Optional[Sequence[StrongParams]] = None,
-                 flips: Optional[Sequence[bool]] = None) -> List[Tuple[Dict, Dict]]:
+                 flips: Optional[Sequence[bool]] = None, sizes: Optional[Sequence[Tuple[int, int]]] = None) -> List[Tuple[Dict, Dict]]:
         n = len(dataset_dicts)
+        imgs = [d["image"].to(self.device, non_blocking=True) for d in dataset_dicts]
+        if sizes is None:
+            sizes = [resize_shortest_edge_size(im.shape[-2], im.shape[-1], self.rng.choice(self.min_size_train), self.max_size_train)
+                     if self.min_size_train else tuple(im.shape[-2:]) for im in imgs]
         flips = list(flips) if flips is not None else [self.rng.random() < self.flip_prob for _ in range(n)]
         params = list(params) if params is not None else [sample_strong_params(self.rng) for _ in range(n)]
-        imgs = [d["image"].to(self.device, non_blocking=True) for d in dataset_dicts]
-        weak = hflip_batch(imgs, flips)
+        weak = hflip_batch(resize_batch(imgs, sizes), flips)          # T.ResizeShortestEdge, then T.RandomFlip
         strong = strong_augment_batch(weak, params)
         out = []
-        for d, w_img, s_img, flip in zip(dataset_dicts, weak, strong, flips):
+        for d, src, w_img, s_img, flip in zip(dataset_dicts, imgs, weak, strong, flips):
             h, w = w_img.shape[-2:]
             inst = None
             if "boxes" in d:
                 b = d["boxes"].to(self.device).float().clone()
+                b[:, 0::2] *= w * 1.0 / src.shape[-1]        # ResizeTransform.apply_coords
+                b[:, 1::2] *= h * 1.0 / src.shape[-2]
                 if flip:                                     # HFlipTransform.apply_coords: x -> w - x, then re-order
                     x1 = w - b[:, 2]
                     x2 = w - b[:, 0]

@@ -88,3 +88,19 @@ def test_parameter_sampling_weights_and_grouping():
         assert len(ls) == len(lw) == len(us) == len(uw) == 2
         assert len({r["width"] > r["height"] for r in ls}) == 1 and len({r["width"] > r["height"] for r in us}) == 1
         assert [r["id"][:2] for r in ls] == [r["id"][:2] for r in lw] and all(r["id"][2] == "weak" for r in lw)
+
+
+def test_resize_restatement_equals_live_pillow():
+    """Image.resize(..., BILINEAR) of D2's ResizeTransform (the weak augmentation's ResizeShortestEdge): the C restatement
+    of Pillow's Resample.c against the live Pillow -- down- and up-scaling, one-axis-only, Cityscapes -> 1333 x 666; and
+    D2's size rule."""
+    pytest.importorskip("PIL")
+    from probabilisticteacher_amd.data import resize_shortest_edge_size
+    rng = np.random.RandomState(1)
+    for (H, W, nh, nw) in [(97, 131, 60, 81), (97, 131, 150, 200), (200, 400, 123, 247), (64, 64, 64, 100), (50, 70, 50, 70),
+                           (1024, 2048, 666, 1333), (375, 500, 800, 1067), (31, 17, 9, 5), (600, 90, 40, 90)]:
+        img = torch.from_numpy(rng.randint(0, 256, (3, H, W)).astype(np.uint8))
+        _eq(A.c_resize(img, nh, nw), A.pil_resize(img, nh, nw), f"resize {H}x{W} -> {nh}x{nw}")
+    assert resize_shortest_edge_size(1024, 2048, 600, 1200) == (600, 1200)
+    assert resize_shortest_edge_size(1024, 2048, 800, 1333) == (667, 1333)        # long side capped: 1333 / 2048 * 1024 = 666.5
+    assert resize_shortest_edge_size(375, 500, 800, 1333) == (800, 1067) and resize_shortest_edge_size(500, 375, 600, 1333) == (800, 600)

@@ -98,3 +98,29 @@ def test_hflip_and_two_crop_mapper_record_format():
     assert torch.equal(inst.gt_boxes.tensor.cpu(), torch.tensor([[37.0, 4.0, 62.0, 20.0], [0.0, 1.0, 7.0, 39.0]]))
     assert inst.gt_classes.cpu().tolist() == [2, 5] and "instances" not in s1 and w1["image"].shape == (3, 31, 32)
     _eq(s1["image"], A.c_gray(imgs[1]), "second image")
+
+
+def test_resize_and_full_weak_plus_strong_pipeline():
+    """ResizeShortestEdge on the device (Pillow's antialiased bilinear resample, byte-exact with the C restatement that is
+    pinned to the live Pillow) incl. Cityscapes -> 1333 x 667, up-scaling, one-axis-only; then the mapper end to end:
+    resize -> flip -> strong augmentation, boxes scaled and flipped."""
+    from probabilisticteacher_amd.data import DeviceTwoCropMapper, StrongParams, resize_batch
+    rs = np.random.RandomState(8)
+    cases = [(_img(rs, 97, 131), (60, 81)), (_img(rs, 97, 131, smooth=True), (150, 200)), (_img(rs, 64, 64), (64, 100)),
+             (_img(rs, 50, 70), (50, 70)), (_img(rs, 1024, 2048, smooth=True), (667, 1333)), (_img(rs, 375, 500), (800, 1067)),
+             (_img(rs, 600, 90), (40, 90)), (_img(rs, 31, 17), (9, 5))]
+    outs = resize_batch([im.to(DEV) for im, _ in cases], [sz for _, sz in cases])
+    for (im, (nh, nw)), o in zip(cases, outs):
+        _eq(o, A.c_resize(im, nh, nw), f"resize {tuple(im.shape)} -> {(nh, nw)}")
+    with pytest.raises(ValueError):
+        resize_batch([cases[4][0].to(DEV)], [(30, 60)])                 # a 34x down-scale is outside the kernel's tap window
+    img = _img(rs, 120, 200, smooth=True)
+    dd = [{"image": img, "boxes": torch.tensor([[20.0, 30.0, 100.0, 90.0]]), "classes": torch.tensor([4])}]
+    mp = DeviceTwoCropMapper(DEV, seed=0, min_size_train=(90,), max_size_train=120)
+    (s, w), = mp(dd, params=[StrongParams(blur_sigma=1.3)], flips=[True])
+    assert w["image"].shape == (3, 72, 120) and (w["height"], w["width"]) == (72, 120)     # 90 / 120 * 200 = 150 > 120 -> capped
+    weak_ref = A.c_resize(img, 72, 120).flip(-1).contiguous()
+    _eq(w["image"], weak_ref, "weak view = resized + flipped")
+    _eq(s["image"], A.c_blur(weak_ref, 1.3), "strong view")
+    want = torch.tensor([[120 - 100 * 0.6, 30 * 0.6, 120 - 20 * 0.6, 90 * 0.6]])
+    assert torch.allclose(s["instances"].gt_boxes.tensor.cpu(), want, atol=1e-4)
