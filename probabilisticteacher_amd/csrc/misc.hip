@@ -30,32 +30,45 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
 }
 
 // dx[pos] = dy[window] iff pos is the FIRST maximum of its window (scan order (0,0),(0,1),(1,0),(1,1)).
-__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                   float* __restrict__ dx, int nc, int h, int w, int oh, int ow, int relu_mask)
+// One thread per 2x2 WINDOW: every x element is read once and every dx element written once (the first version ran one
+// thread per input element, i.e. four reads of each window); the odd last row / column of a floor-mode pool gets zeros from
+// the threads of the neighbouring window.  grid.y = plane (n * c), threads walk the (oh + 1) x (ow + 1) window grid.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int nc, int h, int w, int oh,
+                                                          int ow, int relu_mask)
 {
-    const int64_t total = (int64_t)nc * h * w;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int xx = i % w;
-        const int64_t t = i / w;
-        const int yy = t % h;
-        const int64_t c = t / h;
-        const int ox = xx >> 1, oy = yy >> 1;
-        float g = 0.f;
-        if (ox < ow && oy < oh) {
-            const float* p = x + (c * h + 2 * oy) * (int64_t)w + 2 * ox;
-            const float v[4] = {p[0], p[1], p[w], p[w + 1]};
+  for (int64_t plane = blockIdx.y; plane < nc; plane += gridDim.y) {
+    const float* xp = x + plane * (int64_t)h * w;
+    float* dp = dx + plane * (int64_t)h * w;
+    const float* gp = dy + plane * (int64_t)oh * ow;
+    const int gw = ow + (w & 1), gh = oh + (h & 1);          // window grid incl. the unpooled tail column / row
+    const int total = gw * gh;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int oy = i / gw, ox = i - oy * gw;
+        const int y0 = 2 * oy, x0 = 2 * ox;
+        if (oy < oh && ox < ow) {
+            const float* p = xp + (int64_t)y0 * w + x0;
+            const float v0 = p[0], v1 = p[1], v2 = p[w], v3 = p[w + 1];
             int am = 0;
-            float m = v[0];
-#pragma unroll
-            for (int k = 1; k < 4; ++k)
-                if (v[k] > m || v[k] != v[k]) { m = v[k]; am = k; }
-            const int me = (yy & 1) * 2 + (xx & 1);
+            float m = v0;
+            if (v1 > m || v1 != v1) { m = v1; am = 1; }
+            if (v2 > m || v2 != v2) { m = v2; am = 2; }
+            if (v3 > m || v3 != v3) { m = v3; am = 3; }
             // relu_mask: x is a post-ReLU activation; also apply d/d(pre-activation) = (x > 0) in the same pass
-            if (me == am && (!relu_mask || m > 0.f)) g = dy[(c * oh + oy) * (int64_t)ow + ox];
+            const float g = (!relu_mask || m > 0.f) ? gp[(int64_t)oy * ow + ox] : 0.f;
+            float* q = dp + (int64_t)y0 * w + x0;
+            q[0] = am == 0 ? g : 0.f;
+            q[1] = am == 1 ? g : 0.f;
+            q[w] = am == 2 ? g : 0.f;
+            q[w + 1] = am == 3 ? g : 0.f;
+        } else {
+            // tail: elements that belong to no window
+            for (int dyy = 0; dyy < 2; ++dyy)
+                for (int dxx = 0; dxx < 2; ++dxx)
+                    if (y0 + dyy < h && x0 + dxx < w) dp[(int64_t)(y0 + dyy) * w + x0 + dxx] = 0.f;
         }
-        dx[i] = g;
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------- image prep
@@ -268,8 +281,11 @@ int ptmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int nc, int 
 {
     PTMI_CHECK_ARG(x && dy && dx && nc > 0 && h >= 2 && w >= 2, "maxpool2x2_bwd: bad args");
     const int oh = h / 2, ow = w / 2;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)nc * h * w)), dim3(256), 0, (hipStream_t)s, x, dy,
-                       dx, nc, h, w, oh, ow, relu_mask);
+    const int windows = (oh + (h & 1)) * (ow + (w & 1));
+    int bx = (windows + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)bx, (unsigned)(nc < 65535 ? nc : 65535)), dim3(256), 0,
+                       (hipStream_t)s, x, dy, dx, nc, h, w, oh, ow, relu_mask);
     PTMI_LAUNCH_CHECK("maxpool2x2_bwd");
     return 0;
 }
