@@ -11,7 +11,7 @@
 //     operands go global -> LDS with `buffer_load_dwordx4 ... lds`, double buffered, one barrier per chunk;
 //   * dgrad reuses the same kernel with flipped/transposed packed weights; the producer's ReLU mask can be applied
 //     in the epilogue (epilogue 3); frozen blocks fuse bias + ReLU + 2x2 max pool (epilogue 4);
-//   * the 3-channel stem is a VALU pixel-per-thread kernel (HBM-write bound);
+//   * the 3-channel stem is a VALU kernel over the flattened plane (HBM-write bound; packed fp32 FMAs);
 //   * wgrad: `conv3x3_wgrad_buf_kernel` -- M = Cout, N = Cin (x 9 taps as 9 accumulator tiles), K = pixels; split-K
 //     over pixel tiles with a fixed-order second-stage reduction (deterministic).
 // Shapes whose per-image byte offsets do not fit 32 bits are rejected with an error (no fallback kernels).
@@ -275,48 +275,142 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
 }
 
 // ------------------------------------------------------------------------------------ stem (Cin <= 4), VALU
-// The 3-channel stem has K = 27: 3.7 GF per image against 273 MB of output -- an HBM-write-bound layer whose MFMA
-// formulations (above) spend their time in per-workgroup latency chains (2.3 ms per 16 images = 1.9 TB/s of stores).
-// Here a thread owns ONE pixel and all 64 channels of a channel tile: it gathers its 3x3xCin inputs once, the weights of
-// a (tap, channel) pair are 64 consecutive floats of the packed slab and arrive through the scalar cache (wave-uniform
-// address), and every store instruction writes 64 consecutive pixels of one channel plane (256 B).  64 accumulator
-// VGPRs, no LDS, no barrier, eight waves per SIMD.
-__global__ __launch_bounds__(256) void conv3x3_stem_kernel(const float* __restrict__ x, const float* __restrict__ wp,
-                                                           const float* __restrict__ bias, float* __restrict__ y, int Cin,
-                                                           int Cout, int H, int W, int coTiles, int relu)
+// The 3-channel stem has K = 27: 3.7 GF per image against 273 MB of output -- an HBM-WRITE-bound layer whose MFMA
+// formulation spends its time in per-workgroup latency chains.  What the write side can reach depends on the store
+// pattern (tools/exp/store_pattern.hip, 48 x 64 x 800 x 1333 fp32): a flat fill 6.9 TB/s; 64 planes written as 1 KB runs
+// that start on a 16-B boundary 5.9 TB/s; the same runs starting at each ROW's first pixel -- rows of 1333 floats are only
+// 4-B aligned -- 2.9 TB/s; 256-B runs per row (one pixel per lane) 1.8 TB/s.  So the kernel tiles the FLATTENED plane:
+//   * a lane owns the four consecutive flat pixel indices 4t .. 4t + 3 of a plane (one aligned 16-B store per channel,
+//     1 KB per wave and channel) and a wave the 16 channels 16w .. 16w + 15 of the 64-channel tile;
+//   * the four pixels usually sit in one row and share a 3 x 6 input window per input channel.  Where they wrap over a
+//     row end the wave runs the body once per row touched ("frame": row y0 + f, first column x0 - f W) and each frame
+//     stores the pixels whose column falls inside it -- one extra pass for the one wave in ~5 that holds a row end;
+//   * weights arrive through the scalar cache (one s_load_dwordx16 = the wave's 16 channels of one (tap, ci)) and feed
+//     v_pk_fma_f32 on channel pairs; the input pixel is picked out of a column-pair register with op_sel, so one scalar
+//     load feeds 32 packed FMAs.  (The first version, one pixel x 64 channels per lane, needed 64 B of scalar loads per
+//     8 FMAs and was bound by the scalar cache as well as by its 256-B stores.)
+constexpr int STEM_PX = 4, STEM_CH = 16;
+typedef float stem_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float stem_f2 __attribute__((ext_vector_type(2)));
+typedef float stem_f16 __attribute__((ext_vector_type(16)));
+
+template <int CIN>
+__global__ __launch_bounds__(256, 3) void conv3x3_stem_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int Cin, int Cout, int H, int W, int coTiles, int relu)
 {
     constexpr int BM = 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int px = blockIdx.x * 64 + lane, py = blockIdx.y * 4 + wave, n = blockIdx.z;
-    const int HW = H * W;
-    const bool inside = px < W && py < H;
+    const int lane = threadIdx.x & 63;
+    const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wave's 16-channel group
+    const int HW = H * W, n = blockIdx.y;
+    const int i0 = (blockIdx.x * 64 + lane) * STEM_PX;                     // first flat pixel index of this lane
+    const int y0 = i0 / W, x0 = i0 - y0 * W;
+    const int cnt = min(STEM_PX, HW - i0);                                 // pixels inside the plane (<= 0: idle lane)
+    const int frames = cnt > 0 ? (i0 + cnt - 1) / W - y0 + 1 : 0;          // rows this lane's pixels touch
     const float* xn = x + (size_t)n * Cin * HW;
-    float v[36];                                           // [tap][ci] with ci padded to 4
+    float* yn = y + (size_t)n * Cout * HW + i0;
+    // Input window of the block, staged once for its four waves: for (ci, ky) the flat input range
+    // [b0 + (ky - 1) W - 1, + 64 STEM_PX + 2) is contiguous; what a lane needs sits at 4 lane .. 4 lane + 5 of it.  Row and
+    // column padding is applied when the window is read (a flat neighbour beyond a row end is the next row's pixel).
+    constexpr int TW = 64 * STEM_PX + 8;
+    __shared__ __attribute__((aligned(16))) float tile[CIN * 3][TW];
+    {
+        const long long b0 = (long long)blockIdx.x * 64 * STEM_PX - 1;
+        float stage[CIN * 3], extra = 0.f;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int gy = py + tap / 3 - 1, gx = px + tap % 3 - 1;
-        const bool ok = inside && gy >= 0 && gy < H && gx >= 0 && gx < W;
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) v[tap * 4 + ci] = (ok && ci < Cin) ? xn[(size_t)ci * HW + (size_t)gy * W + gx] : 0.f;
-    }
-    float* yn = y + (size_t)n * Cout * HW + (size_t)py * W + px;
-    for (int cot = 0; cot < coTiles; ++cot) {
-        const float* wt = wp + (size_t)cot * 9 * 4 * BM;   // packed [tap][ci][64 channels] (one 4-channel chunk)
-        const int co0 = cot * BM;
-        float acc[BM];
-#pragma unroll
-        for (int c = 0; c < BM; ++c) acc[c] = (co0 + c < Cout) ? bias[co0 + c] : 0.f;
-#pragma unroll
-        for (int k = 0; k < 36; ++k) {
-            if ((k & 3) >= Cin) continue;                  // padded channel: the slab holds zeros there
-            const float* wr = wt + k * BM;
-#pragma unroll
-            for (int c = 0; c < BM; ++c) acc[c] = fmaf(wr[c], v[k], acc[c]);
+        for (int r = 0; r < CIN * 3; ++r) {                // all loads in flight before the first LDS write
+            const long long g = b0 + (long long)(r % 3 - 1) * W + threadIdx.x;
+            stage[r] = (r / 3 < Cin && g >= 0 && g < HW) ? xn[(size_t)(r / 3) * HW + g] : 0.f;
         }
-        if (inside) {
+        if (threadIdx.x < CIN * 3 * 2) {                   // the two trailing columns of each row
+            const int r = threadIdx.x >> 1;
+            const long long g = b0 + (long long)(r % 3 - 1) * W + 64 * STEM_PX + (threadIdx.x & 1);
+            extra = (r / 3 < Cin && g >= 0 && g < HW) ? xn[(size_t)(r / 3) * HW + g] : 0.f;
+        }
 #pragma unroll
-            for (int c = 0; c < BM; ++c) {
-                if (co0 + c < Cout) yn[(size_t)(co0 + c) * HW] = relu ? fmaxf(acc[c], 0.f) : acc[c];
+        for (int r = 0; r < CIN * 3; ++r) tile[r][threadIdx.x] = stage[r];
+        if (threadIdx.x < CIN * 3 * 2) tile[threadIdx.x >> 1][64 * STEM_PX + (threadIdx.x & 1)] = extra;
+    }
+    __syncthreads();
+    for (int f = 0; __builtin_amdgcn_ballot_w64(f < frames) != 0; ++f) {   // wave-uniform trip count
+        if (f >= frames) continue;
+        const int py = y0 + f, px0 = x0 - f * W;                           // pixel p of the lane has column px0 + p in this frame
+        bool cok[STEM_PX + 2];
+#pragma unroll
+        for (int j = 0; j < STEM_PX + 2; ++j) cok[j] = px0 - 1 + j >= 0 && px0 - 1 + j < W;
+        const bool full = px0 >= 0 && px0 + STEM_PX <= W;                  // all four pixels in this row
+#pragma unroll 1
+        for (int cot = 0; cot < coTiles; ++cot) {
+            const int co0 = cot * BM + cg * STEM_CH;
+            const float* wt = wp + (size_t)cot * 9 * 4 * BM + cg * STEM_CH;     // packed [tap][ci (4)][64 channels]
+            stem_f2 acc[STEM_PX][STEM_CH / 2];             // channel pairs: v_pk_fma_f32 with an SGPR weight pair
+#pragma unroll
+            for (int c = 0; c < STEM_CH / 2; ++c) {
+                stem_f2 b;
+                b.x = (co0 + 2 * c < Cout) ? bias[co0 + 2 * c] : 0.f;
+                b.y = (co0 + 2 * c + 1 < Cout) ? bias[co0 + 2 * c + 1] : 0.f;
+#pragma unroll
+                for (int p = 0; p < STEM_PX; ++p) acc[p][c] = b;
+            }
+            // one s_load_dwordx16 per (tap, ci), requested one step ahead of its use
+            stem_f16 wnext = *reinterpret_cast<const stem_f16*>(wt);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                // this kernel row's inputs: [ci][column pair] = columns px0 - 1 + 2j, px0 + 2j of row py + ky - 1
+                stem_f2 v[CIN][STEM_PX / 2 + 1];
+                const bool rok = py + ky - 1 >= 0 && py + ky - 1 < H;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float4 q0 = *reinterpret_cast<const float4*>(&tile[ci * 3 + ky][lane * STEM_PX]);
+                    const float2 q1 = *reinterpret_cast<const float2*>(&tile[ci * 3 + ky][lane * STEM_PX + 4]);
+                    const float t[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+#pragma unroll
+                    for (int j = 0; j < STEM_PX + 2; ++j) {
+                        const float u = (rok && cok[j]) ? t[j] : 0.f;
+                        if (j & 1) v[ci][j >> 1].y = u; else v[ci][j >> 1].x = u;
+                    }
+                }
+#pragma unroll
+                for (int s9 = 0; s9 < 3 * CIN; ++s9) {     // (channels >= Cin: zero inputs against zero weights)
+                    const int kx = s9 / CIN, ci = s9 % CIN, step = ky * 3 * CIN + s9;
+                    const stem_f16 wcur = wnext;
+                    if (step + 1 < 9 * CIN)
+                        wnext = *reinterpret_cast<const stem_f16*>(wt + (((step + 1) / CIN) * 4 + (step + 1) % CIN) * BM);
+#pragma unroll
+                    for (int c = 0; c < STEM_CH / 2; ++c) {
+                        const stem_f2 wv = {wcur[2 * c], wcur[2 * c + 1]};
+#pragma unroll
+                        for (int p = 0; p < STEM_PX; ++p) {
+                            // acc.{x,y} = fma(w.{x,y}, x, acc.{x,y}) with x one half of an input column pair,
+                            // selected for both result halves by op_sel (no duplicated input registers)
+                            if ((p + kx) & 1)
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                                             : "+v"(acc[p][c]) : "s"(wv), "v"(v[ci][(p + kx) >> 1]));
+                            else
+                                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+                                             : "+v"(acc[p][c]) : "s"(wv), "v"(v[ci][(p + kx) >> 1]));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < STEM_CH; ++c) {
+                if (co0 + c >= Cout) continue;
+                float* dst = yn + (size_t)(co0 + c) * HW;
+                float o[STEM_PX];
+#pragma unroll
+                for (int p = 0; p < STEM_PX; ++p) {
+                    const float a = (c & 1) ? acc[p][c >> 1].y : acc[p][c >> 1].x;
+                    o[p] = relu ? fmaxf(a, 0.f) : a;
+                }
+                if (full) {
+                    stem_f4u q = {o[0], o[1], o[2], o[3]};
+                    *reinterpret_cast<stem_f4u*>(dst) = q;  // 16-B aligned whenever H W % 4 == 0 and y is
+                } else {
+#pragma unroll
+                    for (int p = 0; p < STEM_PX; ++p)
+                        if (px0 + p >= 0 && px0 + p < W) dst[p] = o[p];
+                }
             }
         }
     }
@@ -751,8 +845,12 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
     // 3-channel stem: K = 27 is too short to amortise the LDS pipeline's prologue and the layer is HBM-write bound
     if (BM == 64 && cin <= 4 && epilogue <= 1) {
         // (-ffp-contract=off: fmaf() is explicit in the kernel; K = 27 keeps the rounding difference at the 1e-7 level)
-        hipLaunchKernelGGL(conv3x3_stem_kernel, dim3((unsigned)cdiv(w, 64), (unsigned)cdiv(h, 4), (unsigned)n), dim3(256), 0,
-                           st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
+        PTMI_CHECK_ARG(n < 65536 && (int64_t)h * w < (int64_t)1 << 30, "conv3x3_fwd(stem): grid too large");
+        const dim3 gs((unsigned)cdiv(h * w, 64 * STEM_PX), (unsigned)n);
+        if (cin <= 3)
+            hipLaunchKernelGGL(conv3x3_stem_kernel<3>, gs, dim3(256), 0, st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
+        else
+            hipLaunchKernelGGL(conv3x3_stem_kernel<4>, gs, dim3(256), 0, st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
         PTMI_LAUNCH_CHECK("conv3x3_fwd(stem)");
         return 0;
     }

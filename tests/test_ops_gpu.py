@@ -670,6 +670,42 @@ def test_conv3x3_random_shapes(ops):
         close(bd.grad, br.grad, 1e-4, 1e-3, "bias grad " + tag)
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (2, 3, 64, 5, 1),       # one-column image: a lane's four flat pixels are four rows (four frames)
+    (1, 3, 64, 7, 2),       # two frames per lane
+    (2, 3, 64, 9, 3),       # lanes straddle one or two row ends
+    (1, 3, 64, 6, 5),       # H W % 4 != 0: ragged last lane, unaligned planes
+    (3, 3, 64, 11, 67),     # H W = 737: planes at every 4-B misalignment, row ends inside many lanes
+    (1, 3, 64, 3, 257),     # a row longer than one 256-pixel block
+    (2, 1, 20, 4, 9),       # Cin = 1, channel count off the 16-channel wave groups
+    (1, 2, 70, 8, 13),      # Cin = 2, two 64-channel tiles, the second ragged
+    (2, 4, 130, 5, 31),     # Cin = 4 (the other template instance), three tiles
+    (1, 3, 64, 1, 1),       # a single pixel
+])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3x3_stem_flat_mapping(ops, n, cin, cout, h, w, relu):
+    """The Cin <= 4 stem kernel tiles the FLATTENED plane (four consecutive flat pixels per lane, re-run per row
+    touched): forward against torch CPU on shapes whose lanes wrap over row ends, whose planes are not 16-B aligned,
+    and whose channel counts do not fill the wave's channel groups.  Also checks nothing is written past the tensor."""
+    gen = g(31 * h + w + cin)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    yr = F.conv2d(x, wt, b, padding=1)
+    if relu:
+        yr = F.relu(yr)
+    wp = ops.conv3x3_pack(wt.to(DEV), 0)
+    guard = torch.full((n * cout * h * w + 64,), 7.5, device=DEV)
+    yd = guard[:n * cout * h * w].view(n, cout, h, w)
+    from probabilisticteacher_amd import _lib
+    xd, bd = x.to(DEV), b.to(DEV)
+    _lib.call("ptmi_conv3x3_fwd", ops._ptr(xd), ops._ptr(wp), ops._ptr(bd), None, ops._ptr(yd), n, cin, cout, h, w,
+              1 if relu else 0, ops._stream())
+    torch.cuda.synchronize()
+    close(yd, yr, 1e-5, 1e-5, "stem fwd")
+    assert (guard[n * cout * h * w:] == 7.5).all(), "stem wrote past the end of the output"
+
+
 # ------------------------------------------------------------------------------------------ batched matching / sampling
 def test_iou_match_batched_equals_per_image(ops):
     """ptmi_iou_match_batched (one launch pair per batch) against ptmi_iou_match image by image: indices, labels and
