@@ -60,6 +60,15 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws,
                        int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
+/* bf16-input / fp32-accumulate variants of the two calls above (SOLVER.AMP.ENABLED, pt/engine/trainer.py:98; BASELINE
+ * configs[4]).  Same arguments, same packed weights and workspace size; x / wp / dy are fp32 in memory and every operand
+ * element is rounded to bf16 (round-to-nearest-even) on its way into v_mfma_f32_32x32x16_bf16; accumulation, bias,
+ * epilogues, split-K reduction and outputs are fp32.  The 3-channel stem runs on the same MFMA kernel. */
+int ptmi_conv3x3_fwd_bf16(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                          float* y, int n, int cin, int cout, int h, int w, int epilogue,
+                          ptmi_stream_t s);
+int ptmi_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws,
+                            int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
 /* dz = dy * (y > 0), elementwise (ReLU backward; F.relu_ at vgg.py:67). In-place allowed. */
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s);
 
@@ -87,6 +96,13 @@ int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, i
                   int k, int lda, int ldb, int ldc, int ta, int tb, int bias_mode, int relu,
                   int accumulate, int batch, int64_t stride_a, int64_t stride_b,
                   int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s);
+/* Same contract, bf16-input / fp32-accumulate (SOLVER.AMP.ENABLED, pt/engine/trainer.py:98; BASELINE configs[4]): A and B
+ * are fp32 in memory, every operand element is rounded to bf16 (round-to-nearest-even) on its way into
+ * v_mfma_f32_32x32x16_bf16; products are exact in fp32 and accumulated in fp32; bias / ReLU / C stay fp32. */
+int ptmi_gemm_bf16(const float* a, const float* b, float* c, const float* bias, int m, int n,
+                   int k, int lda, int ldb, int ldc, int ta, int tb, int bias_mode, int relu,
+                   int accumulate, int batch, int64_t stride_a, int64_t stride_b,
+                   int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s);
 /* column sums: out[j] (+)= sum_i a[i][j]  (bias gradients), a is (rows, cols) row-major. */
 int ptmi_colsum(const float* a, float* out, int rows, int cols, int accumulate, ptmi_stream_t s);
 /* row sums over the inner dim: out[i] (+)= sum_j a[i][j] for each of `batch` slabs summed. */

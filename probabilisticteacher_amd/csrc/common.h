@@ -27,6 +27,7 @@ void ptmi_set_error(const char* fmt, ...);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ptmi_bf16x8 __attribute__((ext_vector_type(8)));
 
 // ---- buffer -> LDS DMA helpers (buffer_load_dword[x4] ... lds) ----------------------------------------------
 // Raw buffer resource over [base, base + bytes): lanes whose offset is >= bytes (e.g. 0xFFFFFFFF) are zero-filled
@@ -52,6 +53,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ptmi_rsrc(const void* base, un
 __device__ __forceinline__ void ptmi_bdma16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, float* lds_wave_base)
 {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (ptmi_lds_void_t*)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+
+// eight fp32 values -> the bf16x8 operand of v_mfma_f32_32x32x16_bf16 (v_cvt_pk_bf16_f32: round to nearest even)
+__device__ __forceinline__ ptmi_bf16x8 ptmi_pack_bf16x8(const float* f)
+{
+    ptmi_bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+    return v;
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

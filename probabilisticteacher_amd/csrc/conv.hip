@@ -52,7 +52,11 @@ __device__ __forceinline__ void* uniform_ptr(const void* p)
                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a));
 }
 
-template <int BM, int NWAVE>
+// BF = true: bf16-input / fp32-accumulate variant (SOLVER.AMP.ENABLED).  Same DMA pipeline and LDS layout (fp32 operands);
+// a lane rounds its operand elements to bf16 (v_cvt_pk_bf16_f32, RNE) between LDS and v_mfma_f32_32x32x16_bf16.  The
+// MFMA's 16 k values are (lane half h, element e) <-> (tap = 4t + e / 2, channel 2 (e % 2) + h) for MFMA t of a chunk:
+// taps 0-3, 4-7 and 8 (+ three zero taps) -- 3 MFMAs per accumulator tile and chunk instead of 18.
+template <int BM, int NWAVE, bool BF>
 __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
@@ -168,20 +172,44 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
             if (MODE == 0) continue;
             const float* wsl = lds + buf * STAGE + a_off;
             const float* psl = lds + buf * STAGE + b_off;
+            if constexpr (BF) {
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap % 3;
+                for (int t = 0; t < 3; ++t) {
+                    float a0[8], a1[8], b0[8], b1[8];
 #pragma unroll
-                for (int j = 0; j < CK / 2; ++j) {
-                    const float a0 = wsl[(tap * CK + 2 * j) * BM];
-                    const float a1 = wsl[(tap * CK + 2 * j) * BM + 32];
-                    const float b0 = psl[2 * j * PLANE + ky * PWB + kx];
-                    acc00 = mfma32(a0, b0, acc00);
-                    acc10 = mfma32(a1, b0, acc10);
+                    for (int e = 0; e < 8; ++e) {
+                        const int tap = 4 * t + (e >> 1), j = e & 1, ky = tap / 3, kx = tap % 3;
+                        const bool on = tap < 9;
+                        a0[e] = on ? wsl[(tap * CK + 2 * j) * BM] : 0.f;
+                        a1[e] = on ? wsl[(tap * CK + 2 * j) * BM + 32] : 0.f;
+                        b0[e] = on ? psl[2 * j * PLANE + ky * PWB + kx] : 0.f;
+                        b1[e] = (on && MODE == 2) ? psl[2 * j * PLANE + ky * PWB + kx + 8] : 0.f;
+                    }
+                    const ptmi_bf16x8 A0 = ptmi_pack_bf16x8(a0), A1 = ptmi_pack_bf16x8(a1), B0 = ptmi_pack_bf16x8(b0);
+                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc00, 0, 0, 0);
+                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc10, 0, 0, 0);
                     if (MODE == 2) {
-                        const float b1 = psl[2 * j * PLANE + ky * PWB + kx + 8];
-                        acc01 = mfma32(a0, b1, acc01);
-                        acc11 = mfma32(a1, b1, acc11);
+                        const ptmi_bf16x8 B1 = ptmi_pack_bf16x8(b1);
+                        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc01, 0, 0, 0);
+                        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc11, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+                    for (int j = 0; j < CK / 2; ++j) {
+                        const float a0 = wsl[(tap * CK + 2 * j) * BM];
+                        const float a1 = wsl[(tap * CK + 2 * j) * BM + 32];
+                        const float b0 = psl[2 * j * PLANE + ky * PWB + kx];
+                        acc00 = mfma32(a0, b0, acc00);
+                        acc10 = mfma32(a1, b0, acc10);
+                        if (MODE == 2) {
+                            const float b1 = psl[2 * j * PLANE + ky * PWB + kx + 8];
+                            acc01 = mfma32(a0, b1, acc01);
+                            acc11 = mfma32(a1, b1, acc11);
+                        }
                     }
                 }
             }
@@ -469,7 +497,9 @@ __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_b_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
 }
 
-template <int G>
+// BF = true (bf16-input variant): the eight pixels 16h + 8hf + 0..7 a lane holds are exactly the eight k values of its
+// half in v_mfma_f32_32x32x16_bf16 -- one MFMA per (hf, tap) instead of eight.
+template <int G, bool BF>
 __device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, const float* __restrict__ bl,
                                                 f32x16 (&acc)[G == 0 ? 5 : 4])
 {
@@ -496,12 +526,22 @@ __device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, co
                 v[1 + 4 * t] = q[0]; v[2 + 4 * t] = q[1]; v[3 + 4 * t] = q[2]; v[4 + 4 * t] = q[3];
             }
             v[9] = *(const volatile lds_f32_t*)(br + 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            if constexpr (BF) {
+                const ptmi_bf16x8 A = ptmi_pack_bf16x8(a);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int tap = ky * 3 + kx;
-                    if (tap >= TAP0 && tap < TAP1) acc[tap - TAP0] = mfma32(a[j], v[j + kx], acc[tap - TAP0]);
+                    if (tap >= TAP0 && tap < TAP1)
+                        acc[tap - TAP0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, ptmi_pack_bf16x8(v + kx), acc[tap - TAP0], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int tap = ky * 3 + kx;
+                        if (tap >= TAP0 && tap < TAP1) acc[tap - TAP0] = mfma32(a[j], v[j + kx], acc[tap - TAP0]);
+                    }
                 }
             }
         }
@@ -533,7 +573,7 @@ __device__ __forceinline__ void wgrad_stage_edge(const float* __restrict__ al0, 
 
 // one tap group's whole life: descriptors, stage loop, partial store.  Instantiated twice and selected by a
 // wave-uniform branch so that each group gets its own register allocation (5 or 4 accumulator tiles).
-template <int G, bool EDGE>
+template <int G, bool EDGE, bool BF>
 __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restrict__ x, const float* __restrict__ dy,
                                                float* __restrict__ partial, int N, int Cin, int Cout, int H, int W,
                                                int tilesX, int tilesY, int ciTiles, int S, int txb, int bid, int wave,
@@ -655,7 +695,7 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
         __syncthreads();
         if (tile + S < nTiles) issue(nn, nty, ntx, buf ^ 1);
         if (!EDGE)
-            wgrad_stage_buf<G>(lds + buf * WB_STAGE + a_off, lds + buf * WB_STAGE + b_off, acc);
+            wgrad_stage_buf<G, BF>(lds + buf * WB_STAGE + a_off, lds + buf * WB_STAGE + b_off, acc);
         else
             wgrad_stage_edge<G>(lds + buf * WB_STAGE + a_off - h16 + (lane >> 5), lds + buf * WB_STAGE + b_off - h16 + (lane >> 5),
                                 acc, (wv + 1) >> 1);
@@ -679,6 +719,7 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
 // workgroups nMain .. nMain+nEdge-1 walk that column alone with the interleaved short stage (split-K factor Se, partials
 // after the main ones in the workspace).  The short-stage workgroups are latency-bound (few MFMAs per DMA round trip);
 // dispatched after the main ones they fill the tail of the launch instead of costing a launch of their own.
+template <bool BF>
 __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_buf_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
     int Cout, int H, int W, int tilesXm, int tilesY, int coTiles, int ciTiles, int S, int nMain, int Se)
@@ -688,12 +729,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_buf_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bid = blockIdx.x;
     if (bid < nMain) {
-        if (wave < 4) wgrad_buf_body<0, false>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
-        else wgrad_buf_body<1, false>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
-    } else {
+        if (wave < 4) wgrad_buf_body<0, false, BF>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
+        else wgrad_buf_body<1, false, BF>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
+    } else if constexpr (!BF) {          // (the bf16 variant is launched without right-edge workgroups: Se = 0)
         float* pe = partial + (size_t)S * 9 * Cout * Cin;
-        if (wave < 4) wgrad_buf_body<0, true>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
-        else wgrad_buf_body<1, true>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
+        if (wave < 4) wgrad_buf_body<0, true, false>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
+        else wgrad_buf_body<1, true, false>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
     }
 }
 
@@ -718,22 +759,25 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
 // stage 2 = fixed-order sum over the slots (deterministic).
 constexpr int BG_SLOTS = 16;
 
+// BF: the elements are rounded to bf16 first (the bf16 variant sums the same rounded gradient its MFMAs consume)
+template <bool BF>
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part,
                                                                 int N, int C, int HW)
 {
     __shared__ float sm[4];
+    auto rd = [](float v) { return BF ? (float)(__bf16)v : v; };
     const int c = blockIdx.x, slot = blockIdx.y;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int n = slot; n < N; n += BG_SLOTS) {
         const float* p = dy + ((size_t)n * C + c) * HW;
         int i = threadIdx.x;
         for (; i + 768 < HW; i += 1024) {
-            a0 += p[i];
-            a1 += p[i + 256];
-            a2 += p[i + 512];
-            a3 += p[i + 768];
+            a0 += rd(p[i]);
+            a1 += rd(p[i + 256]);
+            a2 += rd(p[i + 512]);
+            a3 += rd(p[i + 768]);
         }
-        for (; i < HW; i += 256) a0 += p[i];
+        for (; i < HW; i += 256) a0 += rd(p[i]);
     }
     const float t = block_sum_256((a0 + a1) + (a2 + a3), sm);
     if (threadIdx.x == 0) part[c * BG_SLOTS + slot] = t;
@@ -795,6 +839,94 @@ int wgrad_splits(int n, int cin, int cout, int h, int w)
     return S;
 }
 
+int conv3x3_fwd_impl(bool bf, const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
+                     int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
+    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_fwd: bad epilogue %d", epilogue);
+    // the buffer-DMA kernels address one image through 32-bit byte offsets and a 16-bit grid dimension: reject (loudly)
+    // anything larger -- 1333x800 VGG maps use at most 273 MB per image
+    PTMI_CHECK_ARG((int64_t)cin * h * w * 4 < (1ll << 32) && ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) &&
+                   (int64_t)n * cdiv(h, 4) < 65536, "conv3x3_fwd: image too large for 32-bit buffer offsets "
+                   "(n=%d cin=%d cout=%d h=%d w=%d)", n, cin, cout, h, w);
+    PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
+    const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
+    // 8-wave workgroups (8 rows x 32 cols per 128 channels) share one weight slab among twice the pixels:
+    // A/B +3.5 % at 400x666, -3 .. -14 % on the small maps
+    const bool use8 = BM == 128 && cin > 4 && h >= 200;
+    const int TH = (BM == 128 && !use8) ? 4 : 8;
+    const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
+    hipStream_t st = (hipStream_t)s;
+    // 3-channel stem: K = 27 is too short to amortise the LDS pipeline's prologue and the layer is HBM-write bound
+    // (the bf16 variant has no VALU stem: its 3-channel layer runs on the MFMA kernel, one zero-padded 4-channel chunk)
+    if (!bf && BM == 64 && cin <= 4 && epilogue <= 1) {
+        // (-ffp-contract=off: fmaf() is explicit in the kernel; K = 27 keeps the rounding difference at the 1e-7 level)
+        PTMI_CHECK_ARG(n < 65536 && (int64_t)h * w < (int64_t)1 << 30, "conv3x3_fwd(stem): grid too large");
+        const dim3 gs((unsigned)cdiv(h * w, 64 * STEM_PX), (unsigned)n);
+        if (cin <= 3)
+            hipLaunchKernelGGL(conv3x3_stem_kernel<3>, gs, dim3(256), 0, st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
+        else
+            hipLaunchKernelGGL(conv3x3_stem_kernel<4>, gs, dim3(256), 0, st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
+        PTMI_LAUNCH_CHECK("conv3x3_fwd(stem)");
+        return 0;
+    }
+    const dim3 grid3((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
+#define LBUF(BM_, NW_)                                                                                                    \
+    do {                                                                                                                  \
+        if (bf)                                                                                                           \
+            hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_, true>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, y, \
+                               n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue);                           \
+        else                                                                                                              \
+            hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_, false>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, y, \
+                               n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue);                           \
+    } while (0)
+    if (BM == 128 && use8) LBUF(128, 8);
+    else if (BM == 128) LBUF(128, 4);
+    else LBUF(64, 4);
+#undef LBUF
+    PTMI_LAUNCH_CHECK("conv3x3_fwd(buf)");
+    return 0;
+}
+
+int conv3x3_wgrad_impl(bool bf, const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
+                       int cout, int h, int w, int accumulate, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0, "conv3x3_wgrad: bad args");
+    PTMI_CHECK_ARG((int64_t)128 * h * w < (1 << 28), "conv3x3_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
+    const int tilesX = cdiv(w, TW), tilesY = h;
+    const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
+    int S = wgrad_splits(n, cin, cout, h, w);
+    const int Se = bf ? 0 : wgrad_edge_splits(n, cin, cout, h, w);
+    const int64_t bg_off = (int64_t)(S + wgrad_edge_splits(n, cin, cout, h, w)) * 9 * cout * cin;   // as ptmi_conv3x3_wgrad_ws_floats lays it out
+    hipStream_t st = (hipStream_t)s;
+    // Se > 0: the right-edge tile column has few valid pixels and gets the short interleaved stage
+    const int nMain = coTiles * ciTiles * S, nEdge = coTiles * ciTiles * Se;
+    if (bf)
+        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<true>, dim3(nMain), dim3(512), 0, st, x, dy, ws, n, cin, cout, h, w,
+                           tilesX, tilesY, coTiles, ciTiles, S, nMain, 0);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(nMain + nEdge), dim3(512), 0, st, x, dy, ws, n, cin, cout,
+                           h, w, Se > 0 ? tilesX - 1 : tilesX, tilesY, coTiles, ciTiles, S, nMain, Se);
+    S += Se;
+    PTMI_LAUNCH_CHECK("conv3x3_wgrad");
+    const int64_t total = (int64_t)cout * cin * 9;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw,
+                       cout, cin, S, accumulate);
+    PTMI_LAUNCH_CHECK("conv3x3_wgrad_reduce");
+    if (db) {
+        float* part = ws + bg_off + 64;
+        if (bf)
+            hipLaunchKernelGGL(bias_grad_partial_kernel<true>, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
+        else
+            hipLaunchKernelGGL(bias_grad_partial_kernel<false>, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
+        PTMI_LAUNCH_CHECK("conv3x3_bias_grad_partial");
+        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, part, db, cout, accumulate);
+        PTMI_LAUNCH_CHECK("conv3x3_bias_grad_final");
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -826,43 +958,13 @@ int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, 
 int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
                      float* y, int n, int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
-    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_fwd: bad epilogue %d", epilogue);
-    // the buffer-DMA kernels address one image through 32-bit byte offsets and a 16-bit grid dimension: reject (loudly)
-    // anything larger -- 1333x800 VGG maps use at most 273 MB per image
-    PTMI_CHECK_ARG((int64_t)cin * h * w * 4 < (1ll << 32) && ((int64_t)cout + 128) * h * w * 4 < (1ll << 32) &&
-                   (int64_t)n * cdiv(h, 4) < 65536, "conv3x3_fwd: image too large for 32-bit buffer offsets "
-                   "(n=%d cin=%d cout=%d h=%d w=%d)", n, cin, cout, h, w);
-    PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_fwd: bias required for epilogue %d", epilogue);
-    PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_fwd: mask_ref required for epilogue 3");
-    const int BM = ptmi_conv3x3_bm(cout), CK = ptmi_conv3x3_ck(cin);
-    // 8-wave workgroups (8 rows x 32 cols per 128 channels) share one weight slab among twice the pixels:
-    // A/B +3.5 % at 400x666, -3 .. -14 % on the small maps
-    const bool use8 = BM == 128 && cin > 4 && h >= 200;
-    const int TH = (BM == 128 && !use8) ? 4 : 8;
-    const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
-    hipStream_t st = (hipStream_t)s;
-    // 3-channel stem: K = 27 is too short to amortise the LDS pipeline's prologue and the layer is HBM-write bound
-    if (BM == 64 && cin <= 4 && epilogue <= 1) {
-        // (-ffp-contract=off: fmaf() is explicit in the kernel; K = 27 keeps the rounding difference at the 1e-7 level)
-        PTMI_CHECK_ARG(n < 65536 && (int64_t)h * w < (int64_t)1 << 30, "conv3x3_fwd(stem): grid too large");
-        const dim3 gs((unsigned)cdiv(h * w, 64 * STEM_PX), (unsigned)n);
-        if (cin <= 3)
-            hipLaunchKernelGGL(conv3x3_stem_kernel<3>, gs, dim3(256), 0, st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
-        else
-            hipLaunchKernelGGL(conv3x3_stem_kernel<4>, gs, dim3(256), 0, st, x, wp, bias, y, cin, cout, h, w, coTiles, epilogue == 1);
-        PTMI_LAUNCH_CHECK("conv3x3_fwd(stem)");
-        return 0;
-    }
-    const dim3 grid3((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
-#define LBUF(BM_, NW_) hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, \
-                                          y, n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue)
-    if (BM == 128 && use8) LBUF(128, 8);
-    else if (BM == 128) LBUF(128, 4);
-    else LBUF(64, 4);
-#undef LBUF
-    PTMI_LAUNCH_CHECK("conv3x3_fwd(buf)");
-    return 0;
+    return conv3x3_fwd_impl(false, x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue, s);
+}
+
+int ptmi_conv3x3_fwd_bf16(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                          float* y, int n, int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
+{
+    return conv3x3_fwd_impl(true, x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue, s);
 }
 
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
@@ -875,32 +977,13 @@ int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
                        int cout, int h, int w, int accumulate, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0, "conv3x3_wgrad: bad args");
-    PTMI_CHECK_ARG((int64_t)128 * h * w < (1 << 28), "conv3x3_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
-    const int tilesX = cdiv(w, TW), tilesY = h;
-    const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
-    int S = wgrad_splits(n, cin, cout, h, w);
-    const int Se = wgrad_edge_splits(n, cin, cout, h, w);
-    const int64_t bg_off = (int64_t)(S + Se) * 9 * cout * cin;
-    hipStream_t st = (hipStream_t)s;
-    // Se > 0: the right-edge tile column has few valid pixels and gets the short interleaved stage
-    const int nMain = coTiles * ciTiles * S, nEdge = coTiles * ciTiles * Se;
-    hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel, dim3(nMain + nEdge), dim3(512), 0, st, x, dy, ws, n, cin, cout, h, w,
-                       Se > 0 ? tilesX - 1 : tilesX, tilesY, coTiles, ciTiles, S, nMain, Se);
-    S += Se;
-    PTMI_LAUNCH_CHECK("conv3x3_wgrad");
-    const int64_t total = (int64_t)cout * cin * 9;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, dw,
-                       cout, cin, S, accumulate);
-    PTMI_LAUNCH_CHECK("conv3x3_wgrad_reduce");
-    if (db) {
-        float* part = ws + bg_off + 64;
-        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
-        PTMI_LAUNCH_CHECK("conv3x3_bias_grad_partial");
-        hipLaunchKernelGGL(bias_grad_final_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, part, db, cout, accumulate);
-        PTMI_LAUNCH_CHECK("conv3x3_bias_grad_final");
-    }
-    return 0;
+    return conv3x3_wgrad_impl(false, x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, s);
+}
+
+int ptmi_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
+                            int cout, int h, int w, int accumulate, ptmi_stream_t s)
+{
+    return conv3x3_wgrad_impl(true, x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, s);
 }
 
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s)

@@ -17,6 +17,12 @@ constexpr int BMN = 128;
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
+// bf16-input / fp32-accumulate variant (SOLVER.AMP.ENABLED, BASELINE configs[4]): the operands stay fp32 in HBM and
+// LDS; a lane rounds its eight k values to bf16 (v_cvt_pk_bf16_f32, round-to-nearest-even) on the way from LDS to the
+// MFMA: v_mfma_f32_32x32x16_bf16, lane half h element j <-> the same k for A and B.
+__device__ __forceinline__ f32x16 mfma16bf(ptmi_bf16x8 a, ptmi_bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 // ------------------------------------------------------------------------------------ buffer-DMA pipeline
 // Default kernel.  Same 128x128x32 tiling and wave layout, but the operand tiles go global -> LDS directly with
@@ -133,7 +139,7 @@ struct OpTile {
     }
 };
 
-template <bool AK, bool BKF, int BKT>
+template <bool AK, bool BKF, int BKT, bool BF>
 __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_buf_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
     const float* __restrict__ bias, int M, int N, int K, int lda, int ldb, int ldc, int bias_mode, int relu,
@@ -193,12 +199,24 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void gemm_buf_kernel(
         OpTile<AK, BKT>::frag(As, wm * 64 + 32, lane, a1);
         OpTile<BKF, BKT>::frag(Bs, wn * 64, lane, b0);
         OpTile<BKF, BKT>::frag(Bs, wn * 64 + 32, lane, b1);
+        if constexpr (BF) {
 #pragma unroll
-        for (int j = 0; j < HK; ++j) {
-            acc00 = mfma32(a0[j], b0[j], acc00);
-            acc01 = mfma32(a0[j], b1[j], acc01);
-            acc10 = mfma32(a1[j], b0[j], acc10);
-            acc11 = mfma32(a1[j], b1[j], acc11);
+            for (int t = 0; t < HK / 8; ++t) {
+                const ptmi_bf16x8 A0 = ptmi_pack_bf16x8(a0 + 8 * t), A1 = ptmi_pack_bf16x8(a1 + 8 * t);
+                const ptmi_bf16x8 B0 = ptmi_pack_bf16x8(b0 + 8 * t), B1 = ptmi_pack_bf16x8(b1 + 8 * t);
+                acc00 = mfma16bf(A0, B0, acc00);
+                acc01 = mfma16bf(A0, B1, acc01);
+                acc10 = mfma16bf(A1, B0, acc10);
+                acc11 = mfma16bf(A1, B1, acc11);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < HK; ++j) {
+                acc00 = mfma32(a0[j], b0[j], acc00);
+                acc01 = mfma32(a0[j], b1[j], acc01);
+                acc10 = mfma32(a1[j], b0[j], acc10);
+                acc11 = mfma32(a1[j], b1[j], acc11);
+            }
         }
     }
     // Epilogue.  C/D layout: col = lane&31 (n), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (m).  Every access is a raw-buffer
@@ -330,19 +348,9 @@ __global__ __launch_bounds__(256) void rowsum_batched_kernel(const float* __rest
     if (threadIdx.x == 0) out[r] = accumulate ? out[r] + t : t;
 }
 
-}  // namespace
-
-extern "C" {
-
-int64_t ptmi_gemm_ws_floats(int m, int n, int k, int batch)
-{
-    const int S = pick_splitk(m, n, k, batch);
-    return S > 1 ? (int64_t)S * m * n : 0;
-}
-
-int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, int m, int n, int k, int lda,
-                  int ldb, int ldc, int ta, int tb, int bias_mode, int relu, int accumulate, int batch,
-                  int64_t stride_a, int64_t stride_b, int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s)
+int gemm_impl(bool bf, const float* a, const float* b, float* c, const float* bias, int m, int n, int k, int lda,
+              int ldb, int ldc, int ta, int tb, int bias_mode, int relu, int accumulate, int batch,
+              int64_t stride_a, int64_t stride_b, int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(a && b && c && m >= 0 && n >= 0 && k > 0 && batch > 0, "gemm_f32: bad args");
     PTMI_CHECK_ARG(bias_mode == 0 || bias, "gemm_f32: bias missing");
@@ -361,9 +369,17 @@ int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, i
     const int chunk = S > 1 ? cdiv(cdiv(k, S), 32) * 32 : k;
     float* partial = S > 1 ? ws : nullptr;
     dim3 grid((unsigned)(tilesM * tilesN), (unsigned)batch, (unsigned)S), block(256);
-#define L(AK_, BK_)                                                                                               \
-    hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_, 32>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, ldb, ldc, \
-                       bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN, chunk, partial)
+#define L(AK_, BK_)                                                                                                    \
+    do {                                                                                                               \
+        if (bf)                                                                                                        \
+            hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_, 32, true>), grid, block, 0, st, a, b, c, bias, m, n, k, lda,  \
+                               ldb, ldc, bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN, chunk,     \
+                               partial);                                                                               \
+        else                                                                                                           \
+            hipLaunchKernelGGL((gemm_buf_kernel<AK_, BK_, 32, false>), grid, block, 0, st, a, b, c, bias, m, n, k, lda, \
+                               ldb, ldc, bias_mode, relu, accumulate, stride_a, stride_b, stride_c, tilesN, chunk,     \
+                               partial);                                                                               \
+    } while (0)
     if (ak && bk) L(true, true);
     else if (ak && !bk) L(true, false);
     else if (!ak && bk) L(false, true);
@@ -378,6 +394,32 @@ int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, i
         PTMI_LAUNCH_CHECK("gemm_splitk_reduce");
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ptmi_gemm_ws_floats(int m, int n, int k, int batch)
+{
+    const int S = pick_splitk(m, n, k, batch);
+    return S > 1 ? (int64_t)S * m * n : 0;
+}
+
+int ptmi_gemm_f32(const float* a, const float* b, float* c, const float* bias, int m, int n, int k, int lda,
+                  int ldb, int ldc, int ta, int tb, int bias_mode, int relu, int accumulate, int batch,
+                  int64_t stride_a, int64_t stride_b, int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s)
+{
+    return gemm_impl(false, a, b, c, bias, m, n, k, lda, ldb, ldc, ta, tb, bias_mode, relu, accumulate, batch, stride_a,
+                     stride_b, stride_c, ws, ws_floats, s);
+}
+
+int ptmi_gemm_bf16(const float* a, const float* b, float* c, const float* bias, int m, int n, int k, int lda,
+                   int ldb, int ldc, int ta, int tb, int bias_mode, int relu, int accumulate, int batch,
+                   int64_t stride_a, int64_t stride_b, int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s)
+{
+    return gemm_impl(true, a, b, c, bias, m, n, k, lda, ldb, ldc, ta, tb, bias_mode, relu, accumulate, batch, stride_a,
+                     stride_b, stride_c, ws, ws_floats, s);
 }
 
 int ptmi_colsum(const float* a, float* out, int rows, int cols, int accumulate, ptmi_stream_t s)

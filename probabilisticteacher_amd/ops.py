@@ -100,28 +100,49 @@ class _prof:
         return False
 
 
-# ============================================================================ operand rounding (SOLVER.AMP.ENABLED)
+# ============================================================================ bf16 operands (SOLVER.AMP.ENABLED)
 # BASELINE.json configs[4] ("mixed bf16 convs + fp32 loss"; the reference's AMP flag, pt/engine/trainer.py:98): the
 # conv / FC GEMM operands -- activations, weights and, in backward, the incoming gradients -- are rounded to bf16
 # (round-to-nearest-even), products are accumulated in fp32 and results stay fp32; losses, box codec, NMS, optimiser
-# are untouched.  This is the NUMERICS of a bf16-input / fp32-accumulate MFMA path (a bf16 x bf16 product is exact in
-# fp32), executed on the fp32 kernels: it defines and tests the behaviour (loss-curve parity against the fp32 run,
-# tools/loss_curve_parity.py) ahead of native v_mfma_f32_32x32x16_bf16 kernels, and brings NO speed-up.  Never enabled
-# by bench.py (the headline metric is fp32).
+# are untouched.  Two ways to run it:
+#   "bf16"          the native kernels (ptmi_*_bf16: v_mfma_f32_32x32x16_bf16, operands rounded on their way from LDS
+#                   into the MFMA); tensors stay fp32 in HBM.  This is what SOLVER.AMP.ENABLED selects.
+#   "bf16_emulate"  the same numerics on the fp32 kernels: operands are rounded by a separate pass (x.to(bf16).to(f32))
+#                   and multiplied by v_mfma_f32_32x32x2_f32 -- a bf16 x bf16 product is exact in fp32, so the two
+#                   modes differ only in summation order.  The native kernels are tested against this mode.
+# Never enabled by bench.py (the headline metric is fp32).
 _OPERAND_ROUNDING = None
 
 
 def set_operand_rounding(mode: Optional[str]) -> None:
     global _OPERAND_ROUNDING
-    if mode not in (None, "bf16"):
+    if mode not in (None, "bf16", "bf16_emulate"):
         raise ValueError(f"unknown operand rounding {mode!r}")
     _OPERAND_ROUNDING = mode
 
 
 def _rnd(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    if _OPERAND_ROUNDING is None or t is None:
+    if _OPERAND_ROUNDING != "bf16_emulate" or t is None:
         return t
     return t.to(torch.bfloat16).to(F32)
+
+
+def _rnd_grad(t: torch.Tensor) -> torch.Tensor:
+    """Incoming gradient of a Linear / 1x1 conv: rounded by a tensor pass in BOTH bf16 modes -- besides the GEMMs (which
+    would round it themselves in native mode) it feeds the bias-gradient reductions, which must see the same values."""
+    return t if _OPERAND_ROUNDING is None else t.to(torch.bfloat16).to(F32)
+
+
+def _native_bf16() -> bool:
+    return _OPERAND_ROUNDING == "bf16"
+
+
+def _conv_fwd_sym() -> str:
+    return "ptmi_conv3x3_fwd_bf16" if _native_bf16() else "ptmi_conv3x3_fwd"
+
+
+def _conv_wgrad_sym() -> str:
+    return "ptmi_conv3x3_wgrad_bf16" if _native_bf16() else "ptmi_conv3x3_wgrad"
 
 
 # ============================================================================ conv 3x3
@@ -141,7 +162,7 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
     nbytes = 4.0 * (n * h * w * (cin + cout * (2 if epilogue == 3 else 1)) + 9 * cin * cout)
     with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, nbytes):
-        _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
+        _lib.call(_conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
                   epilogue, _stream())
     return y
 
@@ -154,7 +175,7 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0)
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
     with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, 4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout)):
-        _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None, _ptr(y), n, cin, cout, h,
+        _lib.call(_conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None, _ptr(y), n, cin, cout, h,
                   w, 4, _stream())
     return y
 
@@ -196,7 +217,7 @@ class _Conv3x3(torch.autograd.Function):
             nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w)
             ws = _ws("wgrad", nws * 4, x.device)
             with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
-                _lib.call("ptmi_conv3x3_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
+                _lib.call(_conv_wgrad_sym(), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
                           _stream())
         if ctx.needs_input_grad[0]:
             wpd = conv3x3_pack(weight, 1)
@@ -285,7 +306,7 @@ class _VGGBlock(torch.autograd.Function):
                 nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, wd)
                 wsb = _ws("wgrad", nws * 4, xin.device)
                 with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * wd * n):
-                    _lib.call("ptmi_conv3x3_wgrad", _ptr(xin), _ptr(dz), _ptr(dw), _ptr(db), _ptr(wsb), n, cin, cout, h,
+                    _lib.call(_conv_wgrad_sym(), _ptr(xin), _ptr(dz), _ptr(dw), _ptr(db), _ptr(wsb), n, cin, cout, h,
                               wd, 0, _stream())
                 grads[2 * (j - 1)], grads[2 * (j - 1) + 1] = dw, db
             if j > 1:
@@ -297,7 +318,7 @@ class _VGGBlock(torch.autograd.Function):
 
 def vgg_block(x, pool: bool, params):
     """params = [w1, b1, w2, b2, ...]."""
-    if _OPERAND_ROUNDING is not None:          # layer by layer: every conv rounds its own operands
+    if _OPERAND_ROUNDING == "bf16_emulate":    # layer by layer: every conv rounds its own operands
         for j in range(len(params) // 2):
             x = conv3x3(x, params[2 * j], params[2 * j + 1], True)
         return maxpool2x2(x) if pool else x
@@ -317,7 +338,7 @@ def gemm(a, b, m, n, k, lda, ldb, ta, tb, bias=None, bias_mode=0, relu=False, ou
     nws = _lib.load().ptmi_gemm_ws_floats(m, n, k, batch)                   # > 0: this shape runs split-K
     ws = _ws("gemm", nws * 4, a.device) if nws else None
     with _prof("gemm_f32", 2.0 * m * n * k * batch):
-        _lib.call("ptmi_gemm_f32", _ptr(a), _ptr(b), _ptr(out), _ptr(bias), m, n, k, lda, ldb, ldc, ta, tb, bias_mode,
+        _lib.call("ptmi_gemm_bf16" if _native_bf16() else "ptmi_gemm_f32", _ptr(a), _ptr(b), _ptr(out), _ptr(bias), m, n, k, lda, ldb, ldc, ta, tb, bias_mode,
                   int(relu), int(accumulate), batch, stride_a, stride_b, stride_c, _ptr(ws), int(nws), _stream())
     return out
 
@@ -350,7 +371,7 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dy = _chk(dy.contiguous())
-        dz = _rnd(relu_bwd(dy, y) if ctx.relu else dy)
+        dz = _rnd_grad(relu_bwd(dy, y) if ctx.relu else dy)
         r, k = x.shape
         nout = weight.shape[0]
         dx = dw = db = None
@@ -390,7 +411,7 @@ class _Conv1x1(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w2 = ctx.saved_tensors
-        dy = _chk(_rnd(dy).contiguous())
+        dy = _chk(_rnd_grad(dy).contiguous())
         n, ci, h, w = x.shape
         co, hw = w2.shape[0], h * w
         dx = dw = db = None

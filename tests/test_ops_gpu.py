@@ -760,7 +760,160 @@ def test_sample_by_keys_equals_reference_subsample_labels(ops):
         assert torch.equal(fg[i, :cnt[i][0]].cpu(), rf) and torch.equal(bg[i, :cnt[i][1]].cpu(), rb), i
 
 
-def test_bf16_operand_rounding_mode(ops):
+@pytest.mark.parametrize("m,n,k,ta,tb,bias_mode,relu", [
+    (70, 50, 300, 0, 1, 2, True),          # Linear forward (x (R,K), W (N,K))
+    (130, 257, 96, 0, 0, 0, False),        # Linear dX
+    (200, 131, 515, 1, 0, 0, False),       # Linear dW (both operands mn-fast), K % 16 != 0
+    (64, 300, 45, 1, 1, 1, False),         # the fourth layout, K < 64 with a ragged tail
+    (1024, 256, 4096, 1, 0, 0, False),     # long K, few tiles: the split-K path
+    (33, 20, 7, 0, 1, 2, False),           # K smaller than one MFMA step
+])
+def test_gemm_bf16_native(ops, m, n, k, ta, tb, bias_mode, relu):
+    """ptmi_gemm_bf16 (v_mfma_f32_32x32x16_bf16, operands rounded between LDS and the MFMA) against the fp32 product of
+    the bf16-rounded operands computed in float64: every layout, ragged M / N / K, bias / ReLU epilogues, split-K."""
+    gen = g(m + n + k)
+    A = torch.randn((k, m) if ta else (m, k), generator=gen)
+    B = torch.randn((n, k) if tb else (k, n), generator=gen)
+    bias = torch.randn(m if bias_mode == 1 else n, generator=gen) if bias_mode else None
+    rb = lambda t: t.to(torch.bfloat16).double()
+    ref = (rb(A).t() if ta else rb(A)) @ (rb(B).t() if tb else rb(B))
+    if bias_mode == 1:
+        ref = ref + bias.double()[:, None]
+    elif bias_mode == 2:
+        ref = ref + bias.double()[None, :]
+    if relu:
+        ref = ref.clamp_min(0)
+    ops.set_operand_rounding("bf16")
+    try:
+        out = ops.gemm(A.to(DEV), B.to(DEV), m, n, k, A.shape[1], B.shape[1], ta, tb,
+                       bias=None if bias is None else bias.to(DEV), bias_mode=bias_mode, relu=relu)
+        out2 = ops.gemm(A.to(DEV), B.to(DEV), m, n, k, A.shape[1], B.shape[1], ta, tb,
+                        bias=None if bias is None else bias.to(DEV), bias_mode=bias_mode, relu=relu)
+    finally:
+        ops.set_operand_rounding(None)
+    close(out, ref.float(), 1e-5, 4e-6 * math.sqrt(k) + 1e-5, "bf16 gemm")      # fp32 accumulation of k unit-scale products
+    assert torch.equal(out, out2), "bf16 gemm is not reproducible run to run"
+    f32 = ops.gemm(A.to(DEV), B.to(DEV), m, n, k, A.shape[1], B.shape[1], ta, tb,
+                   bias=None if bias is None else bias.to(DEV), bias_mode=bias_mode, relu=relu)
+    if k >= 64:
+        assert float((f32 - out).abs().max()) > 1e-3, "the bf16 entry point did not round its operands"
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,relu", [
+    (2, 3, 64, 37, 45, True),        # the stem layer: MFMA kernel with one zero-padded 4-channel chunk
+    (1, 64, 64, 24, 40, True),       # BM = 64
+    (2, 64, 128, 19, 35, False),     # BM = 128, 4 waves
+    (1, 32, 128, 204, 36, True),     # H >= 200: the 8-wave variant
+    (1, 20, 70, 11, 17, True),       # ragged channel counts (K tail chunk, partial channel tile)
+    (1, 256, 512, 9, 83, True),      # W = 83 as in the 1333x800 block5 map
+    (2, 32, 128, 3, 333, False),     # right-edge tiles straddling the image edge; wgrad edge column in the main stage
+    (1, 40, 130, 1, 70, True),       # a single row
+    (3, 32, 64, 4, 3, True),         # narrower than one 16-B piece
+])
+def test_conv3x3_bf16_native(ops, n, cin, cout, h, w, relu):
+    """ptmi_conv3x3_fwd_bf16 / ptmi_conv3x3_wgrad_bf16 (v_mfma_f32_32x32x16_bf16; operands rounded between LDS and the
+    MFMA) through forward, dgrad, wgrad and bias gradient against torch CPU fp32 on bf16-rounded operands (a bf16 x bf16
+    product is exact in fp32, so only the summation order differs)."""
+    gen = g(n * 1000 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    xr, wr, br = _rb(x).requires_grad_(), _rb(wt).requires_grad_(), b.clone().requires_grad_()
+    zr = F.conv2d(xr, wr, br, padding=1)
+    yr = F.relu(zr) if relu else zr
+    gy = torch.randn(yr.shape, generator=gen)
+    # the gradient that reaches the convolution (after the ReLU mask) is what gets rounded
+    gz = _rb(gy * (zr.detach() > 0)) if relu else _rb(gy)
+    zr.backward(gz)
+    ops.set_operand_rounding("bf16")
+    try:
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, wt, b))
+        yd = ops.conv3x3(xd, wd, bd, relu)
+        yd.backward(gy.to(DEV))
+    finally:
+        ops.set_operand_rounding(None)
+    close(yd, yr, 1e-4, 1e-4, "bf16 conv fwd")
+    # ReLU-mask flips where the pre-activation is within rounding of 0 change which gradient elements exist
+    stable = (zr.detach().abs() > 1e-4) if relu else torch.ones_like(zr, dtype=torch.bool)
+    if bool(stable.all()):
+        close(xd.grad, xr.grad, 1e-4, 2e-4, "bf16 conv dgrad")
+        close(wd.grad, wr.grad, 2e-4, 1e-3, "bf16 conv wgrad")
+        close(bd.grad, br.grad, 1e-4, 1e-3, "bf16 conv bias grad")
+    else:
+        assert float(stable.float().mean()) > 0.999
+
+
+@pytest.mark.parametrize("pool", [False, True])
+def test_vgg_block_bf16_native(ops, pool):
+    """The fused VGG block (epilogues 1 / 3, pool backward) on the bf16 kernels against the same block run layer by layer
+    in "bf16_emulate" mode (separate rounding passes + the fp32 kernels), and the inference-only fused conv+ReLU+pool."""
+    gen = g(197)
+    x = torch.randn(2, 16, 22, 37, generator=gen)
+    ws = [torch.randn(24, 16, 3, 3, generator=gen) * 0.1, torch.randn(24, 24, 3, 3, generator=gen) * 0.08,
+          torch.randn(32, 24, 3, 3, generator=gen) * 0.08]
+    bs = [torch.randn(c, generator=gen) * 0.1 for c in (24, 24, 32)]
+    gy = None
+    res = {}
+    for mode in ("bf16_emulate", "bf16"):
+        ops.set_operand_rounding(mode)
+        try:
+            xd = x.to(DEV).requires_grad_()
+            wd = [t.to(DEV).requires_grad_() for t in ws]
+            bd = [t.to(DEV).requires_grad_() for t in bs]
+            yd = ops.vgg_block(xd, pool, [t for pair in zip(wd, bd) for t in pair])
+            if gy is None:
+                gy = torch.randn(yd.shape, generator=gen).to(DEV)
+            yd.backward(gy)
+            fused = ops.conv3x3_relu_pool_nograd(x.to(DEV), ws[0].to(DEV), bs[0].to(DEV))
+        finally:
+            ops.set_operand_rounding(None)
+        res[mode] = (yd.detach(), xd.grad, [t.grad for t in wd], [t.grad for t in bd], fused)
+    e, nat = res["bf16_emulate"], res["bf16"]
+    close(nat[0], e[0], 1e-4, 1e-4, "block fwd")
+    close(nat[4], e[4], 1e-4, 1e-4, "fused conv+relu+pool")
+    close(nat[1], e[1], 2e-3, 2e-3, "block dx")        # (a handful of ReLU-mask flips between the two summation orders)
+    for i in range(3):
+        close(nat[2][i], e[2][i], 5e-3, 5e-3, f"block dw{i}")
+        close(nat[3][i], e[3][i], 5e-3, 5e-3, f"block db{i}")
+
+
+def test_conv3x3_bf16_random_shapes(ops):
+    """The shape fuzz of the fp32 kernels, on the bf16 entry points (forward + wgrad; no ReLU so no mask flips)."""
+    rng = np.random.RandomState(4048)
+    ops.set_operand_rounding("bf16")
+    try:
+        for case in range(16):
+            n = int(rng.randint(1, 4))
+            cin = int(rng.choice([1, 3, 4, 5, 17, 32, 33, 64]))
+            cout = int(rng.choice([1, 7, 32, 64, 65, 128, 130]))
+            h = int(rng.choice([1, 2, 3, 4, 5, 9, 13]))
+            w = int(rng.choice([1, 2, 3, 5, 8, 25, 31, 32, 33, 39, 57, 64, 71]))
+            gen = g(3000 + case)
+            x = torch.randn(n, cin, h, w, generator=gen)
+            wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+            b = torch.randn(cout, generator=gen) * 0.1
+            xr, wr, br = _rb(x).requires_grad_(), _rb(wt).requires_grad_(), b.clone().requires_grad_()
+            yr = F.conv2d(xr, wr, br, padding=1)
+            gy = torch.randn(yr.shape, generator=gen)
+            yr.backward(_rb(gy))
+            xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, wt, b))
+            yd = ops.conv3x3(xd, wd, bd, False)
+            yd.backward(gy.to(DEV))
+            tag = f"case {case} n={n} cin={cin} cout={cout} h={h} w={w}"
+            close(yd, yr, 1e-4, 1e-4, "fwd " + tag)
+            close(xd.grad, xr.grad, 1e-4, 2e-4, "dgrad " + tag)
+            close(wd.grad, wr.grad, 2e-4, 1e-3, "wgrad " + tag)
+            close(bd.grad, br.grad, 1e-4, 1e-3, "bias grad " + tag)
+    finally:
+        ops.set_operand_rounding(None)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16_emulate"])
+def test_bf16_operand_rounding_mode(ops, mode):
     """SOLVER.AMP.ENABLED (BASELINE configs[4] numerics): conv / FC operands and incoming gradients rounded to bf16, fp32
     accumulation, fp32 results == the fp32 op applied to bf16-rounded tensors."""
     gen = g(99)
@@ -779,7 +932,7 @@ def test_bf16_operand_rounding_mode(ops):
     lxr, lwr = rb(lx).requires_grad_(), rb(lw).requires_grad_()
     lyr = F.linear(lxr, lwr, lb)
     lyr.backward(rb(lg))
-    ops.set_operand_rounding("bf16")
+    ops.set_operand_rounding(mode)
     try:
         xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, wt, b))
         yd = ops.conv3x3(xd, wd, bd, False)

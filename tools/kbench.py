@@ -39,7 +39,11 @@ def main():
     ap.add_argument("--which", default="conv,wgrad,gemm,roi")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--bf16", action="store_true", help="the bf16-input kernels (ptmi_*_bf16); fractions stay relative "
+                                                        "to the fp32 MFMA peak")
     a = ap.parse_args()
+    if a.bf16:
+        ops.set_operand_rounding("bf16")
     dev = "cuda:0"
     which = a.which.split(",")
     sel = a.layers.split(",") if a.layers else None
@@ -62,7 +66,7 @@ def main():
             ws = torch.empty(nws, device=dev)
 
             def f():
-                _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x), ops._ptr(dy), ops._ptr(dw), None, ops._ptr(ws), a.n, cin,
+                _lib.call(ops._conv_wgrad_sym(), ops._ptr(x), ops._ptr(dy), ops._ptr(dw), None, ops._ptr(ws), a.n, cin,
                           cout, h, w, 0, ops._stream())
             ms = timeit(f, a.iters)
             print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}")
