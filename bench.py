@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16 dense peak (--amp only)
 
 
 def synth_records(gen, n, h, w, K, dev, m=12, labelled=True):
@@ -111,6 +112,10 @@ def main():
     ap.add_argument("--student-only", action="store_true",
                     help="BASELINE configs[1]: supervised student fwd/bwd only (burn-in step) on 2 x per-gpu-batch images; "
                          "use --per-gpu-batch 4 for the quoted batch of 8")
+    ap.add_argument("--amp", action="store_true",
+                    help="NOT the headline metric: SOLVER.AMP.ENABLED (BASELINE configs[4] numerics) -- conv / FC operands "
+                         "rounded to bf16 inside the ptmi_*_bf16 kernels (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 "
+                         "losses / optimiser; reported against the dense bf16 MFMA peak")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -133,7 +138,8 @@ def main():
     cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), [
         "MODEL.DEVICE", f"cuda:{local_rank}", "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP",
         10 ** 9 if args.student_only else 0,
-        "SOLVER.IMG_PER_BATCH_LABEL", B * world, "SOLVER.IMG_PER_BATCH_UNLABEL", B * world])
+        "SOLVER.IMG_PER_BATCH_LABEL", B * world, "SOLVER.IMG_PER_BATCH_UNLABEL", B * world,
+        "SOLVER.AMP.ENABLED", bool(args.amp)])
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     torch.manual_seed(0)                                                # identical init on all ranks
     trainer = PTrainer(cfg)
@@ -185,27 +191,32 @@ def main():
         value = world * 2 * B * args.steps / dt             # burn-in step: label_q + label_k = 2B images as well
         srt = sorted(step_ms)
         median = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic() if not args.amp else (None, "not collected for the bf16 kernels")
+        peak = PEAK_BF16_MFMA_TFLOPS if args.amp else PEAK_F32_MFMA_TFLOPS
         conv = prof.get("conv3x3_mfma", {"ms": 0.0, "flops": 0.0, "calls": 0})
         ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         out = {
             "metric": ("student-only train-step img/s at 1333x800" if args.student_only else
-                       "teacher-student train-step img/s at 1333x800"), "value": value, "unit": "img/s",
+                       "teacher-student train-step img/s at 1333x800") +
+                      (" [SOLVER.AMP.ENABLED: bf16 operands, not the headline metric]" if args.amp else ""),
+            "value": value, "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "ms_per_step_median": median, "value_at_median": world * 2 * B / (median * 1e-3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 operands / f32 accumulate (conv, FC); f32 elsewhere" if args.amp else "f32", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[1]: final_c2f.yaml (K=8) student-only supervised fwd/bwd + clip + SGD, "
                                     f"per-GPU {2 * B} synthetic {W}x{H} images (strong + weak view of {B} labelled), random init"
                                     if args.student_only else
                                     f"BASELINE configs[2]: final_c2f.yaml (K=8) full teacher+student+EMA step, per-GPU "
                                     f"{B} labelled + {B} unlabelled synthetic {W}x{H} images, BURN_UP_STEP=0, random init"),
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": ach / peak, "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["calls"], 1),
-                         "kernel": "conv3x3_buf_kernel<BM,NWAVE> + conv3x3_stem_kernel (all 3x3 conv fwd + dgrad launches)",
+                         "kernel": ("conv3x3_buf_kernel<BM,NWAVE,bf16> (all 3x3 conv fwd + dgrad launches)" if args.amp else
+                                    "conv3x3_buf_kernel<BM,NWAVE> + conv3x3_stem_kernel (all 3x3 conv fwd + dgrad launches)"),
                          "calls": conv["calls"],
                          "avg_launch_ms": conv["ms"] / max(conv["calls"], 1),
                          "flops_per_launch_avg": conv["flops"] / max(conv["calls"], 1)},
@@ -216,7 +227,7 @@ def main():
             if (H, W) == (800, 1333) else None,
             "losses": {k: v for k, v in trainer.last_metrics.items() if k.startswith("loss")},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.amp:
             out["cpu_baseline"] = cpu_baseline(H, W, K, student_only=args.student_only)
         print(json.dumps(out))
     if world > 1:

@@ -10,7 +10,8 @@ index-driven pipeline decorrelate sample by sample (one rank swap re-orders a pr
 compared only over the first iterations; the long-run claim is statistical: smoothed curves agree.
 
     python tools/loss_curve_parity.py --iters 500 --out profiles/r02_loss_curve_s2c_fp32.json
-    python tools/loss_curve_parity.py --iters 500 --bf16 --no-oracle ...   (bf16-input emulation, HIP side only)"""
+    python tools/loss_curve_parity.py --iters 500 --bf16 --no-oracle ...   (SOLVER.AMP.ENABLED: native bf16 kernels, HIP only)
+    python tools/loss_curve_parity.py --iters 500 --bf16 --emulate --no-oracle ...   (same numerics on the fp32 kernels)"""
 import argparse
 import json
 import os
@@ -68,6 +69,8 @@ def main():
     ap.add_argument("--width", type=int, default=160)
     ap.add_argument("--window", type=int, default=50)
     ap.add_argument("--bf16", action="store_true", help="HIP side: SOLVER.AMP.ENABLED (bf16-rounded conv / FC operands)")
+    ap.add_argument("--emulate", action="store_true", help="with --bf16: round operands by tensor passes and run the fp32 "
+                                                           "kernels (ops mode bf16_emulate) instead of the native bf16 kernels")
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -90,6 +93,9 @@ def main():
     ratio_rng = random.Random(5)
     ratios = []
     tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
+    if a.bf16 and a.emulate:
+        from probabilisticteacher_amd import ops
+        ops.set_operand_rounding("bf16_emulate")
     sd = tr.model.state_dict()
     tsd = tr.model_teacher.state_dict()
     with torch.no_grad():
@@ -139,7 +145,11 @@ def main():
     def nan_keys(m):
         return sorted(k for k, v in m.items() if k[:4] == "loss" and not np.isfinite(v))
 
-    out = {"config": "final_s2c.yaml (K=1)" + (", bf16-rounded conv/FC operands" if a.bf16 else ", fp32"),
+    mode = ", fp32"
+    if a.bf16:
+        mode = (", bf16 operands: rounding passes + fp32 kernels (bf16_emulate)" if a.emulate
+                else ", bf16 operands: native v_mfma_f32_32x32x16_bf16 kernels")
+    out = {"config": "final_s2c.yaml (K=1)" + mode,
            "iters": a.iters, "burn_up_step": a.burn, "batch": [a.batch, a.batch], "image": [a.height, a.width],
            "hip_finite_total_loss": [finite_total(m) for m in hip_curve], "hip_seconds": t_hip,
            "hip_grad_norm_finite": bool(all(np.isfinite(m["grad_norm"]) for m in hip_curve)),
