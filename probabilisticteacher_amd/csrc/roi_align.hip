@@ -151,8 +151,11 @@ __global__ __launch_bounds__(256) void roi_tables_kernel(const float* __restrict
     }
 }
 
-constexpr int RF2_THREADS = 1024, RF2_SLOTS = 5;
+constexpr int RF2_THREADS = 1024, RF2_SLOTS = 20, RF2_CG = 4;
 
+// thread = (roi slot, bin); it walks the workgroup's (up to) four channel planes itself, so the ROI's header and the bin's
+// row / column taps are fetched once per FOUR outputs (the first version had a thread per (slot, channel, bin): the tap
+// loads, nine 16-B requests per thread and ROI, cost as much TA time as the gathers themselves).
 __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const float* __restrict__ feat,
                                                                         const void* __restrict__ ws,
                                                                         const int32_t* __restrict__ img_off,
@@ -168,11 +171,9 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
     const float* src = feat + ((size_t)n * C + c0) * HW;
     for (int i = tid; i < cg * HW; i += RF2_THREADS) plane[i] = src[i];
     __syncthreads();
-    const int slot = tid / 196, t = tid - slot * 196;
-    const int c = t / 49, rem = t - c * 49;
-    const int ph = rem / 7, pw = rem - ph * 7;
-    if (slot >= RF2_SLOTS || c >= cg) return;
-    const float* f = plane + c * HW;
+    const int slot = tid / 49, bin = tid - slot * 49;
+    const int ph = bin / 7, pw = bin - ph * 7;
+    if (slot >= RF2_SLOTS) return;
     const size_t rstride = sizeof(RoiHeader) + 2 * (size_t)TS * sizeof(TapEntry);
     const int r1 = img_off[n + 1];
     for (int r = img_off[n] + slot; r < r1; r += RF2_SLOTS) {
@@ -180,10 +181,11 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
         const RoiHeader hd = *reinterpret_cast<const RoiHeader*>(base);
         const TapEntry* yt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + ph * hd.gh;
         const TapEntry* xt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + TS + pw * hd.gw;
-        float acc = 0.f;
+        float acc[RF2_CG] = {0.f, 0.f, 0.f, 0.f};
+        // (per channel the arithmetic is the torchvision expression in sample order: bit-identical to the plain kernel)
         if (hd.gw <= 4 && hd.gh <= 4) {
             // common case (ROIs up to 28 feature cells a side): all taps of the bin are fetched up front and the
-            // 4 x 4 sample grid is fully unrolled (same summation order), so the LDS reads of different samples overlap
+            // 4 x 4 sample grid is fully unrolled, so the LDS reads of different samples and channels overlap
             TapEntry ex[4], ey[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -195,50 +197,44 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
 #pragma unroll
             for (int iy = 0; iy < 4; ++iy) {
                 if (ey[iy].lo < 0) continue;
-                const float* f0 = f + ey[iy].lo * W;
-                const float* f1 = f + ey[iy].hi * W;
+                const float* f0 = plane + ey[iy].lo * W;
+                const float* f1 = plane + ey[iy].hi * W;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (ex[k].lo < 0) continue;
                     const float w1 = ey[iy].wlo * ex[k].wlo, w2 = ey[iy].wlo * ex[k].whi, w3 = ey[iy].whi * ex[k].wlo,
                                 w4 = ey[iy].whi * ex[k].whi;
-                    acc += w1 * f0[ex[k].lo] + w2 * f0[ex[k].hi] + w3 * f1[ex[k].lo] + w4 * f1[ex[k].hi];
-                }
-            }
-        } else if (hd.gw <= 4) {
-            // the bin's column taps live in registers for all sample rows
-            TapEntry ex[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < hd.gw) ex[k] = xt[k];
-                else { ex[k].lo = -1; ex[k].hi = -1; ex[k].wlo = ex[k].whi = 0.f; }
-            }
-            for (int iy = 0; iy < hd.gh; ++iy) {
-                const TapEntry ey = yt[iy];
-                if (ey.lo < 0) continue;
-                const float* f0 = f + ey.lo * W;
-                const float* f1 = f + ey.hi * W;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (ex[k].lo < 0) continue;
-                    const float w1 = ey.wlo * ex[k].wlo, w2 = ey.wlo * ex[k].whi, w3 = ey.whi * ex[k].wlo, w4 = ey.whi * ex[k].whi;
-                    acc += w1 * f0[ex[k].lo] + w2 * f0[ex[k].hi] + w3 * f1[ex[k].lo] + w4 * f1[ex[k].hi];
+                    for (int c = 0; c < RF2_CG; ++c) {
+                        if (c >= cg) break;
+                        const int o = c * HW;
+                        acc[c] += w1 * f0[o + ex[k].lo] + w2 * f0[o + ex[k].hi] + w3 * f1[o + ex[k].lo] + w4 * f1[o + ex[k].hi];
+                    }
                 }
             }
         } else {
             for (int iy = 0; iy < hd.gh; ++iy) {
                 const TapEntry ey = yt[iy];
                 if (ey.lo < 0) continue;
+                const float* f0 = plane + ey.lo * W;
+                const float* f1 = plane + ey.hi * W;
                 for (int ix = 0; ix < hd.gw; ++ix) {
                     const TapEntry ex = xt[ix];
                     if (ex.lo < 0) continue;
                     const float w1 = ey.wlo * ex.wlo, w2 = ey.wlo * ex.whi, w3 = ey.whi * ex.wlo, w4 = ey.whi * ex.whi;
-                    acc += w1 * f[ey.lo * W + ex.lo] + w2 * f[ey.lo * W + ex.hi] + w3 * f[ey.hi * W + ex.lo] +
-                           w4 * f[ey.hi * W + ex.hi];
+#pragma unroll
+                    for (int c = 0; c < RF2_CG; ++c) {
+                        if (c >= cg) break;
+                        const int o = c * HW;
+                        acc[c] += w1 * f0[o + ex.lo] + w2 * f0[o + ex.hi] + w3 * f1[o + ex.lo] + w4 * f1[o + ex.hi];
+                    }
                 }
             }
         }
-        out[((size_t)r * C + c0) * 49 + t] = acc / hd.count;
+        float* dst = out + ((size_t)r * C + c0) * 49 + bin;
+#pragma unroll
+        for (int c = 0; c < RF2_CG; ++c)
+            if (c < cg) dst[c * 49] = acc[c] / hd.count;
     }
 }
 
@@ -333,6 +329,7 @@ __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const fl
     const int fx = (wave & 1) * 64 + lane;
     const int fxc = fx < W ? fx : W - 1;                         // clamped: lanes past the map only read
     float* wyl = wystage + wave * H * 8;
+    float* gl = wystage + (RB2_THREADS / 64) * H * 8 + wave * 52;     // this wave's copy of dOut[r][c] (49 values + pad)
     const size_t stride = sizeof(RoiBwdHeader) + (size_t)(H + W) * 8 * sizeof(float);
     const int r0 = img_off[n], r1 = img_off[n + 1];
     const int nwy = H * 2;                                       // f32x4 pieces of a Wy table (<= 128: two per lane)
@@ -361,23 +358,31 @@ __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const fl
             if (hd.y1 >= 0 && hd.x1 >= 0 && hd.x1 >= lo && hd.x0 <= lo + 63) {      // wave-uniform
                 reinterpret_cast<f32x4*>(wyl)[lane < nwy ? lane : 0] = wy0;
                 if (lane + 64 < nwy) reinterpret_cast<f32x4*>(wyl)[lane + 64] = wy1;
+                if (lane < 52) gl[lane] = g;
                 __builtin_amdgcn_wave_barrier();                 // the strip is read by other lanes of this wave
+                const float inv_count = 1.f / hd.count;          // (wave-uniform; the seven quotients below were a third of the ROI's VALU work)
                 float t[7];
+                float gq[52];                                    // the 7x7 gradient, broadcast-read from the strip
+#pragma unroll
+                for (int q = 0; q < 13; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(gl + 4 * q);
+                    gq[4 * q] = v[0]; gq[4 * q + 1] = v[1]; gq[4 * q + 2] = v[2]; gq[4 * q + 3] = v[3];
+                }
 #pragma unroll
                 for (int ph = 0; ph < 7; ++ph) {
-                    float a = rdl(g, ph * 7 + 0) * wxa[0];
-                    a += rdl(g, ph * 7 + 1) * wxa[1];
-                    a += rdl(g, ph * 7 + 2) * wxa[2];
-                    a += rdl(g, ph * 7 + 3) * wxa[3];
-                    a += rdl(g, ph * 7 + 4) * wxb[0];
-                    a += rdl(g, ph * 7 + 5) * wxb[1];
-                    a += rdl(g, ph * 7 + 6) * wxb[2];
-                    t[ph] = a / hd.count;
+                    float a = gq[ph * 7 + 0] * wxa[0];
+                    a += gq[ph * 7 + 1] * wxa[1];
+                    a += gq[ph * 7 + 2] * wxa[2];
+                    a += gq[ph * 7 + 3] * wxa[3];
+                    a += gq[ph * 7 + 4] * wxb[0];
+                    a += gq[ph * 7 + 5] * wxb[1];
+                    a += gq[ph * 7 + 6] * wxb[2];
+                    t[ph] = a * inv_count;
                 }
                 if (fx >= hd.x0 && fx <= hd.x1) {
-                    for (int fy = hd.y0; fy <= hd.y1; ++fy) {
-                        const f32x4 wa = *reinterpret_cast<const f32x4*>(wyl + fy * 8);
-                        const f32x4 wb = *reinterpret_cast<const f32x4*>(wyl + fy * 8 + 4);
+                    // rows are independent read-modify-writes of this lane's LDS column: four at a time, so that the
+                    // LDS round trips (table row, cell read, cell write) of different rows overlap
+                    auto rowsum = [&](const f32x4& wa, const f32x4& wb) {
                         float a = wa[0] * t[0];
                         a += wa[1] * t[1];
                         a += wa[2] * t[2];
@@ -385,7 +390,25 @@ __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const fl
                         a += wb[0] * t[4];
                         a += wb[1] * t[5];
                         a += wb[2] * t[6];
-                        col[fy * W] += a;
+                        return a;
+                    };
+                    int fy = hd.y0;
+                    for (; fy + 3 <= hd.y1; fy += 4) {
+                        f32x4 wa[4], wb[4];
+                        float cv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            wa[u] = *reinterpret_cast<const f32x4*>(wyl + (fy + u) * 8);
+                            wb[u] = *reinterpret_cast<const f32x4*>(wyl + (fy + u) * 8 + 4);
+                            cv[u] = col[(fy + u) * W];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) col[(fy + u) * W] = cv[u] + rowsum(wa[u], wb[u]);
+                    }
+                    for (; fy <= hd.y1; ++fy) {
+                        const f32x4 wa = *reinterpret_cast<const f32x4*>(wyl + fy * 8);
+                        const f32x4 wb = *reinterpret_cast<const f32x4*>(wyl + fy * 8 + 4);
+                        col[fy * W] += rowsum(wa, wb);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();                 // next ROI overwrites the strip
@@ -449,7 +472,7 @@ int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32
     if (pooled != 7 || plane_bytes > budget || !ws)
         return ptmi_roi_align_fwd(feat, rois, out, n, c, h, w, r, pooled, scale, s);
     int cg = (int)(budget / plane_bytes);
-    if (cg > 4) cg = 4;
+    if (cg > RF2_CG) cg = RF2_CG;
     if (cg > c) cg = c;
     const int TS = roi_tab_stride(h, w);
     hipStream_t st = (hipStream_t)s;
@@ -479,7 +502,7 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
                    "roi_align_bwd_grouped: bad args");
     hipStream_t st = (hipStream_t)s;
     const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    const size_t stage = (size_t)(RB2_THREADS / 64) * h * 8 * sizeof(float);
+    const size_t stage = (size_t)(RB2_THREADS / 64) * (h * 8 + 52) * sizeof(float);
     const bool col_ok = pooled == 7 && ws && w <= RB2_XP && h <= 64 && 4 * plane_bytes + stage <= 79 * 1024;
     if (!col_ok || r == 0) {              // not the hot-path shape (or no ROI at all): zero + atomic scatter kernel
         hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)n * c * plane_bytes, st);

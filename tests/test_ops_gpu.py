@@ -216,7 +216,7 @@ def _rand_boxes(gen, n, h, w, lo=4.0):
 
 def test_roi_align(ops):
     gen = g(23)
-    feat = torch.randn(2, 16, 25, 31, generator=gen)
+    feat = torch.randn(2, 18, 25, 31, generator=gen)          # 18 channels: the grouped kernels' last group holds two
     boxes = _rand_boxes(gen, 40, 25 * 16, 31 * 16)
     boxes[0] = torch.tensor([-30.0, -20.0, 40.0, 35.0])        # partly outside
     boxes[1] = torch.tensor([400.0, 300.0, 520.0, 420.0])      # beyond the far border
@@ -233,7 +233,7 @@ def test_roi_align(ops):
     out.backward(gy.to(DEV))
     close(fd.grad, fr.grad, 1e-4, 1e-4, "roi_align bwd (ungrouped fallback: fp32 summation order differs from the CPU loop)")
     empty = ops.roi_align(fd, torch.zeros((0, 5), device=DEV), 7, 1 / 16)
-    assert empty.shape == (0, 16, 7, 7)
+    assert empty.shape == (0, 18, 7, 7)
     # grouped-by-image backward (LDS accumulation, no global atomics) gives the same gradient
     order = torch.argsort(rois[:, 0], stable=True)
     rs = rois[order]
