@@ -529,3 +529,50 @@ def test_voc_evaluation_of_the_eval_path_matches_the_oracle_detections():
         assert np.isfinite(res["bbox"][k]) and abs(res["bbox"][k] - ref["bbox"][k]) <= 2.0, (k, res["bbox"], ref["bbox"])
     with pytest.raises(ValueError):
         PTrainer.build_evaluator(setup_cfg("configs/pt/final_c2f.yaml", ["TEST.EVALUATOR", "nope"]), names)
+
+
+def test_amp_step_native_bf16_kernels_match_emulated_rounding():
+    """SOLVER.AMP.ENABLED (BASELINE configs[4]): one supervised step of the real trainer on the run_step fixture's records,
+    (a) on the native bf16-input kernels and (b) with operands rounded by tensor passes on the fp32 kernels, from the same
+    weights and sampler keys.  The two differ only in fp32 summation order: RPN terms (anchors are fixed) to 1e-3, ROI terms
+    (they inherit proposal-order decisions) to 3e-2, and every updated-parameter probe to the same precision as two fp32
+    implementations; and AMP really changes the numbers relative to fp32."""
+    from probabilisticteacher_amd import ops
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.modeling import sampling
+    z = load("run_step")
+    K, tau, B = int(z["K"]), tuple(float(v) for v in z["tau"]), int(z["B"])
+    ocfg = opt.Cfg(num_classes=K, anchor_generator="DifferentiableAnchorGenerator", tau=tau, burn_up_step=1)
+    params = opt.golden_params(ocfg, int(z["seed"]))
+    out = {}
+    try:
+        for mode in ("bf16", "bf16_emulate", None):
+            cfg = _cfg(K, "DifferentiableAnchorGenerator", tau, burn=1)
+            cfg.defrost() if hasattr(cfg, "defrost") else None
+            cfg.SOLVER.AMP.ENABLED = mode is not None
+            ratios = [float(v) for v in z["it0_ratios"]]
+            tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
+            assert ops._OPERAND_ROUNDING == ("bf16" if mode else None)        # what the config flag selects
+            ops.set_operand_rounding(mode)
+            _load_params(tr.model, params)
+            _load_params(tr.model_teacher, params)
+            data = tuple(_gpu_records(z, f"it0_{nm}", B) for nm in ("lq", "lk", "uq", "uk"))
+            sampling.set_key_source(perm_key_source(opt.SeededPerm(500)))
+            m = tr.run_step(data)
+            sd = tr.model.state_dict()
+            out[mode] = (m, {k: sd[k].flatten()[:64].cpu().clone() for k in
+                             ("backbone.vgg_block3.0.conv1.weight", "proposal_generator.rpn_head.conv.weight",
+                              "roi_heads.box_head.fc1.weight", "roi_heads.box_predictor.cls_score.weight")})
+    finally:
+        sampling.set_key_source(None)
+        ops.set_operand_rounding(None)
+    (mn, pn), (me, pe), (mf, pf) = out["bf16"], out["bf16_emulate"], out[None]
+    for k in ("loss_rpn_cls", "loss_rpn_loc"):
+        close(torch.tensor(mn[k]), torch.tensor(me[k]), 1e-3, 1e-5, "native vs emulate " + k)
+    for k in ("loss_cls", "loss_box_reg", "grad_norm"):
+        close(torch.tensor(mn[k]), torch.tensor(me[k]), 3e-2, 1e-4, "native vs emulate " + k)
+    for k in pn:
+        close(pn[k], pe[k], 1e-3, 2e-5, "updated parameter " + k)
+    assert abs(mn["loss_rpn_cls"] - mf["loss_rpn_cls"]) > 1e-5 or abs(mn["loss_rpn_loc"] - mf["loss_rpn_loc"]) > 1e-5
+    for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"):
+        close(torch.tensor(mn[k]), torch.tensor(mf[k]), 5e-2, 1e-3, "bf16 vs fp32 " + k)
