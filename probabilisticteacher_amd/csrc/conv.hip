@@ -504,35 +504,37 @@ __device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, co
                                                 f32x16 (&acc)[G == 0 ? 5 : 4])
 {
     constexpr int TAP0 = G == 0 ? 0 : 5, TAP1 = G == 0 ? 5 : 9;
+    float a[16];                                       // dY of this lane's 16 pixels 16h + 0..15
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {                   // pixels 16h + 8*hf + j, j = 0..7
-        float a[8];
+    for (int t = 0; t < 4; ++t) {
+        const float4 v = *reinterpret_cast<const float4*>(al + 4 * t);
+        a[4 * t] = v.x; a[4 * t + 1] = v.y; a[4 * t + 2] = v.z; a[4 * t + 3] = v.w;
+    }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float4 v = *reinterpret_cast<const float4*>(al + 8 * hf + 4 * t);
-            a[4 * t] = v.x; a[4 * t + 1] = v.y; a[4 * t + 2] = v.z; a[4 * t + 3] = v.w;
+    for (int ky = (G == 0 ? 0 : 1); ky < (G == 0 ? 2 : 3); ++ky) {
+        // image columns x0 + 16h - 1 .. + 16 -> v[0..17]: four aligned 16-B reads and the two end words, ONCE for both
+        // 8-pixel halves (the single-word reads are the ones that collide in the banks: plane pitch 124 = 4 * 31 words).
+        // volatile + LDS address space keep the reads as written (the optimiser otherwise narrows the 16-B reads to
+        // the lanes used and re-pairs the remains into 8-B reads).
+        float v[18];
+        const float* br = bl + ky * WB_XROW + 4;
+        v[0] = *(const volatile lds_f32_t*)(br - 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 q = *(const volatile lds_f32x4_t*)(br + 4 * t);
+            v[1 + 4 * t] = q[0]; v[2 + 4 * t] = q[1]; v[3 + 4 * t] = q[2]; v[4 + 4 * t] = q[3];
         }
+        v[17] = *(const volatile lds_f32_t*)(br + 16);
 #pragma unroll
-        for (int ky = (G == 0 ? 0 : 1); ky < (G == 0 ? 2 : 3); ++ky) {
-            // image columns x0 + 16h + 8hf - 1 .. + 8 -> v[0..9]: two aligned 16-B reads and the two end words.
-            // volatile + LDS address space keep the reads as written (the optimiser otherwise narrows the 16-B
-            // reads to the lanes used and re-pairs the remains into 8-B reads).
-            float v[10];
-            const float* br = bl + ky * WB_XROW + 8 * hf + 4;
-            v[0] = *(const volatile lds_f32_t*)(br - 1);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const f32x4 q = *(const volatile lds_f32x4_t*)(br + 4 * t);
-                v[1 + 4 * t] = q[0]; v[2 + 4 * t] = q[1]; v[3 + 4 * t] = q[2]; v[4 + 4 * t] = q[3];
-            }
-            v[9] = *(const volatile lds_f32_t*)(br + 8);
+        for (int hf = 0; hf < 2; ++hf) {               // pixels 16h + 8*hf + j, j = 0..7
             if constexpr (BF) {
-                const ptmi_bf16x8 A = ptmi_pack_bf16x8(a);
+                const ptmi_bf16x8 A = ptmi_pack_bf16x8(a + 8 * hf);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int tap = ky * 3 + kx;
                     if (tap >= TAP0 && tap < TAP1)
-                        acc[tap - TAP0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, ptmi_pack_bf16x8(v + kx), acc[tap - TAP0], 0, 0, 0);
+                        acc[tap - TAP0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, ptmi_pack_bf16x8(v + 8 * hf + kx),
+                                                                                  acc[tap - TAP0], 0, 0, 0);
                 }
             } else {
 #pragma unroll
@@ -540,7 +542,8 @@ __device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, co
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int tap = ky * 3 + kx;
-                        if (tap >= TAP0 && tap < TAP1) acc[tap - TAP0] = mfma32(a[j], v[j + kx], acc[tap - TAP0]);
+                        if (tap >= TAP0 && tap < TAP1)
+                            acc[tap - TAP0] = mfma32(a[8 * hf + j], v[8 * hf + j + kx], acc[tap - TAP0]);
                     }
                 }
             }
