@@ -29,14 +29,16 @@ int main(int argc, char** argv)
     fwd_t fwd = (fwd_t)dlsym(lib, "ptmi_conv3x3_fwd");
     pack_t pack = (pack_t)dlsym(lib, "ptmi_conv3x3_pack_weights");
     pf_t pfl = (pf_t)dlsym(lib, "ptmi_conv3x3_packed_floats");
-    const int n = 16, c = 256, h = 200, w = 333;
-    const size_t act = (size_t)n * c * h * w;
+    const bool stem = argc > 2;                         // any second argument: the 3-channel stem layer instead of conv3_2
+    const int n = 16, c = 256, h = stem ? 800 : 200, w = stem ? 1333 : 333;
+    const int cin = stem ? 3 : c, cout = stem ? 64 : c;
+    const size_t act = (size_t)n * (stem ? 64 : c) * h * w;
     float *x, *y, *wt, *wp, *b;
     hipMalloc(&x, act * 4); hipMalloc(&y, act * 4); hipMalloc(&wt, (size_t)c * c * 9 * 4); hipMalloc(&b, c * 4);
-    hipMalloc(&wp, pfl(c, c) * 4);
+    hipMalloc(&wp, pfl(cin, cout) * 4);
     hipMemset(x, 0, act * 4); hipMemset(wt, 0, (size_t)c * c * 9 * 4); hipMemset(b, 0, c * 4);
     hipStream_t sa, sb; hipStreamCreate(&sa); hipStreamCreate(&sb);
-    pack(wt, wp, c, c, 0, sa);
+    pack(wt, wp, cout, cin, 0, sa);
     unsigned long long* out; hipMalloc(&out, 16);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode < 2; ++mode) {              // 0: idle chip, 1: conv kernel running
@@ -44,7 +46,7 @@ int main(int argc, char** argv)
             hipDeviceSynchronize();
             if (mode == 1) {
                 hipEventRecord(e0, sa);
-                for (int i = 0; i < 6; ++i) fwd(x, wp, b, nullptr, y, n, c, c, h, w, 1, sa);      // ~9 ms each
+                for (int i = 0; i < (stem ? 30 : 6); ++i) fwd(x, wp, b, nullptr, y, n, cin, cout, h, w, 1, sa);      // ~9 ms (1.3 ms) each
                 hipEventRecord(e1, sa);
             }
             hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, sb, out, 3000000ull);                 // 30 ms of 100 MHz ticks
@@ -53,8 +55,9 @@ int main(int argc, char** argv)
             float ms = 0.f; if (mode == 1) hipEventElapsedTime(&ms, e0, e1);
             printf("%s: %llu shader ticks / %llu ref ticks -> %.0f MHz%s", mode ? "conv running" : "idle        ", hst[0], hst[1],
                    (double)hst[0] / (double)hst[1] * 100.0, mode ? "" : "\n");
-            if (mode == 1) printf("   (6 conv3_2 launches n=16: %.2f ms each, %.1f TFLOP/s)\n", ms / 6,
-                                  2.0 * 9 * c * c * (double)h * w * n / (ms / 6) / 1e9);
+            const int nl = stem ? 30 : 6;
+            if (mode == 1) printf("   (%d %s launches n=16: %.2f ms each, %.1f TFLOP/s)\n", nl, stem ? "stem" : "conv3_2", ms / nl,
+                                  2.0 * 9 * cin * cout * (double)h * w * n / (ms / nl) / 1e9);
         }
     }
     return 0;
