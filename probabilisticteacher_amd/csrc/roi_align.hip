@@ -309,6 +309,10 @@ __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restr
     for (int i = tid; i < (H + W) * 8; i += 64) wt[i] = tsm[i];
 }
 
+// NP = 16-B pieces of the Wy table per lane: 2 for maps up to 64 rows (the landscape hot path: 50 x 83), 4 up to 128 rows
+// (portrait / mixed batches: 83 x 50, 83 x 83).  The workgroup has two waves per channel plane it holds (CG planes,
+// blockDim = 128 CG), CG chosen by the launcher from the LDS budget.
+template <int NP>
 __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const float* __restrict__ dout,
                                                                         const void* __restrict__ ws,
                                                                         const int32_t* __restrict__ img_off,
@@ -318,26 +322,26 @@ __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const fl
     extern __shared__ float smem[];
     const int HW = H * W;
     float* plane = smem;                                         // CG * HW
-    float* wystage = plane + CG * HW;                            // 8 waves x H x 8
+    float* wystage = plane + CG * HW;                            // 2 CG waves x H x 8
     const int n = blockIdx.y, c0 = blockIdx.x * CG;
     const int cg = min(CG, C - c0);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < cg * HW; i += RB2_THREADS) plane[i] = 0.f;
+    for (int i = tid; i < cg * HW; i += nthreads) plane[i] = 0.f;
     __syncthreads();
     const int c = wave >> 1;                                     // wave-uniform channel; two waves cover 128 columns
     const int fx = (wave & 1) * 64 + lane;
     const int fxc = fx < W ? fx : W - 1;                         // clamped: lanes past the map only read
     float* wyl = wystage + wave * H * 8;
-    float* gl = wystage + (RB2_THREADS / 64) * H * 8 + wave * 52;     // this wave's copy of dOut[r][c] (49 values + pad)
+    float* gl = wystage + (nthreads >> 6) * H * 8 + wave * 52;        // this wave's copy of dOut[r][c] (49 values + pad)
     const size_t stride = sizeof(RoiBwdHeader) + (size_t)(H + W) * 8 * sizeof(float);
     const int r0 = img_off[n], r1 = img_off[n + 1];
-    const int nwy = H * 2;                                       // f32x4 pieces of a Wy table (<= 128: two per lane)
+    const int nwy = H * 2;                                       // f32x4 pieces of a Wy table (<= 64 NP: NP per lane)
     if (c < cg && r0 < r1) {
         float* col = plane + c * HW + fx;
         // everything ROI r needs is fetched while ROI r-1 is being accumulated: its header (scalar), this lane's
         // dOut value (lanes 0-48 hold the 7x7 gradient of channel c), its Wx row and its two pieces of the Wy table
-        auto fetch = [&](int r, RoiBwdHeader& hd, float& g, f32x4& wxa, f32x4& wxb, f32x4& wy0, f32x4& wy1) {
+        auto fetch = [&](int r, RoiBwdHeader& hd, float& g, f32x4& wxa, f32x4& wxb, f32x4 (&wy)[NP]) {
             const char* base = (const char*)ws + (size_t)r * stride;
             hd = *reinterpret_cast<const RoiBwdHeader*>(base);
             const f32x4* wyg = reinterpret_cast<const f32x4*>(base + sizeof(RoiBwdHeader));
@@ -345,19 +349,20 @@ __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const fl
             g = dout[((size_t)r * C + c0 + c) * 49 + (lane < 49 ? lane : 48)];
             wxa = wxg[fxc * 2];
             wxb = wxg[fxc * 2 + 1];
-            wy0 = wyg[lane < nwy ? lane : 0];
-            wy1 = wyg[lane + 64 < nwy ? lane + 64 : 0];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wy[q] = wyg[lane + 64 * q < nwy ? lane + 64 * q : 0];
         };
         RoiBwdHeader hd, hdn;
         float g, gn;
-        f32x4 wxa, wxb, wy0, wy1, wxan, wxbn, wy0n, wy1n;
-        fetch(r0, hd, g, wxa, wxb, wy0, wy1);
+        f32x4 wxa, wxb, wy[NP], wxan, wxbn, wyn[NP];
+        fetch(r0, hd, g, wxa, wxb, wy);
         for (int r = r0; r < r1; ++r) {
-            if (r + 1 < r1) fetch(r + 1, hdn, gn, wxan, wxbn, wy0n, wy1n);
+            if (r + 1 < r1) fetch(r + 1, hdn, gn, wxan, wxbn, wyn);
             const int lo = (wave & 1) * 64;
             if (hd.y1 >= 0 && hd.x1 >= 0 && hd.x1 >= lo && hd.x0 <= lo + 63) {      // wave-uniform
-                reinterpret_cast<f32x4*>(wyl)[lane < nwy ? lane : 0] = wy0;
-                if (lane + 64 < nwy) reinterpret_cast<f32x4*>(wyl)[lane + 64] = wy1;
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    if (lane + 64 * q < nwy) reinterpret_cast<f32x4*>(wyl)[lane + 64 * q] = wy[q];
                 if (lane < 52) gl[lane] = g;
                 __builtin_amdgcn_wave_barrier();                 // the strip is read by other lanes of this wave
                 const float inv_count = 1.f / hd.count;          // (wave-uniform; the seven quotients below were a third of the ROI's VALU work)
@@ -413,12 +418,14 @@ __global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const fl
                 }
                 __builtin_amdgcn_wave_barrier();                 // next ROI overwrites the strip
             }
-            hd = hdn; g = gn; wxa = wxan; wxb = wxbn; wy0 = wy0n; wy1 = wy1n;
+            hd = hdn; g = gn; wxa = wxan; wxb = wxbn;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wy[q] = wyn[q];
         }
     }
     __syncthreads();
     float* dst = dfeat + ((size_t)n * C + c0) * HW;
-    for (int i = tid; i < cg * HW; i += RB2_THREADS) dst[i] = plane[i];
+    for (int i = tid; i < cg * HW; i += nthreads) dst[i] = plane[i];
 }
 
 }  // namespace
@@ -502,8 +509,12 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
                    "roi_align_bwd_grouped: bad args");
     hipStream_t st = (hipStream_t)s;
     const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    const size_t stage = (size_t)(RB2_THREADS / 64) * (h * 8 + 52) * sizeof(float);
-    const bool col_ok = pooled == 7 && ws && w <= RB2_XP && h <= 64 && 4 * plane_bytes + stage <= 79 * 1024;
+    // channel planes per workgroup (two waves each): as many as fit next to the per-wave table strips in half a CU's LDS
+    const size_t strip = (size_t)2 * (h * 8 + 52) * sizeof(float);       // per plane: two waves' Wy table + gradient strips
+    int cg = (int)((79 * 1024) / (plane_bytes + strip));
+    if (cg > 4) cg = 4;
+    if (cg > c) cg = c;
+    const bool col_ok = pooled == 7 && ws && w <= RB2_XP && h <= 128 && cg >= 1;
     if (!col_ok || r == 0) {              // not the hot-path shape (or no ROI at all): zero + atomic scatter kernel
         hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)n * c * plane_bytes, st);
         if (e != hipSuccess) { ptmi_set_error("roi_align_bwd_grouped: memset failed"); return -2; }
@@ -515,13 +526,19 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
     PTMI_LAUNCH_CHECK("roi_align_bwd_tables");
     static bool attr2 = false;
     if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr2 = true;
     }
-    const int cg = c < 4 ? c : 4;
-    hipLaunchKernelGGL(roi_align_bwd_col_kernel, dim3(cdiv(c, cg), n), dim3(RB2_THREADS), 4 * plane_bytes + stage, st,
-                       dout, ws, img_offsets, dfeat, c, h, w, cg);
+    const size_t lds = (size_t)cg * (plane_bytes + strip);
+    if (h <= 64)
+        hipLaunchKernelGGL(roi_align_bwd_col_kernel<2>, dim3(cdiv(c, cg), n), dim3(128 * cg), lds, st, dout, ws, img_offsets,
+                           dfeat, c, h, w, cg);
+    else
+        hipLaunchKernelGGL(roi_align_bwd_col_kernel<4>, dim3(cdiv(c, cg), n), dim3(128 * cg), lds, st, dout, ws, img_offsets,
+                           dfeat, c, h, w, cg);
     PTMI_LAUNCH_CHECK("roi_align_bwd_grouped(col)");
     return 0;
 }

@@ -214,14 +214,17 @@ def _rand_boxes(gen, n, h, w, lo=4.0):
     return b
 
 
-def test_roi_align(ops):
+@pytest.mark.parametrize("fh,fw", [(25, 31), (70, 27), (83, 83)])
+def test_roi_align(ops, fh, fw):
+    """(25, 31): the landscape layout of the grouped kernels; (70, 27) / (83, 83): maps with more than 64 rows (portrait and
+    mixed-orientation batches) -- the grouped backward's four-piece table variant, fewer channel planes per workgroup."""
     gen = g(23)
-    feat = torch.randn(2, 18, 25, 31, generator=gen)          # 18 channels: the grouped kernels' last group holds two
-    boxes = _rand_boxes(gen, 40, 25 * 16, 31 * 16)
+    feat = torch.randn(2, 18, fh, fw, generator=gen)          # 18 channels: the grouped kernels' last group is ragged
+    boxes = _rand_boxes(gen, 40, fh * 16, fw * 16)
     boxes[0] = torch.tensor([-30.0, -20.0, 40.0, 35.0])        # partly outside
-    boxes[1] = torch.tensor([400.0, 300.0, 520.0, 420.0])      # beyond the far border
+    boxes[1] = torch.tensor([fw * 16 - 96.0, fh * 16 - 100.0, fw * 16 + 24.0, fh * 16 + 20.0])      # beyond the far border
     boxes[2] = torch.tensor([10.0, 10.0, 10.5, 10.2])          # tiny
-    boxes[3] = torch.tensor([0.0, 0.0, 496.0, 400.0])          # whole image: 5 x 4 samples per bin (generic tap path)
+    boxes[3] = torch.tensor([0.0, 0.0, fw * 16.0, fh * 16.0])  # whole image: many samples per bin (generic tap path)
     rois = torch.cat([torch.randint(0, 2, (40, 1), generator=gen).float(), boxes], 1)
     fr = feat.clone().requires_grad_()
     ref = d2.roi_align(fr, rois, 7, 1 / 16)
