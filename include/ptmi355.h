@@ -61,9 +61,13 @@ int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws,
                        int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
 /* bf16-input / fp32-accumulate variants of the two calls above (SOLVER.AMP.ENABLED, pt/engine/trainer.py:98; BASELINE
- * configs[4]).  Same arguments, same packed weights and workspace size; x / wp / dy are fp32 in memory and every operand
+ * configs[4]).  Same arguments and workspace size; x / dy are fp32 in memory and every operand
  * element is rounded to bf16 (round-to-nearest-even) on its way into v_mfma_f32_32x32x16_bf16; accumulation, bias,
- * epilogues, split-K reduction and outputs are fp32.  The 3-channel stem runs on the same MFMA kernel. */
+ * epilogues, split-K reduction and outputs are fp32.  The 3-channel stem runs on the same MFMA kernel.
+ * ptmi_conv3x3_fwd_bf16 takes weights packed by ptmi_conv3x3_pack_weights_bf16 (same arguments and buffer size as
+ * ptmi_conv3x3_pack_weights; the slab holds the rounded weights as bf16 in MFMA operand order). */
+int ptmi_conv3x3_pack_weights_bf16(const float* w, float* wp, int w_cout, int w_cin, int mode,
+                                   ptmi_stream_t s);
 int ptmi_conv3x3_fwd_bf16(const float* x, const float* wp, const float* bias, const float* mask_ref,
                           float* y, int n, int cin, int cout, int h, int w, int epilogue,
                           ptmi_stream_t s);

@@ -23,6 +23,7 @@ SIGNATURES = {
     "ptmi_conv3x3_ck": (_i, [_i]),
     "ptmi_conv3x3_packed_floats": (_i64, [_i, _i]),
     "ptmi_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_pack_weights_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ptmi_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

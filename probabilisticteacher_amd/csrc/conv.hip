@@ -55,7 +55,8 @@ __device__ __forceinline__ void* uniform_ptr(const void* p)
 // BF = true: bf16-input / fp32-accumulate variant (SOLVER.AMP.ENABLED).  Same DMA pipeline and LDS layout (fp32 operands);
 // a lane rounds its operand elements to bf16 (v_cvt_pk_bf16_f32, RNE) between LDS and v_mfma_f32_32x32x16_bf16.  The
 // MFMA's 16 k values are (lane half h, element e) <-> (tap = 4t + e / 2, channel 2 (e % 2) + h) for MFMA t of a chunk:
-// taps 0-3, 4-7 and 8 (+ three zero taps) -- 3 MFMAs per accumulator tile and chunk instead of 18.
+// taps 0-3, 4-7 and 8 (+ three zero taps) -- 3 MFMAs per accumulator tile and chunk instead of 18.  The weights arrive
+// already as bf16 in that order (ptmi_conv3x3_pack_weights_bf16): a third less weight DMA, one ds_read_b128 per A operand.
 template <int BM, int NWAVE, bool BF>
 __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
     constexpr int NT = 64 * NWAVE;
     constexpr int WN = NWAVE / (BM / 64);            // waves along the pixel dimension: 2 -> 4 rows, 4 -> 8 rows
     constexpr int TH = 2 * WN, PR = TH + 2, PLANE = PR * PWB;
-    constexpr int WS = 9 * CK * BM;                  // weight slab floats per chunk
+    // weight slab per chunk, in floats: 9 taps x CK channels x BM fp32 -- or, bf16 variant, 3 MFMAs x 2 lane halves x BM rows of
+    // eight bf16 (16 B: a lane's whole A operand of one MFMA, packed by ptmi_conv3x3_pack_weights_bf16)
+    constexpr int WS = BF ? 24 * BM : 9 * CK * BM;
     constexpr int WPC = WS / 4;                      // ... in 16-B pieces
     constexpr int NWI = (WPC + NT - 1) / NT;
     constexpr int PPC = CK * PR * 10;                // patch pieces per chunk (240 / 400)
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
     const bool row_in = y0 + rb < H;
     const int mode = !row_in ? 0 : (cb + 8 < wv ? 2 : (cb < wv ? 1 : 0));      // pixel blocks with work: 0 / 1 / 2
     const int a_off = wm * 64 + nl + (lane >> 5) * BM;
+    const int a_offb = (lane >> 5) * BM + wm * 64 + nl;         // bf16 slab, in 16-B units: [MFMA t][lane half][row]
     const int b_off = WS + (lane >> 5) * PLANE + (rb + pr) * PWB + cb + pc + 3;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};     // acc[co half][pixel block]
@@ -175,17 +179,19 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
             if constexpr (BF) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    float a0[8], a1[8], b0[8], b1[8];
+                    float b0[8], b1[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int tap = 4 * t + (e >> 1), j = e & 1, ky = tap / 3, kx = tap % 3;
                         const bool on = tap < 9;
-                        a0[e] = on ? wsl[(tap * CK + 2 * j) * BM] : 0.f;
-                        a1[e] = on ? wsl[(tap * CK + 2 * j) * BM + 32] : 0.f;
                         b0[e] = on ? psl[2 * j * PLANE + ky * PWB + kx] : 0.f;
                         b1[e] = (on && MODE == 2) ? psl[2 * j * PLANE + ky * PWB + kx + 8] : 0.f;
                     }
-                    const ptmi_bf16x8 A0 = ptmi_pack_bf16x8(a0), A1 = ptmi_pack_bf16x8(a1), B0 = ptmi_pack_bf16x8(b0);
+                    // A: the slab already holds bf16, eight per (MFMA, lane half, row) -- one 16-B read per operand
+                    const f32x4* asl = reinterpret_cast<const f32x4*>(lds + buf * STAGE) + a_offb + t * 2 * BM;
+                    const ptmi_bf16x8 A0 = __builtin_bit_cast(ptmi_bf16x8, asl[0]);
+                    const ptmi_bf16x8 A1 = __builtin_bit_cast(ptmi_bf16x8, asl[32]);
+                    const ptmi_bf16x8 B0 = ptmi_pack_bf16x8(b0);
                     acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc00, 0, 0, 0);
                     acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc10, 0, 0, 0);
                     if (MODE == 2) {
@@ -466,6 +472,32 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
             else v = w[((size_t)ci * wCin + co) * 9 + (2 - ky) * 3 + (2 - kx)];
         }
         wp[i] = v;
+    }
+}
+// bf16 slab of the bf16-input kernel: [channel tile][chunk][MFMA t (3)][lane half h (2)][row m (BM)][element e (8)] with
+// (tap, channel in chunk) = (4t + e / 2, 2 (e % 2) + h); taps 9-11 are zeros.  Rounded to nearest even.
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int wCout, int wCin,
+                                         int mode, int BM, int coTiles, int nChunks)
+{
+    const int64_t total = (int64_t)coTiles * nChunks * 3 * 2 * BM * 8;
+    const int convCout = mode ? wCin : wCout, convCin = mode ? wCout : wCin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int e = r % 8; r /= 8;
+        const int m = r % BM; r /= BM;
+        const int h = r % 2; r /= 2;
+        const int t = r % 3; r /= 3;
+        const int chunk = r % nChunks;
+        const int cot = r / nChunks;
+        const int tap = 4 * t + (e >> 1), co = cot * BM + m, ci = chunk * 4 + 2 * (e & 1) + h;
+        float v = 0.f;
+        if (tap < 9 && co < convCout && ci < convCin) {
+            const int ky = tap / 3, kx = tap % 3;
+            if (mode == 0) v = w[((size_t)co * wCin + ci) * 9 + tap];
+            else v = w[((size_t)ci * wCin + co) * 9 + (2 - ky) * 3 + (2 - kx)];
+        }
+        wp[i] = (__bf16)v;
     }
 }
 // ------------------------------------------------------------------------------------ wgrad, buffer-DMA pipeline
@@ -955,6 +987,20 @@ int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, 
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, wp, w_cout,
                        w_cin, mode, BM, CK, coTiles, nChunks);
     PTMI_LAUNCH_CHECK("conv3x3_pack_weights");
+    return 0;
+}
+
+int ptmi_conv3x3_pack_weights_bf16(const float* w, float* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(w && wp && w_cout > 0 && w_cin > 0, "conv3x3_pack_weights_bf16: bad args");
+    const int convCout = mode ? w_cin : w_cout, convCin = mode ? w_cout : w_cin;
+    const int BM = ptmi_conv3x3_bm(convCout);
+    const int coTiles = cdiv(convCout, BM), nChunks = cdiv(convCin, 4);
+    const int64_t total = (int64_t)coTiles * nChunks * 3 * 2 * BM * 8;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w,
+                       reinterpret_cast<__bf16*>(wp), w_cout, w_cin, mode, BM, coTiles, nChunks);
+    PTMI_LAUNCH_CHECK("conv3x3_pack_weights_bf16");
     return 0;
 }
 

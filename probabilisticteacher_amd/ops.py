@@ -152,7 +152,9 @@ def conv3x3_pack(w: torch.Tensor, mode: int) -> torch.Tensor:
     conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
     n = _lib.load().ptmi_conv3x3_packed_floats(conv_cin, conv_cout)
     wp = torch.empty(n, dtype=F32, device=w.device)
-    _lib.call("ptmi_conv3x3_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
+    # (the bf16-input kernels take their weights rounded and in MFMA operand order)
+    _lib.call("ptmi_conv3x3_pack_weights_bf16" if _native_bf16() else "ptmi_conv3x3_pack_weights", _ptr(w), _ptr(wp), co,
+              ci, mode, _stream())
     return wp
 
 
