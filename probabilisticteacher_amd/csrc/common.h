@@ -28,6 +28,7 @@ void ptmi_set_error(const char* fmt, ...);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 ptmi_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ptmi_bf16x4 __attribute__((ext_vector_type(4)));
 
 // ---- buffer -> LDS DMA helpers (buffer_load_dword[x4] ... lds) ----------------------------------------------
 // Raw buffer resource over [base, base + bytes): lanes whose offset is >= bytes (e.g. 0xFFFFFFFF) are zero-filled
