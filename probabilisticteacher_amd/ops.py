@@ -146,26 +146,41 @@ def _conv_wgrad_sym() -> str:
 
 
 # ============================================================================ conv 3x3
-def conv3x3_pack(w: torch.Tensor, mode: int) -> torch.Tensor:
+def _bf16_stem_on_valu(conv_cin: int, conv_cout: int, epilogue: int) -> bool:
+    """In native bf16 mode the 3-channel stem layer (the shapes ptmi_conv3x3_fwd sends to its VALU stem kernel) keeps that
+    kernel: x and W are rounded by tensor passes (51 MB and 7 KB at the bench shape) and multiplied in fp32 -- the same
+    numbers as the bf16 MFMA kernel up to summation order, at half its time (K = 27 gives the matrix core nothing to do)."""
+    return _native_bf16() and epilogue in (0, 1) and conv_cin <= 4 and conv_cout <= 64
+
+
+def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int) -> torch.Tensor:
+    """Packed weights for conv3x3_raw(..., epilogue) (mode 0) or for the dgrad launch (mode 1: epilogue 2 / 3)."""
     _chk(w, name="conv weight")
     co, ci = w.shape[0], w.shape[1]
     conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
     n = _lib.load().ptmi_conv3x3_packed_floats(conv_cin, conv_cout)
     wp = torch.empty(n, dtype=F32, device=w.device)
-    # (the bf16-input kernels take their weights rounded and in MFMA operand order)
-    _lib.call("ptmi_conv3x3_pack_weights_bf16" if _native_bf16() else "ptmi_conv3x3_pack_weights", _ptr(w), _ptr(wp), co,
-              ci, mode, _stream())
+    if _bf16_stem_on_valu(conv_cin, conv_cout, epilogue):
+        w = w.to(torch.bfloat16).to(F32)
+        sym = "ptmi_conv3x3_pack_weights"
+    else:   # (the bf16-input kernels take their weights rounded and in MFMA operand order)
+        sym = "ptmi_conv3x3_pack_weights_bf16" if _native_bf16() else "ptmi_conv3x3_pack_weights"
+    _lib.call(sym, _ptr(w), _ptr(wp), co, ci, mode, _stream())
     return wp
 
 
 def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor:
+    """wp = conv3x3_pack(w, mode, epilogue) with the SAME epilogue."""
     _chk(x, name="conv input")
     n, cin, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
     nbytes = 4.0 * (n * h * w * (cin + cout * (2 if epilogue == 3 else 1)) + 9 * cin * cout)
+    stem = _bf16_stem_on_valu(cin, cout, epilogue)
+    if stem:
+        x = x.to(torch.bfloat16).to(F32)
     with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, nbytes):
-        _lib.call(_conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
-                  epilogue, _stream())
+        _lib.call("ptmi_conv3x3_fwd" if stem else _conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n,
+                  cin, cout, h, w, epilogue, _stream())
     return y
 
 
@@ -174,7 +189,7 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     x = _chk(_rnd(x).contiguous(), name="conv input")
     n, cin, h, w = x.shape
     cout = weight.shape[0]
-    wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0)
+    wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0, 4)
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
     with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, 4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout)):
         _lib.call(_conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None, _ptr(y), n, cin, cout, h,
@@ -199,7 +214,7 @@ class _Conv3x3(torch.autograd.Function):
         x = _chk(_rnd(x).contiguous(), name="conv input")
         weight = _chk(_rnd(weight).contiguous(), name="conv weight")
         bias = _chk(bias.contiguous(), name="conv bias")
-        wp = conv3x3_pack(weight, 0)
+        wp = conv3x3_pack(weight, 0, 1 if relu else 0)
         y = conv3x3_raw(x, wp, bias, None, weight.shape[0], 1 if relu else 0)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -222,7 +237,7 @@ class _Conv3x3(torch.autograd.Function):
                 _lib.call(_conv_wgrad_sym(), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
                           _stream())
         if ctx.needs_input_grad[0]:
-            wpd = conv3x3_pack(weight, 1)
+            wpd = conv3x3_pack(weight, 1, 2)
             dx = conv3x3_raw(dz, wpd, None, None, cin, 2)
         return dx, dw, db, None
 
@@ -271,7 +286,7 @@ class _VGGBlock(torch.autograd.Function):
         for j in range(k):
             w, b = _chk(wb[2 * j].contiguous()), _chk(wb[2 * j + 1].contiguous())
             ws.append(w)
-            acts.append(conv3x3_raw(acts[-1], conv3x3_pack(w, 0), b, None, w.shape[0], 1))
+            acts.append(conv3x3_raw(acts[-1], conv3x3_pack(w, 0, 1), b, None, w.shape[0], 1))
         out = acts[-1]
         if pool:
             n, c, h, wd = out.shape
@@ -312,9 +327,9 @@ class _VGGBlock(torch.autograd.Function):
                               wd, 0, _stream())
                 grads[2 * (j - 1)], grads[2 * (j - 1) + 1] = dw, db
             if j > 1:
-                dz = conv3x3_raw(dz, conv3x3_pack(w, 1), None, xin, cin, 3)      # dgrad + ReLU mask of layer j-1
+                dz = conv3x3_raw(dz, conv3x3_pack(w, 1, 3), None, xin, cin, 3)      # dgrad + ReLU mask of layer j-1
             elif ctx.needs_input_grad[0]:
-                dx = conv3x3_raw(dz, conv3x3_pack(w, 1), None, None, cin, 2)
+                dx = conv3x3_raw(dz, conv3x3_pack(w, 1, 2), None, None, cin, 2)
         return (dx, None, *grads)
 
 

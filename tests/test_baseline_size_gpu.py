@@ -168,10 +168,10 @@ def test_conv3_2_at_n48_bench_launch_shape_vs_torch():
     yrelu = F.relu(yr)
     yr.backward(gy)
     xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
-    yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0), bd, None, c, 1)
+    yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0, 1), bd, None, c, 1)
     _rel(yd, yrelu.detach(), 1e-4, "conv3_2 forward n=48")
     del yd
-    dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1), None, xd, c, 3)
+    dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1, 3), None, xd, c, 3)
     _rel(dx, xr.grad * (x > 0), 1e-4, "conv3_2 dgrad + mask n=48")
     del dx
     dw, db = torch.empty_like(wd), torch.empty(c, device=DEV)

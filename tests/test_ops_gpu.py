@@ -697,7 +697,7 @@ def test_conv3x3_stem_flat_mapping(ops, n, cin, cout, h, w, relu):
     yr = F.conv2d(x, wt, b, padding=1)
     if relu:
         yr = F.relu(yr)
-    wp = ops.conv3x3_pack(wt.to(DEV), 0)
+    wp = ops.conv3x3_pack(wt.to(DEV), 0, 1 if relu else 0)
     guard = torch.full((n * cout * h * w + 64,), 7.5, device=DEV)
     yd = guard[:n * cout * h * w].view(n, cout, h, w)
     from probabilisticteacher_amd import _lib
@@ -872,12 +872,15 @@ def test_vgg_block_bf16_native(ops, pool):
                 gy = torch.randn(yd.shape, generator=gen).to(DEV)
             yd.backward(gy)
             fused = ops.conv3x3_relu_pool_nograd(x.to(DEV), ws[0].to(DEV), bs[0].to(DEV))
+            # 3 input channels through the MFMA kernel (fused-pool epilogue: not the VALU stem's case)
+            fused3 = ops.conv3x3_relu_pool_nograd(x[:, :3].contiguous().to(DEV), ws[0][:, :3].contiguous().to(DEV), bs[0].to(DEV))
         finally:
             ops.set_operand_rounding(None)
-        res[mode] = (yd.detach(), xd.grad, [t.grad for t in wd], [t.grad for t in bd], fused)
+        res[mode] = (yd.detach(), xd.grad, [t.grad for t in wd], [t.grad for t in bd], fused, fused3)
     e, nat = res["bf16_emulate"], res["bf16"]
     close(nat[0], e[0], 1e-4, 1e-4, "block fwd")
     close(nat[4], e[4], 1e-4, 1e-4, "fused conv+relu+pool")
+    close(nat[5], e[5], 1e-4, 1e-4, "fused conv+relu+pool, 3 input channels")
     close(nat[1], e[1], 2e-3, 2e-3, "block dx")        # (a handful of ReLU-mask flips between the two summation orders)
     for i in range(3):
         close(nat[2][i], e[2][i], 5e-3, 5e-3, f"block dw{i}")

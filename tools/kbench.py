@@ -55,7 +55,7 @@ def main():
         b = torch.zeros(cout, device=dev)
         fl = 2.0 * 9 * cin * cout * h * w * a.n
         if "conv" in which:
-            wp = ops.conv3x3_pack(wt, 0)
+            wp = ops.conv3x3_pack(wt, 0, 1)
             ms = timeit(lambda: ops.conv3x3_raw(x, wp, b, None, cout, 1), a.iters)
             print(f"{name:8s} fwd   n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}")
         if "wgrad" in which and cin >= 64:
