@@ -341,6 +341,37 @@ def test_nms_bit_exact(ops, counts, thr, max_keep):
         assert torch.equal(keep[i, :k].cpu().long(), ref), f"image {i}: keep lists differ"
 
 
+@pytest.mark.parametrize("thr", [0.5, 0.7, 0.3])
+def test_nms_iou_at_the_threshold(ops, thr):
+    """Pairs of boxes whose IoU equals the threshold exactly (integer boxes: inter / union = thr) or misses it by a few
+    ulps of one coordinate: the kernel decides most pairs from `inter` vs `thr * union` and divides only when that cannot
+    decide -- the suppression decisions must stay those of the correctly rounded fp32 quotient (strict `>`), bit for bit."""
+    rs = np.random.RandomState(int(thr * 100))
+    num, den = {0.5: (1, 2), 0.7: (7, 10), 0.3: (3, 10)}[thr]
+    boxes = []
+    for k in range(400):
+        # A = [x, y, x + den * s, y + 1 * t]; B overlaps A on `num` of its `den` columns and has the same size:
+        # inter = num s t, union = (2 den - num) s t -> generalise: choose B so that inter / union = num / den
+        s_, t_ = float(rs.randint(1, 40)), float(rs.randint(1, 30))
+        x, y = float(rs.randint(0, 500) + 1000 * (k % 20)), float(rs.randint(0, 300) + 1000 * (k // 20))
+        # A has width den*s, B = A's sub-box of width num*s (inside A): inter = area(B), union = area(A) -> IoU = num/den
+        a = np.array([x, y, x + den * s_, y + t_], np.float32)
+        b = np.array([x, y, x + num * s_, y + t_], np.float32)
+        j = rs.randint(0, 5)
+        if j:                                         # move one coordinate of B by -2 .. +2 ulps
+            c = rs.randint(0, 4)
+            for _ in range(abs(j - 2) if j != 2 else 0):
+                b[c] = np.nextafter(b[c], np.float32(np.inf if j > 2 else -np.inf))
+        boxes += [a, b]
+    b = torch.from_numpy(np.stack(boxes))
+    n = b.shape[0]
+    ref = d2.nms(b, torch.arange(n, 0, -1).float(), thr)
+    keep, cnt = ops.nms_batched(b.to(DEV), torch.tensor([0, n], dtype=torch.int32, device=DEV), n, thr, n)
+    k = int(cnt[0])
+    assert k == len(ref) and torch.equal(keep[0, :k].cpu().long(), ref), f"kept {k} vs {len(ref)}"
+    assert 0 < n - k < n // 2 + 1                     # some pairs suppress, some do not
+
+
 def test_nms_no_candidates_at_all(ops):
     """every image of the batch has zero candidates (a teacher without any detection above the score threshold)"""
     seg = torch.zeros(4, dtype=torch.int32, device=DEV)
