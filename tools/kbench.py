@@ -72,7 +72,7 @@ def main():
             print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}")
         del x
     if "gemm" in which:
-        for r in (512 * a.n, 2000 * a.n):
+        for r in (512 * a.n, 1024 * a.n, 2000 * a.n):
             xx = torch.randn(r, 25088, device=dev)
             w1 = torch.randn(1024, 25088, device=dev) * 0.01
             b1 = torch.zeros(1024, device=dev)
