@@ -59,6 +59,8 @@ def close(a, b, rtol, atol, what=""):
     (1, 32, 128, 6, 36, True),      # last tile 4 wide
     (3, 32, 64, 4, 3, True),        # narrower than one 16-B piece
     (1, 40, 130, 1, 70, True),      # a single row: top and bottom halo at once
+    (1, 16, 64, 9, 701, True),      # W >= 600: 1 x 32 pixel blocks (row-major variant), odd height, ragged right edge
+    (2, 32, 130, 5, 640, False),    # ... 128-channel tiles, exact tile columns, partial channel tile
 ])
 def test_conv3x3_fwd_bwd(ops, n, cin, cout, h, w, relu):
     gen = g(n * 1000 + cin + cout + h)
@@ -624,7 +626,8 @@ def test_preprocess_and_shrink_paste(ops):
         assert torch.equal(o.cpu(), _paste_ref(cfg, im, ratio)[0]), f"batched shrink_paste ratio {ratio}"
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 37, 45), (1, 128, 128, 20, 83), (1, 3, 64, 24, 33)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 37, 45), (1, 128, 128, 20, 83), (1, 3, 64, 24, 33),
+                                            (1, 16, 64, 11, 666), (1, 8, 130, 6, 601)])      # wide: row-major blocks
 def test_conv3x3_fused_relu_pool(ops, n, cin, cout, h, w):
     gen = g(cin + h)
     x = torch.randn(n, cin, h, w, generator=gen)
