@@ -73,6 +73,20 @@ int ptmi_conv3x3_fwd_bf16(const float* x, const float* wp, const float* bias, co
                           ptmi_stream_t s);
 int ptmi_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws,
                             int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
+/* Fused Winograd F(2x2,3x3) variant of ptmi_conv3x3_fwd for the 64..512-channel layers (conv1_2 .. conv5_3 at
+ * pt/modeling/backbone/vgg.py:45-53,66-69 and the RPN 3x3 conv at pt/modeling/proposal_generator/rpn.py:96; cuDNN, which
+ * the reference runs there, uses Winograd for these fp32 3x3 s1 layers too).  Same arguments, epilogues and dgrad
+ * convention (mode 1 pack) as ptmi_conv3x3_fwd; fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32, 16 instead of 36
+ * multiplies per 2x2 output tile and channel pair.  Input transform (B^T d B), the 16 transform-domain GEMMs and the
+ * output transform (A^T M A) run in ONE kernel; only x, the packed weights and y touch HBM.
+ * Packed weights (ptmi_conv3x3_wino_pack_weights): U = G g G^T as
+ * [ceil(Cout/64)][ceil(Cin/8)][8 ci][4 (position row)][64 co][4 (position column)] fp32, zero padded. */
+int64_t ptmi_conv3x3_wino_packed_floats(int cin, int cout);
+int ptmi_conv3x3_wino_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode,
+                                   ptmi_stream_t s);
+int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                          float* y, int n, int cin, int cout, int h, int w, int epilogue,
+                          ptmi_stream_t s);
 /* dz = dy * (y > 0), elementwise (ReLU backward; F.relu_ at vgg.py:67). In-place allowed. */
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s);
 

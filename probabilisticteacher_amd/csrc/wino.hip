@@ -1,0 +1,463 @@
+// wino.hip -- fused Winograd F(2x2, 3x3) convolution for gfx950 (CDNA4): 3x3 s1 p1, fp32 in / fp32 accumulate on
+// v_mfma_f32_32x32x2_f32, forward and dgrad of the 64..512-channel layers.
+//
+// Replaces the cuDNN conv2d (+bias, +ReLU) the reference reaches at pt/modeling/backbone/vgg.py:45-53,66-69 (conv1_2 ..
+// conv5_3) and the 3x3 conv of D2's StandardRPNHead (pt/modeling/proposal_generator/rpn.py:96) -- cuDNN itself runs these
+// fp32 3x3 s1 layers as Winograd.  The direct implicit-GEMM kernel of conv.hip sits at 0.88 of the fp32 MFMA peak; the
+// only way past that roof is fewer multiplies: F(2x2,3x3) needs 16 instead of 36 per 2x2 output tile and channel pair.
+//
+// One kernel, nothing in HBM but x, the pre-transformed weights and y:
+//   * transform domain: for each of the 16 positions p = (i, j) of the 4x4 tile, M_p[co][tile] = sum_ci U_p[co][ci] V_p[ci][tile]
+//     with U = G g G^T (packed once per call by wino_pack_weights_kernel), V = B^T d B (computed per lane from LDS) and
+//     Y = A^T M A (epilogue, in registers);
+//   * a workgroup = 4 wave64s owns 64 output channels x (8 rows x 32 columns) of one image = 64 tiles; a wave owns
+//     32 channels x 32 tiles (16 tile columns x 2 tile rows) x 16 positions = sixteen 32x32 accumulator tiles = 256
+//     accumulator registers: ONE wave per SIMD, the whole unified register file of it (512 per lane);
+//   * v_mfma_f32_32x32x2_f32 takes A[co = lane & 31][k = lane >> 5] and B[k = lane >> 5][tile = lane & 31]: a lane IS one
+//     (tile, channel) pair, so it reads its own 4x4 input window from the LDS patch (twelve 8-byte reads), applies B^T d B
+//     with 32 additions and holds the B operands of all 16 positions' MFMAs -- no cross-lane movement, no transform-domain
+//     tensor anywhere.  The A operands of the 16 positions are 64 contiguous bytes per (channel, ci) in the packed slab
+//     (four ds_read_b128);
+//   * K is walked in 8-channel chunks (four k-steps of 2 channels = 64 MFMAs = 4096 matrix-pipe cycles per wave and chunk),
+//     double buffered in LDS, operands arrive with `buffer_load_dwordx4 ... lds` (per-lane offsets are loop invariants;
+//     halo rows / columns and padded channels carry offset 0xFFFFFFFF and are zero-filled by the buffer range check), ONE
+//     workgroup barrier per chunk, placed inside the last k-step's MFMA stream whose operands are already in registers;
+//   * the next k-step's LDS reads and input transform are issued between the current k-step's MFMAs (software pipeline in
+//     source order, pinned with sched_barrier): with one wave per SIMD nothing else hides them;
+//   * epilogue: inverse transform in registers (the 16 positions of a (channel, tile) pair live in the same lane and register
+//     index of the 16 accumulator tiles), then the epilogues of conv.hip: bias / bias+ReLU / none / ReLU mask of the
+//     producer (dgrad) / bias+ReLU+2x2 max pool (a Winograd tile IS a pool window).
+// dgrad = the same kernel on dY with the flipped / transposed filter (pack mode 1), as in conv.hip.
+
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) f32x2 wlds_f32x2_t;
+typedef __attribute__((address_space(3))) f32x4 wlds_f32x4_t;
+typedef __attribute__((address_space(3))) void wlds_void_t;
+
+constexpr int WKC = 8;                 // input channels per chunk
+constexpr int WBM = 64;                // output channels per workgroup
+constexpr int WTH = 8, WTW = 32;       // output pixels per workgroup: 8 rows x 32 columns = 4 x 16 Winograd tiles
+constexpr int WPP = 48;                // patch row pitch in floats: 10 loaded 16-B pieces (image columns x0-4 .. x0+35) + 2 pad
+                                       // pieces; 2 rows = 96 floats = 32 banks (mod 64): the two tile rows of a wave read
+                                       // disjoint bank halves with ds_read_b64
+constexpr int WPR = WTH + 2;           // patch rows (image rows y0-1 .. y0+8)
+constexpr int WPL = WPR * WPP;         // floats per channel plane (480)
+constexpr int WUS = WKC * 4 * WBM * 4; // U floats per chunk: [ci 8][position row i 4][co 64][position column j 4] = 8192
+constexpr int WPS = WKC * WPL;         // patch floats per chunk (3840 = 960 pieces = 15 waves' worth)
+constexpr int WSTAGE = WUS + WPS;      // 12032 floats = 47 KB; two stages
+constexpr int WNT = 256;
+constexpr int WUI = WUS / 4 / WNT;     // U DMA instructions per lane and chunk (8)
+constexpr int WPI = (WPS / 4 + WNT - 1) / WNT;   // patch DMA instructions per lane and chunk (4; the last one waves 0-2 only)
+
+__device__ __forceinline__ void wino_vmwait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// V = B^T d B for the lane's (tile, channel): d rows a = 0..3 arrive as three 8-byte reads each, D[3a + t] = LDS columns
+// 2 ttx + 2 + 2t, + 1; the window's columns b = 0..3 are elements 1..4 of that row of six.
+__device__ __forceinline__ void wino_xform(const f32x2 (&D)[12], float (&V)[16])
+{
+    float t[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float d0 = ((b + 1) & 1) ? D[0 + ((b + 1) >> 1)][1] : D[0 + ((b + 1) >> 1)][0];
+        const float d1 = ((b + 1) & 1) ? D[3 + ((b + 1) >> 1)][1] : D[3 + ((b + 1) >> 1)][0];
+        const float d2 = ((b + 1) & 1) ? D[6 + ((b + 1) >> 1)][1] : D[6 + ((b + 1) >> 1)][0];
+        const float d3 = ((b + 1) & 1) ? D[9 + ((b + 1) >> 1)][1] : D[9 + ((b + 1) >> 1)][0];
+        t[0][b] = d0 - d2;
+        t[1][b] = d1 + d2;
+        t[2][b] = d2 - d1;
+        t[3][b] = d1 - d3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        V[4 * i + 0] = t[i][0] - t[i][2];
+        V[4 * i + 1] = t[i][1] + t[i][2];
+        V[4 * i + 2] = t[i][2] - t[i][1];
+        V[4 * i + 3] = t[i][1] - t[i][3];
+    }
+}
+
+__global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * WSTAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // grid = (coTiles, N * tilesY, tilesX) as conv.hip: the channel tiles of a pixel tile are neighbours in time (shared
+    // patch in L2 / MALL) and, with 8 channel tiles, each XCD (linear id mod 8) keeps ONE channel tile's U slabs in its L2
+    const int cot = blockIdx.x;
+    const int ty = blockIdx.y / N, n = blockIdx.y - ty * N;
+    const int tx = blockIdx.z;
+    const int x0 = tx * WTW, y0 = ty * WTH;
+    const int HW = H * W;
+    const int wv = W - x0;                                   // valid columns right of x0 (> 0)
+
+    // ---- DMA descriptors: this lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first plane
+    unsigned pvoff[WPI];
+    int fix = 0;                                             // words 1..3 of piece i (bits 4i+1 .. 4i+3) beyond the image edge
+#pragma unroll
+    for (int i = 0; i < WPI; ++i) {
+        const int pidx = tid + i * WNT;
+        const int ci = pidx / (WPR * 12), rem = pidx - ci * (WPR * 12);
+        const int r = rem / 12, q = rem - r * 12;
+        const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+        pvoff[i] = 0xFFFFFFFFu;
+        if (pidx < WPS / 4 && q < 10 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            pvoff[i] = (unsigned)(ci * HW + gy * W + gx) * 4u;
+#pragma unroll
+            for (int e = 1; e < 4; ++e) fix |= (gx + e >= W) ? (1 << (4 * i + e)) : 0;
+        }
+    }
+    const unsigned wvoff = (unsigned)tid * 16u;
+    const bool edge = wv < 36;                               // some loaded piece may straddle the right image edge
+
+    const char* xc = (const char*)(x + (size_t)n * Cin * HW);
+    const char* wc = (const char*)(wp + (size_t)cot * nChunks * WUS);
+    unsigned xleft = (unsigned)Cin * (unsigned)HW * 4u;      // bytes from xc to the end of image n (< 2^32: launcher)
+
+    // one DMA instruction of a chunk: idx 0 .. WPI-1 = patch pieces, WPI .. WPI+WUI-1 = U pieces
+    auto dma_piece = [&](int idx, int buf) {
+        if (idx < WPI) {
+            if ((idx + 1) * WNT * 4 <= WPS || wave * 64 + idx * WNT < WPS / 4) {     // wave-uniform (WPS / 4 is a multiple of 64)
+                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                    ptmi_uniform_ptr(xc), 0, __builtin_amdgcn_readfirstlane((int)xleft), 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (wlds_void_t*)(lds + buf * WSTAGE + WUS + wave * 256 + idx * WNT * 4),
+                                                         16, (int)pvoff[idx], 0, 0, 0);
+            }
+        } else {
+            const int i = idx - WPI;
+            const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(wc), 0, WUS * 4, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (wlds_void_t*)(lds + buf * WSTAGE + wave * 256 + i * WNT * 4), 16,
+                                                     (int)wvoff, i * WNT * 16, 0, 0);
+        }
+    };
+    auto advance = [&]() {
+        wc += WUS * 4;
+        xc += (size_t)WKC * HW * 4;
+        xleft -= (unsigned)WKC * (unsigned)HW * 4u;
+    };
+    auto issue = [&](int buf) {
+#pragma unroll
+        for (int idx = 0; idx < WPI + WUI; ++idx) dma_piece(idx, buf);
+        advance();
+    };
+    auto fixup = [&](int buf) {
+        if (edge && fix) {
+            float* pw = lds + buf * WSTAGE + WUS + tid * 4;
+#pragma unroll
+            for (int i = 0; i < WPI; ++i) {
+#pragma unroll
+                for (int e = 1; e < 4; ++e)
+                    if (fix & (1 << (4 * i + e))) pw[i * WNT * 4 + e] = 0.f;
+            }
+        }
+    };
+
+    // ---- the lane's role in the MFMAs
+    const int wm = wave >> 1, wn = wave & 1;                 // channel half (32) / row half (4 rows = 2 tile rows) of the tile
+    const int nl = lane & 31, kh = lane >> 5;
+    const int ttx = nl & 15, tty = nl >> 4;                  // tile column / row inside the wave's 16 x 2 tiles
+    const bool active = y0 + 4 * wn < H;                     // (wave-uniform) some of the wave's rows lie inside the image
+    const int a_off = kh * (4 * WBM * 4) + (wm * 32 + nl) * 4;                               // + ks * 2048 + i * 256
+    const int b_off = WUS + kh * WPL + (wn * 4 + tty * 2) * WPP + 2 * ttx + 2;              // + ks * 960 + a * 48 + 2 t
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
+
+    if (active) {
+        f32x4 A0[4], A1[4];
+        f32x2 D0[12], D1[12];
+        float V0[16], V1[16];
+        float tt[4][4];
+        // One k-step = 16 MFMAs on (A, V), one per position, with the rest of the wave's work placed between them (one
+        // wave per SIMD: whatever is not issued in the shadow of an MFMA leaves the matrix pipe idle):
+        //   P = 0      the next k-step's four A reads -- in the chunk's LAST k-step first the hand-over: own DMA pieces of
+        //              the next chunk landed, edge fix-ups, workgroup barrier (its operands are already in registers)
+        //   P = 1..3   the next k-step's twelve window reads
+        //   P = 4..7   one DMA instruction each for the NEXT chunk (k-steps 0..2 carry its 4 + 8 instructions); the buffer
+        //              they fill was released by the previous hand-over barrier
+        //   P = 8..11  input transform, rows;   P = 12..15  input transform, columns
+        auto kstep = [&](auto ks_c, const f32x4 (&A)[4], const float (&V)[16], f32x4 (&An)[4], f32x2 (&Dn)[12], float (&Vn)[16],
+                         int buf, bool more) {
+            constexpr int KS = decltype(ks_c)::value;
+            const float* src = lds + (KS < 3 ? buf : buf ^ 1) * WSTAGE;
+            const float* ap = src + a_off + ((KS + 1) & 3) * (2 * 4 * WBM * 4);
+            const float* bp = src + b_off + ((KS + 1) & 3) * (2 * WPL);
+            const bool next = KS < 3 || more;
+            auto step = [&](auto p_c) {
+                constexpr int P = decltype(p_c)::value;
+                acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], V[P], acc[P], 0, 0, 0);
+                if constexpr (P == 0) {
+                    if (KS == 3 && more) {
+                        wino_vmwait0();
+                        fixup(buf ^ 1);
+                        __syncthreads();
+                    }
+                    if (next) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) An[i] = *(const volatile wlds_f32x4_t*)(ap + i * (WBM * 4));
+                    }
+                }
+                if constexpr (P >= 1 && P <= 3) {
+                    if (next) {
+#pragma unroll
+                        for (int e = 4 * (P - 1); e < 4 * P; ++e)
+                            Dn[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3));
+                    }
+                }
+                if constexpr (P >= 4 && P <= 7 && KS < 3) {
+                    if (more) dma_piece(KS * 4 + (P - 4), buf ^ 1);
+                    if (P == 7 && KS == 2 && more) advance();
+                }
+                if constexpr (P >= 8 && P <= 11) {
+                    if (next) {
+                        constexpr int b = P - 8, k = b + 1;
+                        const float d0 = Dn[0 + (k >> 1)][k & 1], d1 = Dn[3 + (k >> 1)][k & 1];
+                        const float d2 = Dn[6 + (k >> 1)][k & 1], d3 = Dn[9 + (k >> 1)][k & 1];
+                        tt[0][b] = d0 - d2;
+                        tt[1][b] = d1 + d2;
+                        tt[2][b] = d2 - d1;
+                        tt[3][b] = d1 - d3;
+                    }
+                }
+                if constexpr (P >= 12) {
+                    if (next) {
+                        constexpr int i = P - 12;
+                        Vn[4 * i + 0] = tt[i][0] - tt[i][2];
+                        Vn[4 * i + 1] = tt[i][1] + tt[i][2];
+                        Vn[4 * i + 2] = tt[i][2] - tt[i][1];
+                        Vn[4 * i + 3] = tt[i][1] - tt[i][3];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});  step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{});  step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{});  step(std::integral_constant<int, 9>{});
+            step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+            step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+            step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+        };
+
+        issue(0);
+        wino_vmwait0();
+        fixup(0);
+        __syncthreads();
+        {   // operands of the first k-step
+            const float* ap = lds + a_off;
+            const float* bp = lds + b_off;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A0[i] = *(const volatile wlds_f32x4_t*)(ap + i * (WBM * 4));
+#pragma unroll
+            for (int e = 0; e < 12; ++e) D0[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3));
+            wino_xform(D0, V0);
+        }
+        for (int chunk = 0; chunk < nChunks; ++chunk) {
+            const int buf = chunk & 1;
+            const bool more = chunk + 1 < nChunks;
+            kstep(std::integral_constant<int, 0>{}, A0, V0, A1, D1, V1, buf, more);
+            kstep(std::integral_constant<int, 1>{}, A1, V1, A0, D0, V0, buf, more);
+            kstep(std::integral_constant<int, 2>{}, A0, V0, A1, D1, V1, buf, more);
+            kstep(std::integral_constant<int, 3>{}, A1, V1, A0, D0, V0, buf, more);
+        }
+    } else {
+        // a wave whose rows all lie below the image: same DMA issue / wait / barrier sequence, no MFMAs
+        issue(0);
+        wino_vmwait0();
+        fixup(0);
+        __syncthreads();
+        for (int chunk = 0; chunk + 1 < nChunks; ++chunk) {
+            issue((chunk & 1) ^ 1);
+            wino_vmwait0();
+            fixup((chunk & 1) ^ 1);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- epilogue: Y = A^T M A per (channel, tile) in registers, then bias / ReLU / mask / pool and buffer stores.
+    // Accumulator element r of a lane: channel (r & 3) + 8 (r >> 2) + 4 kh of the wave's 32, tile nl.
+    const int py = y0 + wn * 4 + tty * 2, px = x0 + ttx * 2;          // the tile's first output pixel
+    const int half4 = 4 * kh;
+    const int co_w = cot * WBM + wm * 32;                              // wave-uniform first channel
+    const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
+    f32x4 bv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bv[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (epi <= 1 || epi == 4)
+            bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, half4 * 4, (co_w + g * 8) * 4, 0));
+    }
+    auto inverse = [&](int r, float (&o)[4]) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = (acc[j][r] + acc[4 + j][r]) + acc[8 + j][r];
+            s1[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
+        }
+        o[0] = (s0[0] + s0[1]) + s0[2];
+        o[1] = (s0[1] - s0[2]) - s0[3];
+        o[2] = (s1[0] + s1[1]) + s1[2];
+        o[3] = (s1[1] - s1[2]) - s1[3];
+    };
+    if (epi == 4) {
+        // bias + ReLU + 2x2/2 max pool (floor mode): the tile's four outputs are one pool window
+        const int OH = H >> 1, OW = W >> 1, OHW = OH * OW;
+        const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)Cout * (unsigned)OHW * 4u);
+        const int oy = py >> 1, ox = px >> 1;
+        const unsigned pv = (oy < OH && ox < OW) ? (unsigned)(half4 * OHW + oy * OW + ox) * 4u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int soff = (co_w + (r & 3) + 8 * (r >> 2)) * OHW * 4;
+            const float b = bv[r >> 2][r & 3];
+            float o[4];
+            inverse(r, o);
+            const float m = fmaxf(fmaxf(fmaxf(o[0] + b, o[1] + b), fmaxf(o[2] + b, o[3] + b)), 0.f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ry, (int)pv, soff, 0);
+        }
+        return;
+    }
+    const unsigned img_bytes = (unsigned)Cout * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * HW, img_bytes);
+    const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(epi == 3 ? mref + (size_t)n * Cout * HW : y, epi == 3 ? img_bytes : 0u);
+    // per-lane byte offsets of the tile's two rows: pair = both columns inside the image (8-byte access), single = only
+    // the first one (odd W, last column)
+    unsigned pv2[2], pv1[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const bool rok = py + a < H;
+        const unsigned o = (unsigned)(half4 * HW + (py + a) * W + px) * 4u;
+        pv2[a] = (rok && px + 1 < W) ? o : 0xFFFFFFFFu;
+        pv1[a] = (rok && px + 1 == W) ? o : 0xFFFFFFFFu;
+    }
+    const bool odd_edge = (W & 1) && x0 + WTW > W;                     // (workgroup-uniform) a lane may hold a single column
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int soff = (co_w + (r & 3) + 8 * (r >> 2)) * HW * 4;
+        const float b = bv[r >> 2][r & 3];
+        float o[4];
+        inverse(r, o);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float v0 = o[2 * a], v1 = o[2 * a + 1];
+            if (epi <= 1) {
+                v0 += b;
+                v1 += b;
+                if (epi == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+            } else if (epi == 3) {
+                const f32x2 mk = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)pv2[a], soff, 0));
+                float m0 = mk[0];
+                if (odd_edge) {
+                    const float ms = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)pv1[a], soff, 0));
+                    m0 = (pv1[a] != 0xFFFFFFFFu) ? ms : m0;
+                }
+                v0 = (m0 > 0.f) ? v0 : 0.f;
+                v1 = (mk[1] > 0.f) ? v1 : 0.f;
+            }
+            const f32x2 st = {v0, v1};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, st), ry, (int)pv2[a], soff, 0);
+            if (odd_edge) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, (int)pv1[a], soff, 0);
+        }
+    }
+}
+
+// U = G g G^T with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], laid out as the kernel's LDS image:
+// [channel tile (64)][chunk (8 ci)][ci][position row i][co][position column j].  mode as ptmi_conv3x3_pack_weights.
+__global__ void wino_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int wCout, int wCin, int mode,
+                                         int coTiles, int nChunks)
+{
+    const int64_t total = (int64_t)coTiles * nChunks * WKC * WBM;
+    const int convCout = mode ? wCin : wCout, convCin = mode ? wCout : wCin;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = idx;
+        const int col = t % WBM; t /= WBM;
+        const int cil = t % WKC; t /= WKC;
+        const int chunk = t % nChunks;
+        const int cot = t / nChunks;
+        const int co = cot * WBM + col, ci = chunk * WKC + cil;
+        float g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float v = 0.f;
+                if (co < convCout && ci < convCin)
+                    v = mode == 0 ? w[((size_t)co * wCin + ci) * 9 + ky * 3 + kx]
+                                  : w[((size_t)ci * wCin + co) * 9 + (2 - ky) * 3 + (2 - kx)];
+                g[ky][kx] = v;
+            }
+        }
+        float r[4][3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            r[0][kx] = g[0][kx];
+            r[1][kx] = 0.5f * ((g[0][kx] + g[1][kx]) + g[2][kx]);
+            r[2][kx] = 0.5f * ((g[0][kx] - g[1][kx]) + g[2][kx]);
+            r[3][kx] = g[2][kx];
+        }
+        float* dst = wp + ((size_t)(cot * nChunks + chunk) * WKC + cil) * (4 * WBM * 4) + col * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 u;
+            u[0] = r[i][0];
+            u[1] = 0.5f * ((r[i][0] + r[i][1]) + r[i][2]);
+            u[2] = 0.5f * ((r[i][0] - r[i][1]) + r[i][2]);
+            u[3] = r[i][2];
+            *reinterpret_cast<f32x4*>(dst + i * (WBM * 4)) = u;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ptmi_conv3x3_wino_packed_floats(int cin, int cout)
+{
+    return (int64_t)cdiv(cout, WBM) * cdiv(cin, WKC) * WUS;
+}
+
+int ptmi_conv3x3_wino_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(w && wp && w_cout > 0 && w_cin > 0, "conv3x3_wino_pack_weights: bad args");
+    const int convCout = mode ? w_cin : w_cout, convCin = mode ? w_cout : w_cin;
+    const int coTiles = cdiv(convCout, WBM), nChunks = cdiv(convCin, WKC);
+    const int64_t total = (int64_t)coTiles * nChunks * WKC * WBM;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(wino_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, wp, w_cout, w_cin, mode,
+                       coTiles, nChunks);
+    PTMI_LAUNCH_CHECK("conv3x3_wino_pack_weights");
+    return 0;
+}
+
+int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
+                          int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino_fwd: bad args");
+    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_wino_fwd: bad epilogue %d", epilogue);
+    PTMI_CHECK_ARG((int64_t)(cin + WKC) * h * w * 4 < (1ll << 32) && ((int64_t)cout + WBM) * h * w * 4 < (1ll << 32) &&
+                   (int64_t)n * cdiv(h, WTH) < 65536 && cdiv(w, WTW) < 65536,
+                   "conv3x3_wino_fwd: image too large for 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d)", n, cin,
+                   cout, h, w);
+    PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_wino_fwd: bias required for epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue != 4 || bias, "conv3x3_wino_fwd: bias required for epilogue 4");
+    PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_wino_fwd: mask_ref required for epilogue 3");
+    const int tilesX = cdiv(w, WTW), tilesY = cdiv(h, WTH), coTiles = cdiv(cout, WBM), nChunks = cdiv(cin, WKC);
+    const dim3 grid((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
+    hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n, cin, cout, h, w,
+                       nChunks, epilogue);
+    PTMI_LAUNCH_CHECK("conv3x3_wino_fwd");
+    return 0;
+}
+
+}  // extern "C"

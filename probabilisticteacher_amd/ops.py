@@ -146,6 +146,25 @@ def _conv_wgrad_sym() -> str:
 
 
 # ============================================================================ conv 3x3
+# Forward / dgrad algorithm of the fp32 3x3 layers: "auto" = fused Winograd F(2x2,3x3) (csrc/wino.hip) wherever the
+# input has enough channels to amortise its per-workgroup prologue, the direct implicit GEMM (csrc/conv.hip) for the
+# 3-channel stem; "direct" = the direct kernel everywhere (comparison runs, tests).  The bf16 modes keep the direct
+# kernels (their parity statement -- products of rounded operands are exact in fp32 -- does not survive a transform).
+_CONV_ALGO = "auto"
+_WINO_MIN_CIN = 32
+
+
+def set_conv_algo(mode: str) -> None:
+    global _CONV_ALGO
+    if mode not in ("auto", "direct"):
+        raise ValueError(f"unknown conv algorithm {mode!r}")
+    _CONV_ALGO = mode
+
+
+def _use_wino(conv_cin: int) -> bool:
+    return _CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and conv_cin >= _WINO_MIN_CIN
+
+
 def _bf16_stem_on_valu(conv_cin: int, conv_cout: int, epilogue: int) -> bool:
     """In native bf16 mode the 3-channel stem layer (the shapes ptmi_conv3x3_fwd sends to its VALU stem kernel) keeps that
     kernel: x and W are rounded by tensor passes (51 MB and 7 KB at the bench shape) and multiplied in fp32 -- the same
@@ -158,6 +177,11 @@ def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int) -> torch.Tensor:
     _chk(w, name="conv weight")
     co, ci = w.shape[0], w.shape[1]
     conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
+    if _use_wino(conv_cin):
+        n = _lib.load().ptmi_conv3x3_wino_packed_floats(conv_cin, conv_cout)
+        wp = torch.empty(n, dtype=F32, device=w.device)
+        _lib.call("ptmi_conv3x3_wino_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
+        return wp
     n = _lib.load().ptmi_conv3x3_packed_floats(conv_cin, conv_cout)
     wp = torch.empty(n, dtype=F32, device=w.device)
     if _bf16_stem_on_valu(conv_cin, conv_cout, epilogue):
@@ -175,6 +199,11 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     n, cin, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
     nbytes = 4.0 * (n * h * w * (cin + cout * (2 if epilogue == 3 else 1)) + 9 * cin * cout)
+    if _use_wino(cin):
+        with _prof("conv3x3_wino", 2.0 * 9 * cin * cout * h * w * n, nbytes):
+            _lib.call("ptmi_conv3x3_wino_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
+                      epilogue, _stream())
+        return y
     stem = _bf16_stem_on_valu(cin, cout, epilogue)
     if stem:
         x = x.to(torch.bfloat16).to(F32)
@@ -191,9 +220,11 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     cout = weight.shape[0]
     wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0, 4)
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
-    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, 4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout)):
-        _lib.call(_conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None, _ptr(y), n, cin, cout, h,
-                  w, 4, _stream())
+    wino = _use_wino(cin)
+    with _prof("conv3x3_wino" if wino else "conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n,
+               4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout)):
+        _lib.call("ptmi_conv3x3_wino_fwd" if wino else _conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None,
+                  _ptr(y), n, cin, cout, h, w, 4, _stream())
     return y
 
 

@@ -1,0 +1,132 @@
+"""GPU parity tests (pytest -m gpu) of the fused Winograd F(2x2,3x3) kernel (csrc/wino.hip) through the C ABI:
+every epilogue, forward and dgrad packs, against stock torch CPU fp32 conv2d AND against the direct kernel of conv.hip.
+
+Tolerance: 1e-4 relative + 1e-4 of the tensor's scale -- the same bar as the direct kernel's tests (the transforms add a
+few fp32 roundings per output; measured differences are ~1e-6 of the scale)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"{what}: max abs err {err.max():.3e}, max |ref| {np.abs(b).max():.3e}, " \
+                               f"{int((err > tol).sum())} of {err.size} off, first at {np.argwhere(err > tol)[0]}"
+
+
+def _wino(x, wt, bias, mask, epilogue, mode=0):
+    """ptmi_conv3x3_wino_pack_weights + ptmi_conv3x3_wino_fwd on device tensors"""
+    from probabilisticteacher_amd import _lib, ops
+    call, ptr, stream = _lib.call, ops._ptr, ops._stream
+    co, ci = wt.shape[0], wt.shape[1]
+    conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
+    n, cin, h, w = x.shape
+    assert cin == conv_cin
+    wp = torch.empty(_lib.load().ptmi_conv3x3_wino_packed_floats(conv_cin, conv_cout), device=DEV)
+    call("ptmi_conv3x3_wino_pack_weights", ptr(wt), ptr(wp), co, ci, mode, stream())
+    y = torch.full((n, conv_cout, h // 2, w // 2) if epilogue == 4 else (n, conv_cout, h, w), float("nan"), device=DEV)
+    call("ptmi_conv3x3_wino_fwd", ptr(x), ptr(wp), ptr(bias), ptr(mask), ptr(y), n, conv_cin, conv_cout, h, w, epilogue,
+         stream())
+    return y
+
+
+SHAPES = [
+    (1, 8, 64, 8, 32),        # one chunk, one workgroup, exact tile
+    (1, 16, 64, 8, 32),       # two chunks (double buffer hand-over)
+    (2, 64, 64, 24, 40),      # several tiles, second tile column 8 wide
+    (2, 64, 128, 19, 35),     # odd H and W: single-column lane at the right edge, rows below the image
+    (1, 128, 256, 13, 33),
+    (1, 256, 512, 9, 83),     # W = 83 as the 1333x800 block-5 map
+    (1, 20, 70, 11, 17),      # channel counts that are not multiples of the chunk / channel tile
+    (1, 32, 128, 5, 166),     # W = 166 / 333: 16-B pieces straddling the right image edge
+    (2, 32, 128, 3, 333),     # H = 3: the lower wave pair of every workgroup is idle
+    (1, 40, 130, 1, 70),      # a single row
+    (3, 32, 64, 4, 3),        # narrower than one 16-B piece
+    (1, 5, 7, 2, 1),          # one column
+    (1, 24, 64, 50, 83),      # the block-5 map itself (7 x 3 workgroups, ragged both ways)
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
+def test_wino_forward_epilogues(n, cin, cout, h, w):
+    gen = g(n * 1000 + cin + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    ref = F.conv2d(x, wt, b, padding=1)
+    xd, wd, bd = x.to(DEV), wt.to(DEV), b.to(DEV)
+    close(_wino(xd, wd, bd, None, 0), ref, 1e-4, 1e-4, "epilogue 0 (bias)")
+    close(_wino(xd, wd, bd, None, 1), F.relu(ref), 1e-4, 1e-4, "epilogue 1 (bias + relu)")
+    close(_wino(xd, wd, None, None, 2), ref - b.view(1, -1, 1, 1), 1e-4, 1e-4, "epilogue 2 (none)")
+    if h >= 2 and w >= 2:
+        close(_wino(xd, wd, bd, None, 4), F.max_pool2d(F.relu(ref), 2, 2), 1e-4, 1e-4, "epilogue 4 (bias + relu + pool)")
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
+def test_wino_dgrad_with_relu_mask(n, cin, cout, h, w):
+    """dX = conv(dY, W^T flipped) (pack mode 1), plain (epilogue 2) and through the producer's ReLU mask (epilogue 3)."""
+    gen = g(7 + n * 1000 + cin + cout + h + w)
+    xr = torch.randn(n, cin, h, w, generator=gen).requires_grad_()
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    gy = torch.randn(n, cout, h, w, generator=gen)
+    F.conv2d(xr, wt, None, padding=1).backward(gy)
+    mask_src = torch.randn(n, cin, h, w, generator=gen)            # "activation of the producing layer"
+    got = _wino(gy.to(DEV), wt.to(DEV), None, None, 2, mode=1)
+    close(got, xr.grad, 1e-4, 2e-4, "dgrad")
+    got3 = _wino(gy.to(DEV), wt.to(DEV), None, mask_src.to(DEV), 3, mode=1)
+    close(got3, xr.grad * (mask_src > 0), 1e-4, 2e-4, "dgrad + relu mask")
+
+
+def test_wino_equals_direct_kernel_closely():
+    """Same inputs through both algorithms (ops.set_conv_algo): forward, dgrad and the fused block agree to fp32 rounding."""
+    from probabilisticteacher_amd import ops
+    gen = g(3)
+    x = torch.randn(2, 64, 45, 70, generator=gen).to(DEV)
+    wt = (torch.randn(128, 64, 3, 3, generator=gen) * 0.06).to(DEV)
+    b = (torch.randn(128, generator=gen) * 0.1).to(DEV)
+    gy = torch.randn(2, 128, 45, 70, generator=gen).to(DEV)
+    outs = {}
+    try:
+        for algo in ("auto", "direct"):
+            ops.set_conv_algo(algo)
+            xd = x.clone().requires_grad_()
+            y = ops.conv3x3(xd, wt, b, True)
+            y.backward(gy)
+            outs[algo] = (y.detach(), xd.grad)
+    finally:
+        ops.set_conv_algo("auto")
+    close(outs["auto"][0], outs["direct"][0], 1e-5, 2e-5, "forward wino vs direct")
+    close(outs["auto"][1], outs["direct"][1], 1e-5, 2e-5, "dgrad wino vs direct")
+
+
+def test_wino_baseline_layer_shapes():
+    """One image of every distinct Winograd layer shape of the 1333x800 stack against torch CPU on border-including crops
+    (the full-size comparison of every layer runs in test_baseline_size_gpu.py through the production autograd nodes)."""
+    for cin, cout, h, w in [(64, 64, 800, 1333), (128, 256, 200, 333), (512, 512, 50, 83)]:
+        gen = g(cin + h)
+        x = torch.randn(1, cin, h, w, generator=gen)
+        wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+        b = torch.randn(cout, generator=gen) * 0.1
+        got = _wino(x.to(DEV), wt.to(DEV), b.to(DEV), None, 1).cpu()
+        assert torch.isfinite(got).all()
+        for ys, xs in [(slice(0, 24), slice(0, 40)), (slice(h - 24, h), slice(w - 40, w)), (slice(h // 2 - 9, h // 2 + 9), slice(w - 45, w))]:
+            # a crop grown by one pixel of context on each interior side gives exact values for the crop's interior
+            y0, y1 = max(ys.start - 1, 0), min(ys.stop + 1, h)
+            x0, x1 = max(xs.start - 1, 0), min(xs.stop + 1, w)
+            ref = F.relu(F.conv2d(x[:, :, y0:y1, x0:x1], wt, b, padding=1))
+            ref = ref[:, :, ys.start - y0: ys.start - y0 + (ys.stop - ys.start), xs.start - x0: xs.start - x0 + (xs.stop - xs.start)]
+            close(got[:, :, ys, xs], ref, 1e-4, 1e-4, f"layer {cin}->{cout} {h}x{w} crop {ys} {xs}")

@@ -41,7 +41,10 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--bf16", action="store_true", help="the bf16-input kernels (ptmi_*_bf16); fractions stay relative "
                                                         "to the fp32 MFMA peak")
+    ap.add_argument("--algo", default="auto", choices=["auto", "direct"], help="fp32 forward / dgrad algorithm "
+                    "(auto = fused Winograd where it applies; TF/s are ALGORITHMIC direct-convolution FLOPs either way)")
     a = ap.parse_args()
+    ops.set_conv_algo(a.algo)
     if a.bf16:
         ops.set_operand_rounding("bf16")
     dev = "cuda:0"
