@@ -32,6 +32,10 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef WINO_EXP
+#define WINO_EXP 0      // timing experiments (tools/exp/wino_variants.sh): bit 0 no DMA, 1 no window reads, 2 no A reads, 3 no transform, 4 no barrier
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -185,40 +189,43 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         //   P = 4..7   one DMA instruction each for the NEXT chunk (k-steps 0..2 carry its 4 + 8 instructions); the buffer
         //              they fill was released by the previous hand-over barrier
         //   P = 8..11  input transform, rows;   P = 12..15  input transform, columns
-        auto kstep = [&](auto ks_c, const f32x4 (&A)[4], const float (&V)[16], f32x4 (&An)[4], f32x2 (&Dn)[12], float (&Vn)[16],
-                         int buf, bool more) {
+        auto kstep = [&](auto ks_c, auto more_c, const f32x4 (&A)[4], const float (&V)[16], f32x4 (&An)[4], f32x2 (&Dn)[12],
+                         float (&Vn)[16], int buf) {
             constexpr int KS = decltype(ks_c)::value;
+            constexpr bool more = decltype(more_c)::value;
             const float* src = lds + (KS < 3 ? buf : buf ^ 1) * WSTAGE;
             const float* ap = src + a_off + ((KS + 1) & 3) * (2 * 4 * WBM * 4);
             const float* bp = src + b_off + ((KS + 1) & 3) * (2 * WPL);
-            const bool next = KS < 3 || more;
+            constexpr bool next = KS < 3 || more;
             auto step = [&](auto p_c) {
                 constexpr int P = decltype(p_c)::value;
                 acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], V[P], acc[P], 0, 0, 0);
                 if constexpr (P == 0) {
+#if !(WINO_EXP & 16)
                     if (KS == 3 && more) {
                         wino_vmwait0();
                         fixup(buf ^ 1);
                         __syncthreads();
                     }
-                    if (next) {
+#endif
+                    if (next && !(WINO_EXP & 4)) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) An[i] = *(const volatile wlds_f32x4_t*)(ap + i * (WBM * 4));
                     }
                 }
                 if constexpr (P >= 1 && P <= 3) {
-                    if (next) {
+                    if (next && !(WINO_EXP & 2)) {
 #pragma unroll
                         for (int e = 4 * (P - 1); e < 4 * P; ++e)
                             Dn[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3));
                     }
                 }
                 if constexpr (P >= 4 && P <= 7 && KS < 3) {
-                    if (more) dma_piece(KS * 4 + (P - 4), buf ^ 1);
+                    if (more && !(WINO_EXP & 1)) dma_piece(KS * 4 + (P - 4), buf ^ 1);
                     if (P == 7 && KS == 2 && more) advance();
                 }
                 if constexpr (P >= 8 && P <= 11) {
-                    if (next) {
+                    if (next && !(WINO_EXP & 8)) {
                         constexpr int b = P - 8, k = b + 1;
                         const float d0 = Dn[0 + (k >> 1)][k & 1], d1 = Dn[3 + (k >> 1)][k & 1];
                         const float d2 = Dn[6 + (k >> 1)][k & 1], d3 = Dn[9 + (k >> 1)][k & 1];
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
                     }
                 }
                 if constexpr (P >= 12) {
-                    if (next) {
+                    if (next && !(WINO_EXP & 8)) {
                         constexpr int i = P - 12;
                         Vn[4 * i + 0] = tt[i][0] - tt[i][2];
                         Vn[4 * i + 1] = tt[i][1] + tt[i][2];
@@ -262,14 +269,15 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
             for (int e = 0; e < 12; ++e) D0[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3));
             wino_xform(D0, V0);
         }
-        for (int chunk = 0; chunk < nChunks; ++chunk) {
-            const int buf = chunk & 1;
-            const bool more = chunk + 1 < nChunks;
-            kstep(std::integral_constant<int, 0>{}, A0, V0, A1, D1, V1, buf, more);
-            kstep(std::integral_constant<int, 1>{}, A1, V1, A0, D0, V0, buf, more);
-            kstep(std::integral_constant<int, 2>{}, A0, V0, A1, D1, V1, buf, more);
-            kstep(std::integral_constant<int, 3>{}, A1, V1, A0, D0, V0, buf, more);
-        }
+        // (the last chunk has its own copy of the body: no DMA, no hand-over -- and no branches inside either copy)
+        auto chunk_body = [&](auto more_c, int buf) {
+            kstep(std::integral_constant<int, 0>{}, more_c, A0, V0, A1, D1, V1, buf);
+            kstep(std::integral_constant<int, 1>{}, more_c, A1, V1, A0, D0, V0, buf);
+            kstep(std::integral_constant<int, 2>{}, more_c, A0, V0, A1, D1, V1, buf);
+            kstep(std::integral_constant<int, 3>{}, more_c, A1, V1, A0, D0, V0, buf);
+        };
+        for (int chunk = 0; chunk + 1 < nChunks; ++chunk) chunk_body(std::true_type{}, chunk & 1);
+        chunk_body(std::false_type{}, (nChunks - 1) & 1);
     } else {
         // a wave whose rows all lie below the image: same DMA issue / wait / barrier sequence, no MFMAs
         issue(0);
