@@ -20,6 +20,8 @@ SOURCES = ["abi.cpp", "conv.hip", "wino.hip", "gemm.hip", "misc.hip", "boxes.hip
 # CPU reference does.  -munsafe-fp-atomics: hardware fp32 atomic add for the ROIAlign backward scatter.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
+# per-file extra flags (none at present)
+FILE_FLAGS = {}
 
 
 def _deps_mtime():
@@ -35,7 +37,7 @@ def _compile(src):
                 os.path.getmtime(os.path.join(HERE, "..", "include", "ptmi355.h")))
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(path), hdr_m):
         return obj
-    cmd = ["hipcc"] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+    cmd = ["hipcc"] + FLAGS + FILE_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
     subprocess.check_call(cmd)
     return obj
 

@@ -32,10 +32,6 @@
 #include "common.h"
 #include <type_traits>
 
-#ifndef WINO_EXP
-#define WINO_EXP 0      // timing experiments (tools/exp/wino_variants.sh): bit 0 no DMA, 1 no window reads, 2 no A reads, 3 no transform, 4 no barrier
-#endif
-
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -54,12 +50,19 @@ constexpr int WPR = WTH + 2;           // patch rows (image rows y0-1 .. y0+8)
 constexpr int WPL = WPR * WPP;         // floats per channel plane (480)
 constexpr int WUS = WKC * 4 * WBM * 4; // U floats per chunk: [ci 8][position row i 4][co 64][position column j 4] = 8192
 constexpr int WPS = WKC * WPL;         // patch floats per chunk (3840 = 960 pieces = 15 waves' worth)
-constexpr int WSTAGE = WUS + WPS;      // 12032 floats = 47 KB; two stages
+constexpr int WPSP = 4096;             // ... padded to 16 waves' worth: every wave issues the same four patch DMAs (the counted
+                                       // vmcnt waits rely on it; pieces 960 .. 1023 carry offset 0xFFFFFFFF)
+constexpr int WSTAGE = WUS + WPSP;     // 12288 floats = 48 KB; three stages
 constexpr int WNT = 256;
 constexpr int WUI = WUS / 4 / WNT;     // U DMA instructions per lane and chunk (8)
 constexpr int WPI = (WPS / 4 + WNT - 1) / WNT;   // patch DMA instructions per lane and chunk (4; the last one waves 0-2 only)
 
 __device__ __forceinline__ void wino_vmwait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The main loop's input-transform additions, one VALU instruction each and opaque to the optimiser: the SLP vectoriser
+// otherwise packs them into v_pk_add_f32 and pays with register shuffles (v_mov / v_pk_mov) between the MFMAs -- 25 VALU in
+// one MFMA slot of a one-wave-per-SIMD kernel (the epilogue keeps its packed arithmetic).
+__device__ __forceinline__ float wino_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wino_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // V = B^T d B for the lane's (tile, channel): d rows a = 0..3 arrive as three 8-byte reads each, D[3a + t] = LDS columns
 // 2 ttx + 2 + 2t, + 1; the window's columns b = 0..3 are elements 1..4 of that row of six.
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi)
 {
-    __shared__ __attribute__((aligned(16))) float lds[2 * WSTAGE];
+    __shared__ __attribute__((aligned(16))) float lds[3 * WSTAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -129,12 +132,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     // one DMA instruction of a chunk: idx 0 .. WPI-1 = patch pieces, WPI .. WPI+WUI-1 = U pieces
     auto dma_piece = [&](int idx, int buf) {
         if (idx < WPI) {
-            if ((idx + 1) * WNT * 4 <= WPS || wave * 64 + idx * WNT < WPS / 4) {     // wave-uniform (WPS / 4 is a multiple of 64)
-                const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-                    ptmi_uniform_ptr(xc), 0, __builtin_amdgcn_readfirstlane((int)xleft), 0x00020000);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (wlds_void_t*)(lds + buf * WSTAGE + WUS + wave * 256 + idx * WNT * 4),
-                                                         16, (int)pvoff[idx], 0, 0, 0);
-            }
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                ptmi_uniform_ptr(xc), 0, __builtin_amdgcn_readfirstlane((int)xleft), 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (wlds_void_t*)(lds + buf * WSTAGE + WUS + wave * 256 + idx * WNT * 4),
+                                                     16, (int)pvoff[idx], 0, 0, 0);
         } else {
             const int i = idx - WPI;
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(wc), 0, WUS * 4, 0x00020000);
@@ -183,65 +184,69 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         float tt[4][4];
         // One k-step = 16 MFMAs on (A, V), one per position, with the rest of the wave's work placed between them (one
         // wave per SIMD: whatever is not issued in the shadow of an MFMA leaves the matrix pipe idle):
-        //   P = 0      the next k-step's four A reads -- in the chunk's LAST k-step first the hand-over: own DMA pieces of
-        //              the next chunk landed, edge fix-ups, workgroup barrier (its operands are already in registers)
-        //   P = 1..3   the next k-step's twelve window reads
-        //   P = 4..7   one DMA instruction each for the NEXT chunk (k-steps 0..2 carry its 4 + 8 instructions); the buffer
-        //              they fill was released by the previous hand-over barrier
-        //   P = 8..11  input transform, rows;   P = 12..15  input transform, columns
-        auto kstep = [&](auto ks_c, auto more_c, const f32x4 (&A)[4], const float (&V)[16], f32x4 (&An)[4], f32x2 (&Dn)[12],
-                         float (&Vn)[16], int buf) {
+        //   P = 0      in the chunk's LAST k-step the hand-over (this k-step's operands are already in registers): own DMA
+        //              pieces of the next chunk landed (counted vmcnt), edge fix-ups, workgroup barrier
+        //   P = 0..7   the next k-step's twelve 8-byte window reads (two per slot, then one)
+        //   P = 4..7   one DMA instruction each for the chunk AFTER the next (k-steps 0..2 carry its 4 + 8 instructions)
+        //   P = 8..11  the next k-step's four 16-byte A reads;  P = 10, 11  input transform, rows (two columns each)
+        //   P = 12..15 input transform, columns (one position row each) -- every LDS read is at least four MFMAs old when
+        //              the k-step ends, so the hand-over's lgkmcnt(0) costs nothing
+        // (s_memtime probes, tools/exp: with the hand-over's reads still in flight, the edge fix-up branches in the main
+        // body and two LDS stages the chunk's last k-step took 1.8k cycles against 1.1-1.2k for the others.)
+        auto kstep = [&](auto ks_c, auto more_c, auto more2_c, auto edge_c, const f32x4 (&A)[4], const float (&V)[16],
+                         f32x4 (&An)[4], f32x2 (&Dn)[12], float (&Vn)[16], int cur, int nxt, int nn) {
             constexpr int KS = decltype(ks_c)::value;
-            constexpr bool more = decltype(more_c)::value;
-            const float* src = lds + (KS < 3 ? buf : buf ^ 1) * WSTAGE;
+            constexpr bool more = decltype(more_c)::value;        // a chunk follows this one
+            constexpr bool more2 = decltype(more2_c)::value;      // ... and another one after it (its DMA is issued here)
+            constexpr bool EDGE = decltype(edge_c)::value;        // right-edge workgroup: DMA pieces may need fix-ups
+            constexpr bool next = KS < 3 || more;
+            const float* src = lds + (KS < 3 ? cur : nxt) * WSTAGE;
             const float* ap = src + a_off + ((KS + 1) & 3) * (2 * 4 * WBM * 4);
             const float* bp = src + b_off + ((KS + 1) & 3) * (2 * WPL);
-            constexpr bool next = KS < 3 || more;
+            auto dread = [&](int e) { Dn[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3)); };
             auto step = [&](auto p_c) {
                 constexpr int P = decltype(p_c)::value;
                 acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], V[P], acc[P], 0, 0, 0);
-                if constexpr (P == 0) {
-#if !(WINO_EXP & 16)
-                    if (KS == 3 && more) {
-                        wino_vmwait0();
-                        fixup(buf ^ 1);
-                        __syncthreads();
-                    }
-#endif
-                    if (next && !(WINO_EXP & 4)) {
+                if constexpr (P == 0 && KS == 3 && more) {
+                    // chunk + 1 was issued a whole chunk ago; the WPI + WUI DMA instructions of chunk + 2 are newer
+                    if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + WUI) : "memory");
+                    else wino_vmwait0();
+                    if (EDGE) fixup(nxt);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                if constexpr (P <= 11) {                      // ONE window read per slot
+                    if (next) dread(P);
+                }
+                if constexpr (P >= 12) {                      // ONE A read per slot
+                    if (next) An[P - 12] = *(const volatile wlds_f32x4_t*)(ap + (P - 12) * (WBM * 4));
+                }
+                if constexpr (P >= 4 && P <= 7) {
+                    if (KS < 3 && more2) dma_piece(KS * 4 + (P - 4), nn);
+                    if (P == 7 && KS == 2 && more2) advance();
+                }
+                if constexpr (P == 13) {
+                    if (next) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) An[i] = *(const volatile wlds_f32x4_t*)(ap + i * (WBM * 4));
+                        for (int b = 0; b < 4; ++b) {
+                            const int k = b + 1;
+                            const float d0 = Dn[0 + (k >> 1)][k & 1], d1 = Dn[3 + (k >> 1)][k & 1];
+                            const float d2 = Dn[6 + (k >> 1)][k & 1], d3 = Dn[9 + (k >> 1)][k & 1];
+                            tt[0][b] = wino_sub(d0, d2);
+                            tt[1][b] = wino_add(d1, d2);
+                            tt[2][b] = wino_sub(d2, d1);
+                            tt[3][b] = wino_sub(d1, d3);
+                        }
                     }
                 }
-                if constexpr (P >= 1 && P <= 3) {
-                    if (next && !(WINO_EXP & 2)) {
+                if constexpr (P >= 14) {
+                    if (next) {
 #pragma unroll
-                        for (int e = 4 * (P - 1); e < 4 * P; ++e)
-                            Dn[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3));
-                    }
-                }
-                if constexpr (P >= 4 && P <= 7 && KS < 3) {
-                    if (more && !(WINO_EXP & 1)) dma_piece(KS * 4 + (P - 4), buf ^ 1);
-                    if (P == 7 && KS == 2 && more) advance();
-                }
-                if constexpr (P >= 8 && P <= 11) {
-                    if (next && !(WINO_EXP & 8)) {
-                        constexpr int b = P - 8, k = b + 1;
-                        const float d0 = Dn[0 + (k >> 1)][k & 1], d1 = Dn[3 + (k >> 1)][k & 1];
-                        const float d2 = Dn[6 + (k >> 1)][k & 1], d3 = Dn[9 + (k >> 1)][k & 1];
-                        tt[0][b] = d0 - d2;
-                        tt[1][b] = d1 + d2;
-                        tt[2][b] = d2 - d1;
-                        tt[3][b] = d1 - d3;
-                    }
-                }
-                if constexpr (P >= 12) {
-                    if (next && !(WINO_EXP & 8)) {
-                        constexpr int i = P - 12;
-                        Vn[4 * i + 0] = tt[i][0] - tt[i][2];
-                        Vn[4 * i + 1] = tt[i][1] + tt[i][2];
-                        Vn[4 * i + 2] = tt[i][2] - tt[i][1];
-                        Vn[4 * i + 3] = tt[i][1] - tt[i][3];
+                        for (int i = 2 * (P - 14); i < 2 * (P - 14) + 2; ++i) {
+                            Vn[4 * i + 0] = wino_sub(tt[i][0], tt[i][2]);
+                            Vn[4 * i + 1] = wino_add(tt[i][1], tt[i][2]);
+                            Vn[4 * i + 2] = wino_sub(tt[i][2], tt[i][1]);
+                            Vn[4 * i + 3] = wino_sub(tt[i][1], tt[i][3]);
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -257,9 +262,14 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         };
 
         issue(0);
-        wino_vmwait0();
+        if (nChunks > 1) {
+            issue(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + WUI) : "memory");
+        } else {
+            wino_vmwait0();
+        }
         fixup(0);
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         {   // operands of the first k-step
             const float* ap = lds + a_off;
             const float* bp = lds + b_off;
@@ -269,26 +279,52 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
             for (int e = 0; e < 12; ++e) D0[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3));
             wino_xform(D0, V0);
         }
-        // (the last chunk has its own copy of the body: no DMA, no hand-over -- and no branches inside either copy)
-        auto chunk_body = [&](auto more_c, int buf) {
-            kstep(std::integral_constant<int, 0>{}, more_c, A0, V0, A1, D1, V1, buf);
-            kstep(std::integral_constant<int, 1>{}, more_c, A1, V1, A0, D0, V0, buf);
-            kstep(std::integral_constant<int, 2>{}, more_c, A0, V0, A1, D1, V1, buf);
-            kstep(std::integral_constant<int, 3>{}, more_c, A1, V1, A0, D0, V0, buf);
+        // three stages in LDS: chunk c is computed from stage c % 3 while chunk c + 1 sits complete (or landing) in the next
+        // one and chunk c + 2 is being fetched into the third: a DMA piece has a whole chunk (~4.5k cycles) to land before
+        // the hand-over that waits for it.  Right-edge workgroups (some 16-B piece straddles the image edge) run their own
+        // copy of the loop with the fix-up writes in the hand-over; the common copy is branch-free.
+        auto main_loop = [&](auto edge_c) {
+            auto chunk_body = [&](auto more_c, auto more2_c, int cur, int nxt, int nn) {
+                kstep(std::integral_constant<int, 0>{}, more_c, more2_c, edge_c, A0, V0, A1, D1, V1, cur, nxt, nn);
+                kstep(std::integral_constant<int, 1>{}, more_c, more2_c, edge_c, A1, V1, A0, D0, V0, cur, nxt, nn);
+                kstep(std::integral_constant<int, 2>{}, more_c, more2_c, edge_c, A0, V0, A1, D1, V1, cur, nxt, nn);
+                kstep(std::integral_constant<int, 3>{}, more_c, more2_c, edge_c, A1, V1, A0, D0, V0, cur, nxt, nn);
+            };
+            int cur = 0, nxt = 1, nn = 2;
+            for (int chunk = 0; chunk + 2 < nChunks; ++chunk) {
+                chunk_body(std::true_type{}, std::true_type{}, cur, nxt, nn);
+                const int t = cur; cur = nxt; nxt = nn; nn = t;
+            }
+            if (nChunks > 1) {
+                chunk_body(std::true_type{}, std::false_type{}, cur, nxt, nn);
+                cur = nxt;
+            }
+            chunk_body(std::false_type{}, std::false_type{}, cur, nxt, nn);
         };
-        for (int chunk = 0; chunk + 1 < nChunks; ++chunk) chunk_body(std::true_type{}, chunk & 1);
-        chunk_body(std::false_type{}, (nChunks - 1) & 1);
+        if (edge) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
     } else {
         // a wave whose rows all lie below the image: same DMA issue / wait / barrier sequence, no MFMAs
         issue(0);
-        wino_vmwait0();
-        fixup(0);
-        __syncthreads();
-        for (int chunk = 0; chunk + 1 < nChunks; ++chunk) {
-            issue((chunk & 1) ^ 1);
+        if (nChunks > 1) {
+            issue(1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + WUI) : "memory");
+        } else {
             wino_vmwait0();
-            fixup((chunk & 1) ^ 1);
-            __syncthreads();
+        }
+        fixup(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int nxt = 1, nn = 2;
+        for (int chunk = 0; chunk + 1 < nChunks; ++chunk) {
+            if (chunk + 2 < nChunks) {
+                issue(nn);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + WUI) : "memory");
+            } else {
+                wino_vmwait0();
+            }
+            fixup(nxt);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const int t = nxt; nxt = nn; nn = (t + 2) % 3;
         }
         return;
     }

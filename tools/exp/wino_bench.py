@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--n", type=int, default=16)
     ap.add_argument("--layers", default="conv3_2")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--trace", action="store_true", help="libs built with -DWINO_TRACE: print the k-step timestamps of one wave")
+    ap.add_argument("--slots", action="store_true", help="libs built from wino_v5s.hip: slot-level stamps of KS1 / KS3")
+    ap.add_argument("--coarse", action="store_true", help="libs built from wino_v5c.hip: entry / loop / epilogue stamps")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     vp = ctypes.c_void_p
@@ -36,8 +39,11 @@ def main():
             st = vp(torch.cuda.current_stream().cuda_stream)
             lib.ptmi_conv3x3_wino_pack_weights(vp(wt.data_ptr()), vp(wp.data_ptr()), cout, cin, 0, st)
 
+            tr = torch.zeros(4096, dtype=torch.int64, device="cuda:0") if (a.trace or a.slots or a.coarse) else None
+
             def f():
-                rc = lib.ptmi_conv3x3_wino_fwd(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()), None, vp(y.data_ptr()),
+                rc = lib.ptmi_conv3x3_wino_fwd(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()),
+                                               vp(tr.data_ptr()) if (a.trace or a.slots or a.coarse) else None, vp(y.data_ptr()),
                                                a.n, cin, cout, h, w, 1, st)
                 assert rc == 0
             f()
@@ -49,6 +55,30 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
+            if a.coarse:
+                t = tr.cpu().tolist()
+                for g in range(2):
+                    for w in range(4):
+                        v = t[g * 32 + w * 8: g * 32 + w * 8 + 5]
+                        print(f"wg {g} wave {w}: entry->loop {v[1]-v[0]}  loop {v[2]-v[1]}  epilogue issue {v[3]-v[2]}  store drain {v[4]-v[3]}  total {v[4]-v[0]}  entry abs {v[0]}")
+            if a.slots:
+                t = tr.cpu().tolist()
+                for w in range(4):
+                    for k, nm in ((0, "KS1"), (1, "KS3")):
+                        v = t[w * 16 + k * 7: w * 16 + k * 7 + 7]
+                        print(f"wave {w} {nm}: start->vmwait {v[1]-v[0] if v[1] else None} vmwait->after-barrier {v[2]-v[1] if v[2] else None} "
+                              f"start->slot4 {v[3]-v[0]} slot4->8 {v[4]-v[3]} slot8->12 {v[5]-v[4]} slot12->15 {v[6]-v[5]}  abs start {v[0] % 100000}")
+            if a.slots:
+                for w in range(4):
+                    tk0, t15p, tk015 = t[64 + w * 4: 64 + w * 4 + 3]
+                    print(f"wave {w}: prev KS3 slot15 -> KS0 start {tk0 - t15p}; KS0 start -> KS0 slot15 {tk015 - tk0}; KS0 slot15 -> KS1 start {t[w * 16] - tk015}; "
+                          f"KS1 slot15 -> (KS2) -> KS3 start {t[w * 16 + 7] - t[w * 16 + 6]}")
+            if a.trace:
+                t = tr.cpu().tolist()
+                k = int(t[4095])
+                d = [t[i + 1] - t[i] for i in range(0, k)]
+                print("trace: prologue", d[0], "k-steps", d[1:k - 0][:40], "...", "mean k-step", sum(d[1:k]) / max(k - 1, 1),
+                      "by KS:", [sum(d[1 + j:k:4]) / max(len(d[1 + j:k:4]), 1) for j in range(4)])
             print(f"{name} n={a.n} {os.path.basename(path):32s} {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s eff  "
                   f"{fl / 2.25 / ms / 1e9 / 157.3:6.1%} of MFMA peak (issued)")
 
