@@ -80,24 +80,63 @@ def cpu_baseline(h, w, K, seed=0, student_only=False):
                        f"1 unlabelled {w}x{h} image, {dt:.1f} s")}
 
 
-PMC_PROFILE = "profiles/r02_bench_b16_pmc_by_kernel.json"
+PMC_PROFILE = "profiles/r03_bench_b16_pmc_by_kernel.json"
+DOMINANT = "conv3x3_wino_kernel"          # the kernel the roofline object describes (its rocprofv3 name contains this)
 
 
-def pmc_traffic():
-    """HBM-side bytes per conv fwd/dgrad launch: NOT measured in this run (PMC collection serialises kernels and needs
-    rocprofv3) -- read from the committed rocprofv3 PMC passes of this same command (tools/pmc_collect.py: FETCH_SIZE and
-    WRITE_SIZE in KB from separate --pmc passes, FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md),
-    restricted to the kernels this bench launches.  Returns (bytes per launch, provenance) or (None, reason)."""
+def committed_pmc_traffic():
+    """Fallback only: HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (tools/pmc_collect.py).  Returns (bytes per launch, provenance) or (None, reason)."""
     f = os.path.join(ROOT, PMC_PROFILE)
     if not os.path.exists(f):
         return None, f"{PMC_PROFILE} absent"
     d = json.load(open(f))
     tot, n = 0.0, 0
     for k, v in d.get("kernels", {}).items():
-        if k.startswith("conv3x3_buf_kernel") or k.startswith("conv3x3_stem_kernel"):
+        if DOMINANT in k:
             tot += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
             n += v["dispatches"]
     return (tot / n if n else None), f"{PMC_PROFILE} (collected on {d.get('git_head', '?')}, {d.get('command', '?')})"
+
+
+def measured_pmc_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel, measured NOW: this script re-runs itself for one warm-up + one step
+    under `rocprofv3 --kernel-trace --pmc <counter>` -- FETCH_SIZE and WRITE_SIZE in separate passes, as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-B request on gfx950: doubled) -- after the timed region,
+    so that the counters do not perturb the timing.  Returns (bytes per launch, provenance) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    tot, disp = {}, 0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ptmi_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+               "--pmc-traffic", "off", "--per-gpu-batch", str(args.per_gpu_batch), "--height", str(args.height),
+               "--width", str(args.width)] + (["--student-only"] if args.student_only else [])
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True, timeout=420)
+        except Exception as e:      # noqa: BLE001  (a profiler failure must not take the bench line with it)
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 {counter} pass failed: {e!r}"
+        n, val = 0, 0.0
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if DOMINANT in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    val += float(row["Counter_Value"])
+                    n += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if r.returncode != 0 or n == 0:
+            return None, f"rocprofv3 {counter} pass: rc {r.returncode}, {n} dispatches of {DOMINANT}: {r.stdout[-300:]!r}"
+        tot[counter], disp = val, n
+    return ((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / disp,
+            f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 1 warm-up + 1 step each, "
+            f"{disp} dispatches of {DOMINANT}; FETCH_SIZE x2 per the gfx950 correction)")
 
 
 def main():
@@ -116,6 +155,11 @@ def main():
                     help="NOT the headline metric: SOLVER.AMP.ENABLED (BASELINE configs[4] numerics) -- conv / FC operands "
                          "rounded to bf16 inside the ptmi_*_bf16 kernels (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 "
                          "losses / optimiser; reported against the dense bf16 MFMA peak")
+    ap.add_argument("--grad-reduce", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="N > 1: the bucketed gradient exchange as all-reduce or as reduce-scatter + all-gather (engine/flat.py)")
+    ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
+                    help="auto (N = 1): measure roofline.traffic after the timed region by re-running one step under rocprofv3 "
+                         "PMC passes; off: report the committed profile's number, labelled as such")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -142,7 +186,7 @@ def main():
         "SOLVER.AMP.ENABLED", bool(args.amp)])
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     torch.manual_seed(0)                                                # identical init on all ranks
-    trainer = PTrainer(cfg)
+    trainer = PTrainer(cfg, grad_reduce=args.grad_reduce)
     gen = torch.Generator().manual_seed(1234 + rank * 1000)
     H, W = args.height, args.width
 
@@ -168,11 +212,12 @@ def main():
     ops.profile_start()
     ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
-    step_ms = []
+    step_ms, early = [], []
     for i in range(args.steps):
         ts = time.perf_counter()
         trainer.run_step(batches[i % 2])          # (ends with the metrics read-back, i.e. synchronised)
         step_ms.append(1e3 * (time.perf_counter() - ts))
+        early.append(trainer.reducer.launched_in_backward)
     sync()
     dt = time.perf_counter() - t0
     ms1 = torch.cuda.memory_stats()
@@ -184,17 +229,43 @@ def main():
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt_max = float(t.item())
+    # self-verification of the data-parallel run (all ranks take part): what the process group really looks like, every
+    # rank's own step time, and that the replicas are still bit-identical after the timed steps
+    from probabilisticteacher_amd.engine.flat import replicas_identical
+    per_rank = torch.tensor([dt / args.steps * 1e3], dtype=torch.float64, device=dev)
+    if world > 1:
+        gathered = [torch.empty_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)
+        per_rank_ms = [float(g.item()) for g in gathered]
+    else:
+        per_rank_ms = [float(per_rank.item())]
+    same_s, sums_s = replicas_identical(trainer.student.flat)
+    same_t, _ = replicas_identical(trainer.teacher.flat)
+    assert same_s and same_t, f"data-parallel replicas diverged: student checksums {sums_s}"
+    dt = dt_max
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * 2 * B * args.steps / dt             # burn-in step: label_q + label_k = 2B images as well
         srt = sorted(step_ms)
         median = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-        traffic, traffic_src = pmc_traffic() if not args.amp else (None, "not collected for the bf16 kernels")
+        if args.amp:
+            traffic, traffic_src = None, "not collected for the bf16 kernels"
+        else:
+            traffic, traffic_src = (measured_pmc_traffic(args) if args.pmc_traffic == "auto" and world == 1
+                                    else (None, "not measured in this run (--pmc-traffic off or N > 1)"))
+            if traffic is None:
+                fb, fb_src = committed_pmc_traffic()
+                traffic, traffic_src = fb, f"{fb_src}; {traffic_src}"
         peak = PEAK_BF16_MFMA_TFLOPS if args.amp else PEAK_F32_MFMA_TFLOPS
-        conv = prof.get("conv3x3_mfma", {"ms": 0.0, "flops": 0.0, "calls": 0})
-        ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        # the dominant kernel: the fused Winograd F(2x2,3x3) kernel (fp32 bench) / the direct bf16-input kernel (--amp).
+        # `achieved` / `frac` price the MFMA FLOPs the kernel ISSUES (never above the peak); the direct-convolution FLOPs the
+        # same launches stand for are reported next to it as `effective_direct_tflops`
+        dom = "conv3x3_mfma" if args.amp else "conv3x3_wino"
+        conv = prof.get(dom, {"ms": 0.0, "flops": 0.0, "issued": 0.0, "bytes": 0.0, "calls": 0})
+        ach = conv["issued"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        eff = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         out = {
             "metric": ("student-only train-step img/s at 1333x800" if args.student_only else
                        "teacher-student train-step img/s at 1333x800") +
@@ -216,16 +287,32 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["calls"], 1),
                          "kernel": ("conv3x3_buf_kernel<BM,NWAVE,bf16> (all 3x3 conv fwd + dgrad launches)" if args.amp else
-                                    "conv3x3_buf_kernel<BM,NWAVE> + conv3x3_stem_kernel (all 3x3 conv fwd + dgrad launches)"),
+                                    "conv3x3_wino_kernel (fused Winograd F(2x2,3x3): every 3x3 conv fwd + dgrad launch with "
+                                    ">= 32 input channels; the 3-channel stem runs conv3x3_stem_kernel, listed under kernels)"),
+                         "achieved_is": "MFMA FLOPs issued by the kernel (16 multiplies per 2x2 tile and channel pair, tile "
+                                        "padding included) / HIP-event time; equals the direct FLOPs for the bf16 kernels",
+                         "effective_direct_tflops": eff,
+                         "effective_direct_over_peak": eff / peak,
                          "calls": conv["calls"],
                          "avg_launch_ms": conv["ms"] / max(conv["calls"], 1),
-                         "flops_per_launch_avg": conv["flops"] / max(conv["calls"], 1)},
+                         "mfma_flops_issued_per_launch_avg": conv["issued"] / max(conv["calls"], 1),
+                         "direct_flops_per_launch_avg": conv["flops"] / max(conv["calls"], 1)},
             "kernels": {k: {"ms_per_step": v["ms"] / args.steps, "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12)
                             if v["ms"] > 0 and v["flops"] else None, "calls_per_step": v["calls"] / args.steps}
                         for k, v in prof.items()},
             "step_conv_tflops": ((0.67106 + 0.90253) if args.student_only else 2.696) * 2 * B * world * args.steps / dt
             if (H, W) == (800, 1333) else None,
             "losses": {k: v for k, v in trainer.last_metrics.items() if k.startswith("loss")},
+            "distributed": {"world_size_seen_by_process_group": dist.get_world_size() if dist.is_initialized() else 1,
+                            "backend": dist.get_backend() if dist.is_initialized() else None,
+                            "per_rank_ms_per_step": per_rank_ms,
+                            "grad_exchange": {"mode": trainer.reducer.mode, "active": trainer.reducer.active,
+                                              "buckets": len(trainer.reducer.buckets),
+                                              "buckets_launched_during_backward_avg": sum(early) / max(len(early), 1),
+                                              "overlap_fraction": (sum(early) / max(len(early), 1)) / len(trainer.reducer.buckets),
+                                              "bytes_exchanged_per_step": trainer.reducer.bytes_per_step if trainer.reducer.active else 0},
+                            "replicas_bit_identical_after_run": bool(same_s and same_t),
+                            "student_checksums": [str(v) for v in sums_s]},
         }
         if world == 1 and not args.no_cpu_baseline and not args.amp:
             out["cpu_baseline"] = cpu_baseline(H, W, K, student_only=args.student_only)

@@ -31,7 +31,9 @@ def optimizer_state_dict(trainer) -> Dict:
     """The flat momentum buffer as a torch.optim.SGD state_dict with one group per parameter."""
     S = trainer.cfg.SOLVER
     names = _trainable_names(trainer)
-    lr = lr_at(trainer.cfg, max(trainer.iter - 1, 0))
+    # the scheduler has already stepped when a checkpoint is written (hooks.LRScheduler.after_step precedes the checkpointer):
+    # the file holds the learning rate of the NEXT iteration to run
+    lr = lr_at(trainer.cfg, trainer.iter)
     groups, state = [], {}
     for i, n in enumerate(names):
         groups.append({"lr": lr, "momentum": S.MOMENTUM, "dampening": 0, "weight_decay": S.WEIGHT_DECAY,

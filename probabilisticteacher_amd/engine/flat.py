@@ -43,10 +43,14 @@ class FlatParams:
         self.grad = None
         self.on_zero_grad = []          # callbacks run at the start of every step (the gradient reducer re-arms itself)
 
+    GRAD_PAD = 64       # the gradient storage is padded to a multiple of this (reduce-scatter shards: any world size dividing 64)
+
     def attach_grads(self) -> torch.Tensor:
         """Point every trainable parameter's .grad at a view of one flat buffer (autograd accumulates in place)."""
         if self.grad is None:
-            self.grad = torch.zeros(self.n_trainable, dtype=torch.float32, device=self.flat.device)
+            padded = (self.n_trainable + self.GRAD_PAD - 1) // self.GRAD_PAD * self.GRAD_PAD
+            self.grad_storage = torch.zeros(padded, dtype=torch.float32, device=self.flat.device)
+            self.grad = self.grad_storage[: self.n_trainable]
         for n, p in self.params.items():
             if p.requires_grad:
                 off, k = self.index[n]
@@ -54,9 +58,11 @@ class FlatParams:
         return self.grad
 
     def zero_grad(self) -> None:
-        self.attach_grads().zero_()
+        # callbacks first: the gradient reducer waits for collectives an abandoned step may have left in flight -- they
+        # write into this buffer, so it is zeroed only after they have drained
         for fn in self.on_zero_grad:
             fn()
+        self.attach_grads().zero_()
 
     def trainable(self) -> torch.Tensor:
         return self.flat[: self.n_trainable]
@@ -87,10 +93,15 @@ class BucketedGradReducer:
     left (parameters that received no gradient this step keep their zeros), waits, and divides by the world size."""
 
     def __init__(self, fp: FlatParams, world_size: int, bucket_elems: int = 16 * 1024 * 1024, group=None,
-                 force: bool = False):
+                 force: bool = False, mode: str = "all_reduce"):
         """force: install the hooks and run the collectives even for world_size 1 (the sum over one rank is the identity;
-        used to exercise the RCCL / stream-ordering path on a single GPU)."""
-        self.fp, self.world, self.group = fp, world_size, group
+        used to exercise the RCCL / stream-ordering path on a single GPU).
+        mode: "all_reduce" -- one all-reduce per bucket; "reduce_scatter" -- the same exchange spelled as reduce-scatter +
+        all-gather per bucket (on the fully connected xGMI mesh each rank then owns 1/W of a bucket and the
+        two halves use all seven links; which of the two RCCL runs faster is a measurement for the first 8-GPU node)."""
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"unknown gradient exchange {mode!r}")
+        self.fp, self.world, self.group, self.mode = fp, world_size, group, mode
         self.active = world_size > 1 or force
         grad = fp.attach_grads()
         names = [n for n, p in fp.params.items() if p.requires_grad]
@@ -106,13 +117,35 @@ class BucketedGradReducer:
                     self.bucket_of[m] = len(self.buckets)
                 self.buckets.append((off, end))
                 end, members = off, []
-        self.size = [sum(1 for b in self.bucket_of.values() if b == i) for i in range(len(self.buckets))]
+        if mode == "reduce_scatter":
+            # bucket boundaries on multiples of the world size (equal shards): a cut moves UP to the next multiple, i.e. the
+            # first elements of a bucket's lowest parameter travel with the following (later) bucket -- which therefore also
+            # waits for that parameter; the buffer's padded tail belongs to bucket 0
+            w = max(world_size, 1)
+            assert fp.GRAD_PAD % w == 0, f"world size {w} must divide {fp.GRAD_PAD}"
+            cuts = [min((s + w - 1) // w * w, fp.grad_storage.numel()) for s, _ in self.buckets]
+            ends = [fp.grad_storage.numel()] + cuts[:-1]
+            self.buckets = [(s, e) for s, e in zip(cuts, ends)]
+            assert self.buckets[-1][0] == 0 and all(e > s for s, e in self.buckets)
+            names_in = {i: set() for i in range(len(self.buckets))}
+            for n in names:
+                off, k = fp.index[n]
+                for i, (s, e) in enumerate(self.buckets):
+                    if off < e and off + k > s:
+                        names_in[i].add(n)
+            self.members = names_in
+            self.shards = [torch.empty((e - s) // w, dtype=torch.float32, device=grad.device) for s, e in self.buckets]
+        else:
+            self.members = {i: {n for n, b in self.bucket_of.items() if b == i} for i in range(len(self.buckets))}
+        self.size = [len(self.members[i]) for i in range(len(self.buckets))]
+        self.bytes_per_step = 4 * sum(e - s for s, e in self.buckets)
         self._grad = grad
         self._hooks = []
         if self.active:
             for n in names:
                 p = fp.params[n]
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(self.bucket_of[n])))
+                self._hooks.append(p.register_post_accumulate_grad_hook(
+                    self._make_hook([i for i in range(len(self.buckets)) if n in self.members[i]])))
         self.reset()
         # re-arm at the start of every step: a backward() that was not followed by finish() (an exception mid-step, a
         # test) must not leave stale ready-counts behind
@@ -126,15 +159,22 @@ class BucketedGradReducer:
         self.handles = []
         self.launched_in_backward = 0               # (diagnostic) buckets that left before finish()
 
-    def _make_hook(self, b: int):
+    def _make_hook(self, bs):
         def hook(_param):
-            self.pending[b] -= 1
+            for b in bs:
+                self.pending[b] -= 1
             self._launch_ready()
         return hook
 
     def _launch(self, b: int):
         s, e = self.buckets[b]
-        self.handles.append(dist.all_reduce(self._grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.mode == "all_reduce":
+            self.handles.append(dist.all_reduce(self._grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:       # collectives of one process group run in issue order: the all-gather follows its reduce-scatter
+            buf = self.fp.grad_storage[s:e]
+            self.handles.append(dist.reduce_scatter_tensor(self.shards[b], buf, op=dist.ReduceOp.SUM, group=self.group,
+                                                           async_op=True))
+            self.handles.append(dist.all_gather_into_tensor(buf, self.shards[b], group=self.group, async_op=True))
 
     def _launch_ready(self):
         while self.next < len(self.buckets) and self.pending[self.next] <= 0:
@@ -157,6 +197,24 @@ class BucketedGradReducer:
         self.reset()
         self.launched_in_backward = n_early
         return self._grad
+
+
+def replica_checksum(flat: torch.Tensor) -> torch.Tensor:
+    """Order-independent exact checksum of a flat fp32 buffer: the int64 sum of its bit patterns (one device scalar)."""
+    return flat.view(torch.int32).to(torch.int64).sum()
+
+
+def replicas_identical(flat: torch.Tensor, group=None):
+    """Data parallelism keeps the replicas bit-identical: every rank applies the same averaged gradient to the same
+    parameters (reference trainer.py:92-95; no parameter broadcast after start-up).  Returns (all equal?, per-rank checksums);
+    one all-gather of one int64 per rank."""
+    mine = replica_checksum(flat).reshape(1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True, [int(mine.item())]
+    allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(allv, mine, group=group)
+    vals = [int(v.item()) for v in allv]
+    return all(v == vals[0] for v in vals), vals
 
 
 def broadcast_(flat: torch.Tensor, src: int = 0, group=None):

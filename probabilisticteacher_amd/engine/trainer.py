@@ -21,13 +21,16 @@ from .flat import BucketedGradReducer, FlatParams, broadcast_
 
 class PTrainer:
     def __init__(self, cfg, data_loader=None, ratio_fn: Optional[Callable[[], float]] = None,
-                 force_grad_reducer: bool = False):
+                 force_grad_reducer: bool = False, grad_reduce: str = "all_reduce"):
         """force_grad_reducer: run the bucketed gradient all-reduce (hooks + collectives) even with one rank -- needs an
-        initialised process group; the sum over one rank is the identity (single-GPU validation of the DDP path)."""
+        initialised process group; the sum over one rank is the identity (single-GPU validation of the DDP path).
+        grad_reduce: "all_reduce" or "reduce_scatter" (engine/flat.py: BucketedGradReducer)."""
         self.cfg = cfg
         check_optimizer_options(cfg)
-        # reference trainer.py:98 (cfg.SOLVER.AMP.ENABLED): mixed precision for the conv / FC GEMMs (see ops.py)
-        ops.set_operand_rounding("bf16" if cfg.SOLVER.AMP.ENABLED else None)
+        # reference trainer.py:98 (cfg.SOLVER.AMP.ENABLED): mixed precision for the conv / FC GEMMs (see ops.py).  The mode
+        # belongs to THIS trainer and is applied around each of its steps (ops.operand_rounding): "bf16", None, or -- for
+        # the comparison runs of tools/ and tests/ -- "bf16_emulate"
+        self.operand_rounding = "bf16" if cfg.SOLVER.AMP.ENABLED else None
         self.world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.model = build_model(cfg)                  # student
         self.model_teacher = build_model(cfg)          # teacher (per-rank replica, never all-reduced)
@@ -43,7 +46,7 @@ class PTrainer:
         self.momentum_buf = torch.zeros_like(self.student.trainable())
         # gradient exchange overlapped with backward: 16 MB buckets from the tail of the flat buffer (box head first)
         self.reducer = BucketedGradReducer(self.student, self.world_size, bucket_elems=4 * 1024 * 1024,
-                                           force=force_grad_reducer)
+                                           force=force_grad_reducer, mode=grad_reduce)
         self._first_step = True
         self.joint_student_pass = True      # one backbone pass for the two student branches when they share a canvas
         self.ensem_ts_model = EnsembleTSModel(self.model_teacher, self.model)
@@ -134,6 +137,10 @@ class PTrainer:
 
     # ------------------------------------------------------------------ the step (trainer.py:263-392)
     def run_step(self, data=None) -> Dict[str, float]:
+        with ops.operand_rounding(self.operand_rounding):
+            return self._run_step(data)
+
+    def _run_step(self, data=None) -> Dict[str, float]:
         assert self.model.training, "[PTrainer] model was changed to eval mode!"
         start = time.perf_counter()
         if data is None:
@@ -238,12 +245,38 @@ class PTrainer:
         raise ValueError("Unknown test evaluator.")
 
     @classmethod
-    def test(cls, cfg, model, data_loader, class_names, is_2007: bool = False):
-        """DefaultTrainer.test for one dataset: eval-mode inference over `data_loader` (batches of records with ground
-        truth) + the evaluator; returns {"bbox": {"AP", "AP50", "AP75"}, ...}.  The reference's eval hooks call this for
-        the student (results suffixed `_student`) and the teacher (trainer.py:529-542)."""
+    def build_train_loader(cls, cfg):
+        """trainer.py:139-141 -> pt/data/build.py:107: the two-crop semi-supervised loader over cfg.DATASETS.TRAIN_LABEL /
+        TRAIN_UNLABEL (device-side mapper, data/build.py)"""
+        from ..data import build_detection_semisup_train_loader_two_crops
+        return build_detection_semisup_train_loader_two_crops(cfg)
+
+    @classmethod
+    def build_test_loader(cls, cfg, dataset_name):
+        from ..data import build_detection_test_loader
+        return build_detection_test_loader(cfg, dataset_name)
+
+    @classmethod
+    def test(cls, cfg, model, data_loader=None, class_names=None, is_2007: bool = False):
+        """DefaultTrainer.test(cfg, model): eval-mode inference + the evaluator over every dataset of cfg.DATASETS.TEST
+        (results keyed by dataset name when there are several, flat for one -- D2's convention), or over an explicit
+        `data_loader` of record batches with `class_names`.  Returns {"bbox": {"AP", "AP50", "AP75"}, ...}; on ranks other than
+        0 of a multi-rank run the evaluator returns None (predictions are gathered on rank 0) and so does this."""
         from ..evaluation import inference_on_dataset
-        return inference_on_dataset(model, data_loader, cls.build_evaluator(cfg, class_names, is_2007))
+        amp = "bf16" if cfg.SOLVER.AMP.ENABLED else None
+        if data_loader is not None:
+            with ops.operand_rounding(amp):
+                return inference_on_dataset(model, data_loader, cls.build_evaluator(cfg, class_names, is_2007))
+        from ..data import datasets
+        results = {}
+        for name in cfg.DATASETS.TEST:
+            meta = datasets.metadata(name)
+            with ops.operand_rounding(amp):
+                results[name] = inference_on_dataset(model, cls.build_test_loader(cfg, name),
+                                                     cls.build_evaluator(cfg, meta["thing_classes"], meta["year"] == 2007))
+        if len(results) == 1:
+            results = list(results.values())[0]
+        return results
 
     # ------------------------------------------------------------------ trainer shell (trainer.py:466-547)
     def resume_or_load(self, resume: bool = False):
@@ -259,11 +292,30 @@ class PTrainer:
             self.iter = self.start_iter = int(t.item())
         return inc
 
-    def train(self, start_iter: Optional[int] = None, max_iter: Optional[int] = None, log_period: int = 20):
-        """TrainerBase.train with the reference's hooks (trainer.py:498-547) that do not need a dataset: LR schedule
-        (folded into the fused step), PeriodicCheckpointer (rank 0: model_{iter:07d}.pth every CHECKPOINT_PERIOD
-        iterations, model_final.pth, `last_checkpoint`), PeriodicWriter every 20 iterations (console line + one JSON
-        record per line in OUTPUT_DIR/metrics.json, D2's JSONWriter format)."""
+    def _run_eval_hooks(self, eval_fn) -> Dict[str, float]:
+        """trainer.py:529-542: `test_and_save_results_student` (keys suffixed `_student`) then `..._teacher`, each an EvalHook;
+        results flattened the way D2's EvalHook does (`bbox_student/AP50`, `bbox/AP50`) for the metrics writer."""
+        res_s = eval_fn(self.cfg, self.model)
+        self._last_eval_results_student = res_s
+        res_t = eval_fn(self.cfg, self.model_teacher)
+        self._last_eval_results_teacher = res_t
+        flat = {}
+        for res, sfx in ((res_s, "_student"), (res_t, "")):
+            for k, v in (res or {}).items():
+                if isinstance(v, dict):
+                    for kk, vv in v.items():
+                        if isinstance(vv, (int, float)):
+                            flat[f"{k}{sfx}/{kk}"] = float(vv)
+        return flat
+
+    def train(self, start_iter: Optional[int] = None, max_iter: Optional[int] = None, log_period: int = 20, eval_fn=None,
+              run_eval: bool = True):
+        """TrainerBase.train with the reference's hooks (trainer.py:498-547): LR schedule (folded into the fused step),
+        PeriodicCheckpointer (rank 0: model_{iter:07d}.pth every CHECKPOINT_PERIOD iterations, model_final.pth,
+        `last_checkpoint`), the two EvalHooks (student, then teacher, every TEST.EVAL_PERIOD iterations and after the last
+        one; `eval_fn(cfg, model)` defaults to `PTrainer.test` over cfg.DATASETS.TEST), PeriodicWriter every 20 iterations
+        (console line + one JSON record per line in OUTPUT_DIR/metrics.json, D2's JSONWriter format; evaluation results ride
+        on the next record, as D2's storage does)."""
         import json
         import os
         from .. import checkpoint
@@ -276,14 +328,25 @@ class PTrainer:
         if rank0:
             os.makedirs(out_dir, exist_ok=True)
         t_last, it_last = time.perf_counter(), self.iter
+        period = int(self.cfg.TEST.EVAL_PERIOD)
+        eval_fn = eval_fn or type(self).test
+        pending_eval: Dict[str, float] = {}
         while self.iter < max_iter:
             it = self.iter
             m = self.run_step()
             if ckpt is not None:
                 ckpt.step(it)
+            # D2 EvalHook: after every `period`-th iteration (after_step) and once after the last one (after_train)
+            if run_eval and ((period > 0 and (it + 1) % period == 0) or it + 1 >= max_iter):
+                flat = self._run_eval_hooks(eval_fn)
+                pending_eval.update(flat)
+                if rank0 and flat:
+                    print(f"eval @ iter {it}: " + "  ".join(f"{k}: {v:.4f}" for k, v in sorted(flat.items())), flush=True)
             if rank0 and ((it + 1) % log_period == 0 or it == max_iter - 1):
                 now = time.perf_counter()
                 rec = dict(m, iteration=it, lr=lr_at(self.cfg, it), time=(now - t_last) / max(it + 1 - it_last, 1))
+                rec.update(pending_eval)
+                pending_eval = {}
                 t_last, it_last = now, it + 1
                 with open(os.path.join(out_dir, "metrics.json"), "a") as f:
                     f.write(json.dumps(rec, sort_keys=True) + "\n")

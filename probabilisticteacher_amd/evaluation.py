@@ -118,7 +118,26 @@ class PascalVOCDetectionEvaluator:
                 line = f"{score:.3f} {xmin + 1:.1f} {ymin + 1:.1f} {xmax:.1f} {ymax:.1f}".split(" ")
                 self._predictions[cls].append((image_id,) + tuple(float(v) for v in line))
 
-    def evaluate(self) -> "OrderedDict[str, dict]":
+    def _gather(self):
+        """D2's evaluator gathers every rank's predictions on rank 0 before scoring (comm.gather of the pickled lists); the
+        ground truth of the images a rank processed travels with them.  Non-zero ranks return None from evaluate()."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return True
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, (dict(self._predictions), self._gt))
+        if dist.get_rank() != 0:
+            return False
+        self._predictions, self._gt = defaultdict(list), {}
+        for preds, gt in parts:
+            for c, lines in preds.items():
+                self._predictions[c].extend(lines)
+            self._gt.update(gt)
+        return True
+
+    def evaluate(self) -> "Optional[OrderedDict[str, dict]]":
+        if not self._gather():
+            return None
         aps = defaultdict(list)                       # iou threshold (percent) -> per-class APs
         for cls_id, _ in enumerate(self._class_names):
             dets = self._predictions.get(cls_id, [])

@@ -163,7 +163,14 @@ class GuassianFastRCNNOutputLayers(nn.Module):
             deltas.contiguous(), pb, probs, roi_img, hw, K, self.box2box_transform.weights,
             self.box2box_transform.scale_clamp, self.test_score_thresh)
         seg = ops.dev_i32([K * o for o in roff], dev)                     # dense (roi, class) segments per image
+        # NMS capacity = the dense segment length K * max R_i (no host read to learn the candidate count).  Memory law of the
+        # bitmask workspace: images * cap * ceil(cap / 64) * 8 bytes -- 32 MB per image at K = 8, R = 2000 (the shipped
+        # configs, ~0.5 GB for 16 images), ~200 MB per image at K = 20, ~3.2 GB per image at K = 80; the scan kernel keeps one
+        # row of the mask in LDS, which caps cap at 524 288 candidates per image.
         cap = K * max(counts) if counts else 0
+        if cap > 524288:
+            raise ValueError(f"ROI inference: {K} classes x {max(counts)} proposals = {cap} NMS candidates per image exceed the "
+                             "524 288 the single-pass bitmask NMS holds; lower MODEL.RPN.POST_NMS_TOPK_TEST")
         srt, order = ops.segsort_desc(keys.view(-1), seg)
         nms_boxes = ops.roi_infer_nms_boxes(boxes, order, seg, img_max, cap, K)
         topk = self.test_topk_per_image if self.test_topk_per_image >= 0 else max(cap, 1)

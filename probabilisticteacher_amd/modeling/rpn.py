@@ -131,7 +131,9 @@ class GuassianRPN(nn.Module):
             losses = self._losses_unsup(anchors, logits, d8, gt_instances)
         elif self.training and compute_loss:
             losses = self._losses_sup(anchors, logits, d8, gt_instances)
-            losses = {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+            # the reference weights the supervised RPN losses TWICE -- inside `losses` (rpn.py:254) and again here
+            # (rpn.py:141) -- and the unsupervised ones not at all (rpn.py:347-360); invisible at the shipped 1.0
+            losses = {k: v * self.loss_weight.get(k, 1.0) * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
         else:
             losses = {}
         proposals = self.predict_proposals(anchors, logits, d8, images.image_sizes)

@@ -8,9 +8,9 @@ Here every candidate gets an i.i.d. random key and the k smallest keys win (== t
 argsort(keys[candidates])): the same uniformly random k-subsets, computed for the whole batch without a host sync.
 
 The only injection point is the key source (`set_key_source`), the counterpart of seeding the reference's global RNG:
-parity tests hand in keys that encode a given sequence of permutations (tests/helpers.py: `perm_key_source` for the
-permutations recorded from the real reference, `keyed_perm_source` for the oracle's KeyedPerm), so the golden fixtures
-and the oracle comparisons run through exactly this code."""
+parity tests hand in keys that encode a given sequence of permutations (`perm_key_source` below for the permutations recorded
+from the real reference, `keyed_perm_source` for a shared keyed stream), so the golden fixtures and the oracle comparisons
+run through exactly this code."""
 from typing import Callable, List, Optional
 
 import torch
@@ -26,6 +26,37 @@ def set_key_source(fn: Optional[KeySource]) -> None:
     """None = torch.rand on the device (production)."""
     global _KEY_SOURCE
     _KEY_SOURCE = fn
+
+
+def perm_key_source(perm_fn) -> KeySource:
+    """Keys that make the keyed sampler select exactly `pos[perm_fn(len(pos))[:k]]`, `neg[perm_fn(len(neg))[:k]]` -- image by
+    image, positives first: the order in which the reference draws its two `randperm`s (D2 subsample_labels).  Candidate j of
+    a permutation gets key (rank + .5) / (n + 1), so ascending key order == permutation order.  `perm_fn(n)` returns a
+    permutation of range(n): a replay of recorded `randperm` results, or a seeded generator -- the counterpart of seeding the
+    reference's global RNG."""
+    def src(labels, sizes, bg_label):
+        lab = labels.detach().cpu()
+        keys = torch.zeros(lab.shape, dtype=torch.float32)
+        if sizes is None:
+            rows, krows = list(lab), list(keys)
+        else:
+            rows, krows = list(torch.split(lab, [int(s) for s in sizes])), list(torch.split(keys, [int(s) for s in sizes]))
+        for lb, k in zip(rows, krows):
+            for idx in (torch.nonzero((lb != -1) & (lb != bg_label)).squeeze(1), torch.nonzero(lb == bg_label).squeeze(1)):
+                p = perm_fn(int(idx.numel()))
+                k[idx[p]] = (torch.arange(idx.numel(), dtype=torch.float32) + 0.5) / (idx.numel() + 1)
+        return keys
+    return src
+
+
+def keyed_perm_source(kp) -> KeySource:
+    """A keyed-permutation object (`kp.draw(shape)` -> uniform keys, e.g. a seeded stream shared with another implementation)
+    as the key source: one key row per image, in image order."""
+    def src(labels, sizes, bg_label):
+        if sizes is None:
+            return kp.draw(tuple(labels.shape))
+        return torch.cat([kp.draw((int(s),)) for s in sizes]) if len(sizes) else torch.zeros(0)
+    return src
 
 
 def draw_keys(labels: torch.Tensor, sizes: Optional[List[int]], bg_label: int) -> torch.Tensor:

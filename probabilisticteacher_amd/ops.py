@@ -6,6 +6,7 @@ There is no CPU path: tensors must live on a ROCm device and the shared library 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import math
 from typing import List, Optional, Sequence, Tuple
@@ -66,25 +67,29 @@ def profile_start() -> None:
 
 
 def profile_stop() -> dict:
-    """Synchronise and return {kernel: {"ms", "flops", "bytes", "calls"}} accumulated since profile_start()."""
+    """Synchronise and return {kernel: {"ms", "flops", "issued", "bytes", "calls"}} accumulated since profile_start()."""
     global _PROF
     rec, _PROF = _PROF or [], None
     torch.cuda.synchronize()
     out = {}
-    for name, flops, nbytes, e0, e1 in rec:
-        d = out.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "calls": 0})
+    for name, flops, nbytes, issued, e0, e1 in rec:
+        d = out.setdefault(name, {"ms": 0.0, "flops": 0.0, "issued": 0.0, "bytes": 0.0, "calls": 0})
         d["ms"] += e0.elapsed_time(e1)
         d["flops"] += flops
+        d["issued"] += issued
         d["bytes"] += nbytes
         d["calls"] += 1
     return out
 
 
 class _prof:
-    """flops / nbytes = ALGORITHMIC work of the launch group (every operand read once, every result written once)."""
+    """flops / nbytes = ALGORITHMIC work of the launch group (every operand read once, every result written once; for a
+    convolution the DIRECT-convolution FLOPs, whatever algorithm runs); issued = FLOPs of the MFMA instructions the launch
+    actually issues (Winograd: 16 instead of 36 multiplies per 2x2 tile and channel pair, plus its tile padding)."""
 
-    def __init__(self, name, flops=0.0, nbytes=0.0):
+    def __init__(self, name, flops=0.0, nbytes=0.0, issued=None):
         self.name, self.flops, self.nbytes = name, float(flops), float(nbytes)
+        self.issued = float(flops if issued is None else issued)
 
     def __enter__(self):
         if _PROF is not None:
@@ -96,7 +101,7 @@ class _prof:
     def __exit__(self, *exc):
         if _PROF is not None:
             self.e1.record()
-            _PROF.append((self.name, self.flops, self.nbytes, self.e0, self.e1))
+            _PROF.append((self.name, self.flops, self.nbytes, self.issued, self.e0, self.e1))
         return False
 
 
@@ -119,6 +124,18 @@ def set_operand_rounding(mode: Optional[str]) -> None:
     if mode not in (None, "bf16", "bf16_emulate"):
         raise ValueError(f"unknown operand rounding {mode!r}")
     _OPERAND_ROUNDING = mode
+
+
+@contextlib.contextmanager
+def operand_rounding(mode: Optional[str]):
+    """Scope the operand-rounding mode: a trainer (or an evaluation) carries its own mode and applies it around its forward /
+    backward, so that two models with different SOLVER.AMP settings in one process do not change each other's numerics."""
+    prev = _OPERAND_ROUNDING
+    set_operand_rounding(mode)
+    try:
+        yield
+    finally:
+        set_operand_rounding(prev)
 
 
 def _rnd(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -161,6 +178,15 @@ def set_conv_algo(mode: str) -> None:
     _CONV_ALGO = mode
 
 
+def wino_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
+    """FLOPs of the v_mfma_f32_32x32x2_f32 instructions one ptmi_conv3x3_wino_fwd launch issues: a wave runs 16 MFMAs
+    (4096 FLOP each) per 2-channel k-step for its 32 channels x 32 tiles (= 4 rows x 32 columns of pixels); waves whose rows
+    lie wholly below the image issue none.  (Checked against SQ_INSTS_VALU_MFMA_MOPS_F32, profiles/r03_*.)"""
+    co_tiles, tiles_x, chunks = -(-cout // 64), -(-w // 32), -(-cin // 8)
+    waves = n * co_tiles * tiles_x * (-(-h // 4)) * 2
+    return float(waves) * chunks * 4 * 16 * 4096
+
+
 def _use_wino(conv_cin: int) -> bool:
     return _CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and conv_cin >= _WINO_MIN_CIN
 
@@ -200,7 +226,7 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
     nbytes = 4.0 * (n * h * w * (cin + cout * (2 if epilogue == 3 else 1)) + 9 * cin * cout)
     if _use_wino(cin):
-        with _prof("conv3x3_wino", 2.0 * 9 * cin * cout * h * w * n, nbytes):
+        with _prof("conv3x3_wino", 2.0 * 9 * cin * cout * h * w * n, nbytes, wino_issued_flops(n, cin, cout, h, w)):
             _lib.call("ptmi_conv3x3_wino_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
                       epilogue, _stream())
         return y
@@ -222,7 +248,8 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
     wino = _use_wino(cin)
     with _prof("conv3x3_wino" if wino else "conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n,
-               4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout)):
+               4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout),
+               wino_issued_flops(n, cin, cout, h, w) if wino else None):
         _lib.call("ptmi_conv3x3_wino_fwd" if wino else _conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None,
                   _ptr(y), n, cin, cout, h, w, 4, _stream())
     return y

@@ -1,0 +1,56 @@
+"""Shared by tools/gen_loss_curve_golden.py (CPU oracle, dev container) and tests/test_config4_gpu.py (HIP trainer, GPU box):
+the workload of the bounded configs[4] loss-curve test -- final_s2c.yaml (Sim10k -> Cityscapes, K = 1), synthetic records
+whose objects are learnable in a few dozen iterations, the shrink ratios and the sampler-key seeds of every iteration.
+
+Nothing here depends on a GPU or on the reference; both sides rebuild the identical inputs from the constants below."""
+import random
+
+import torch
+
+SETTINGS = dict(height=192, width=256, batch=2, pool=8, data_seed=2024, ratio_seed=5,
+                burn=180, iters=300, base_lr=0.02, warmup_iters=20, window=30, param_seed=101,
+                obj_min=0.30, obj_max=0.65)      # object extent as a fraction of the image extent (anchors are 128-512 px)
+LOSS_KEYS = ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")
+KEY_SEEDS = (1000, 5000, 9000)     # sampler-key seeds: one trajectory each (iteration `it` of a trajectory uses seed + it)
+
+
+def make_pool(settings, K):
+    """`pool` batches of (label_q, label_k, unlabel_q, unlabel_k) as plain CPU tensors:
+    [{"image": uint8 (3,H,W), "boxes": (M,4), "classes": (M,)}] -- bright rectangles on dim noise; the strong view adds
+    pixel noise.  The caller wraps them into its own Instances type."""
+    h, w, n = settings["height"], settings["width"], settings["batch"]
+    gen = torch.Generator().manual_seed(settings["data_seed"])
+    pool = []
+    for _ in range(settings["pool"]):
+        streams = [[], [], [], []]
+        for stream in (0, 2):
+            for _ in range(n):
+                m = int(torch.randint(1, 4, (1,), generator=gen))
+                lo, hi = settings["obj_min"], settings["obj_max"]
+                wh = (lo + torch.rand(m, 2, generator=gen) * (hi - lo)) * torch.tensor([float(w), float(h)])
+                xy = torch.rand(m, 2, generator=gen) * (torch.tensor([float(w), float(h)]) - wh)
+                boxes = torch.cat([xy, xy + wh], 1)
+                cls = torch.randint(0, K, (m,), generator=gen)
+                base = torch.randint(0, 96, (3, h, w), generator=gen, dtype=torch.uint8)
+                for b in boxes.long().tolist():
+                    base[:, b[1]:b[3], b[0]:b[2]] += 120
+                for view in (0, 1):
+                    img = base.clone()
+                    if view == 0:
+                        img = (img.int() + torch.randint(-20, 21, img.shape, generator=gen)).clamp(0, 255).to(torch.uint8)
+                    streams[stream + view].append({"image": img, "boxes": boxes.clone(), "classes": cls.clone()})
+        pool.append(tuple(streams))
+    return pool
+
+
+def ratio_schedule(settings):
+    """per iteration: (label ratios, unlabel ratios) -- PTrainer.resize draws unlabel_q first, then label_q (trainer.py:329-330)"""
+    rng = random.Random(settings["ratio_seed"])
+    out = []
+    for it in range(settings["iters"]):
+        burn = it < settings["burn"]
+        n_lab = 2 * settings["batch"] if burn else settings["batch"]
+        r_lab = [rng.uniform(0.5, 1.0) for _ in range(n_lab)]
+        r_unl = [] if burn else [rng.uniform(0.5, 1.0) for _ in range(settings["batch"])]
+        out.append((r_lab, r_unl))
+    return out

@@ -76,31 +76,4 @@ def match_detections(boxes_a, cls_a, boxes_b, cls_b, box_tol=5e-3):
 
 
 # ------------------------------------------------------------------ key sources for the product's sampler
-def perm_key_source(perm_fn):
-    """Keys that make the product's keyed sampler (probabilisticteacher_amd/modeling/sampling.py) select exactly
-    `pos[perm_fn(len(pos))[:k]]`, `neg[perm_fn(len(neg))[:k]]` -- image by image, positives first: the order in which the
-    reference draws its two `randperm`s (D2 subsample_labels).  Candidate j of a permutation gets key (rank + .5)/(n + 1),
-    so ascending key order == permutation order.  `perm_fn` is e.g. oracle.pt.SeededPerm replaying the permutations the
-    golden fixtures were generated with."""
-    def src(labels, sizes, bg_label):
-        lab = labels.detach().cpu()
-        keys = torch.zeros(lab.shape, dtype=torch.float32)
-        if sizes is None:
-            rows, krows = list(lab), list(keys)
-        else:
-            rows, krows = list(torch.split(lab, [int(s) for s in sizes])), list(torch.split(keys, [int(s) for s in sizes]))
-        for l, k in zip(rows, krows):
-            for idx in (torch.nonzero((l != -1) & (l != bg_label)).squeeze(1), torch.nonzero(l == bg_label).squeeze(1)):
-                p = perm_fn(int(idx.numel()))
-                k[idx[p]] = (torch.arange(idx.numel(), dtype=torch.float32) + 0.5) / (idx.numel() + 1)
-        return keys
-    return src
-
-
-def keyed_perm_source(kp):
-    """The oracle's KeyedPerm as the product's key source: one key row per image, in image order."""
-    def src(labels, sizes, bg_label):
-        if sizes is None:
-            return kp.draw(tuple(labels.shape))
-        return torch.cat([kp.draw((int(s),)) for s in sizes]) if len(sizes) else torch.zeros(0)
-    return src
+from probabilisticteacher_amd.modeling.sampling import keyed_perm_source, perm_key_source  # noqa: E402,F401

@@ -39,7 +39,9 @@ def _batch(gen, n, h, w, K):
     return tuple(synth_records(gen, n, h, w, K, DEV) for _ in range(4))
 
 
-def test_bucketed_rccl_allreduce_in_run_step_is_bitwise_identity(rccl_world1):
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
+def test_bucketed_rccl_allreduce_in_run_step_is_bitwise_identity(rccl_world1, mode):
+    """`mode`: one all-reduce per bucket, or the same exchange as reduce-scatter + all-gather on shard-aligned buckets"""
     from probabilisticteacher_amd.config import setup_cfg
     from probabilisticteacher_amd.engine import PTrainer
     from probabilisticteacher_amd.modeling import sampling
@@ -50,7 +52,7 @@ def test_bucketed_rccl_allreduce_in_run_step_is_bitwise_identity(rccl_world1):
     for force in (False, True):
         torch.manual_seed(0)
         ratios = iter([0.8, 0.6, 0.9, 0.7, 0.75, 0.65, 0.85, 0.55] * 2)
-        tr = PTrainer(cfg, ratio_fn=lambda: next(ratios), force_grad_reducer=force)
+        tr = PTrainer(cfg, ratio_fn=lambda: next(ratios), force_grad_reducer=force, grad_reduce=mode)
         assert tr.reducer.active == force and len(tr.reducer.buckets) >= 4
         gen = torch.Generator().manual_seed(77)
         keyg = torch.Generator().manual_seed(5)

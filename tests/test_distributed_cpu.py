@@ -166,3 +166,51 @@ def test_write_metrics_reference_semantics_with_rank_dependent_keys():
     assert set(m0) == {"loss_cls_sup", "loss_rpn_cls_sup", "loss_cls_unsup", "total_loss", "grad_norm", "data_time"}
     assert m0["loss_cls_sup"] == 1.5 and m0["loss_rpn_cls_sup"] == 1.5 and m0["loss_cls_unsup"] == 2.5
     assert m0["total_loss"] == 5.5 and m0["data_time"] == 1.25 and m0["grad_norm"] == 2.0 and out[1]["grad_norm"] == 4.0
+
+
+def _worker_checksum(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from probabilisticteacher_amd.engine.flat import BucketedGradReducer, FlatParams, broadcast_, replicas_identical
+    torch.manual_seed(3 + rank)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    flat = FlatParams(model)
+    same_before, _ = replicas_identical(flat.flat)            # different seeds: replicas differ
+    broadcast_(flat.flat)
+    red = BucketedGradReducer(flat, world, bucket_elems=20)
+    g = torch.Generator().manual_seed(50 + rank)                # rank-local data
+    for _ in range(3):                                          # three data-parallel SGD steps
+        flat.zero_grad()
+        ((model(torch.randn(4, 6, generator=g)) - torch.randn(4, 3, generator=g)) ** 2).mean().backward()
+        grad = red.finish()
+        with torch.no_grad():
+            flat.trainable().add_(grad, alpha=-0.1)
+    same_after, sums = replicas_identical(flat.flat)
+    if rank == 1:
+        with torch.no_grad():
+            flat.flat[5] += 1e-6                                # one rank drifts by one ulp-ish step
+    same_drift, _ = replicas_identical(flat.flat)
+    q.put((rank, same_before, same_after, same_drift, sums, red.bytes_per_step, flat.n_trainable))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replica_checksums_detect_divergence_across_ranks():
+    """what bench.py asserts after the timed steps at N > 1: data-parallel replicas stay bit-identical (int64 sum of the
+    parameters' bit patterns, one all-gather) -- and the check really fires when one rank drifts"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_checksum, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, before, after, drift, sums, nbytes, nt in out:
+        assert not before and after and not drift, (rank, before, after, drift)
+        assert len(sums) == 2 and sums[0] == sums[1]
+        assert nbytes == 4 * nt, "every trainable element is exchanged exactly once per step"
+

@@ -1,7 +1,9 @@
 """CPU: host-side logic of the plug-in layer (config, registry, structures, LR schedule, flat buffers, sampler)."""
+import itertools
 import math
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -317,3 +319,109 @@ def test_voc_evaluator_known_answers():
     assert res["per_class_AP50"] == {"car": 100.0, "person": 100.0}
     assert abs(res["bbox"]["AP50"] - 100.0) < 1e-9 and abs(res["bbox"]["AP75"] - 100.0) < 1e-9
     assert abs(res["bbox"]["AP"] - (100.0 * 10 + 100.0 * 7) / 20) < 1e-9
+
+
+def _write_voc_dir(root, ids, class_names, rng, h=96, w=128, with_difficult=True):
+    """a tiny VOC-format dataset: JPEGImages/<id>.jpg, Annotations/<id>.xml, ImageSets/Main/train.txt"""
+    import os
+    from PIL import Image
+    for sub in ("JPEGImages", "Annotations", "ImageSets/Main"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    truth = {}
+    for fid in ids:
+        img = rng.randint(0, 96, (h, w, 3)).astype(np.uint8)
+        m = int(rng.randint(1, 4))
+        objs = []
+        for _ in range(m):
+            bw, bh = int(rng.randint(24, 60)), int(rng.randint(20, 50))
+            x1, y1 = int(rng.randint(1, w - bw)), int(rng.randint(1, h - bh))
+            img[y1:y1 + bh, x1:x1 + bw] += 120
+            objs.append((class_names[int(rng.randint(len(class_names)))], x1, y1, x1 + bw, y1 + bh, int(with_difficult and rng.rand() < 0.25)))
+        objs.append(("ignored-class", 1, 1, 9, 9, 0))
+        Image.fromarray(img).save(os.path.join(root, "JPEGImages", fid + ".jpg"), quality=95)
+        xml = f"<annotation><size><width>{w}</width><height>{h}</height><depth>3</depth></size>" + "".join(
+            f"<object><name>{n}</name><difficult>{d}</difficult><bndbox><xmin>{a}</xmin><ymin>{b}</ymin><xmax>{c}</xmax><ymax>{e}</ymax>"
+            f"</bndbox></object>" for n, a, b, c, e, d in objs) + "</annotation>"
+        open(os.path.join(root, "Annotations", fid + ".xml"), "w").write(xml)
+        truth[fid] = objs[:-1]
+    open(os.path.join(root, "ImageSets", "Main", "train.txt"), "w").write("\n".join(ids) + "\n")
+    return truth
+
+
+def test_voc_directory_reader_and_training_sampler(tmp_path):
+    """pt/data/datasets/builtin.py + D2 load_voc_instances / TrainingSampler restated in probabilisticteacher_amd/data"""
+    from probabilisticteacher_amd.data import datasets, training_sampler
+    rng = np.random.RandomState(1)
+    names = ("car", "person")
+    truth = _write_voc_dir(str(tmp_path), ["a1", "b2", "c3"], names, rng)
+    datasets.register_pascal_voc("tiny_train", str(tmp_path), "train", names)
+    dicts = datasets.get_dataset_dicts(["tiny_train"], filter_empty=True)
+    assert [d["image_id"] for d in dicts] == ["a1", "b2", "c3"] and datasets.metadata("tiny_train")["thing_classes"] == list(names)
+    for d in dicts:
+        assert (d["height"], d["width"]) == (96, 128) and len(d["annotations"]) == len(truth[d["image_id"]])
+        for a, (n, x1, y1, x2, y2, diff) in zip(d["annotations"], truth[d["image_id"]]):
+            assert a["bbox"] == [x1 - 1.0, y1 - 1.0, float(x2), float(y2)] and a["category_id"] == names.index(n) and a["difficult"] == diff
+        m = datasets.to_mapper_input(d)
+        assert m["image"].dtype == torch.uint8 and tuple(m["image"].shape) == (3, 96, 128) and m["boxes"].shape == (len(d["annotations"]), 4)
+    with pytest.raises(KeyError):
+        datasets.get_dataset_dicts(["nope"])
+    a = list(itertools.islice(training_sampler(5, seed=3), 12))
+    b = list(itertools.islice(training_sampler(5, seed=3), 12))
+    assert a == b and sorted(a[:5]) == [0, 1, 2, 3, 4] and sorted(a[5:10]) == [0, 1, 2, 3, 4], "seeded epochs of a full permutation"
+
+
+def test_voc_evaluator_against_the_independent_oracle():
+    """probabilisticteacher_amd/evaluation.py against oracle/voc.py (written separately: plain-Python loops, no shared code) on
+    241 detections, 14 images, 3 classes, difficult objects, duplicate and cross-class detections, score ties after the
+    3-decimal text round trip -- AP / AP50 / AP75 to 1e-9, VOC2010+ and VOC2007 rules."""
+    from oracle import voc
+    from probabilisticteacher_amd.evaluation import PascalVOCDetectionEvaluator
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    rng = np.random.RandomState(0)
+    K = 3
+    for is07 in (False, True):
+        ev = PascalVOCDetectionEvaluator([f"c{i}" for i in range(K)], is_2007=is07)
+        dets, gt = [], {}
+        for iid in range(14):
+            m = int(rng.randint(0, 5))
+            b = rng.rand(m, 2) * 60
+            boxes = np.concatenate([b, b + 10 + rng.rand(m, 2) * 40], 1).astype(np.float32)
+            cls, diff = rng.randint(0, K, m), rng.rand(m) < 0.2
+            inst = FreeInstances((128, 128))
+            inst.gt_boxes, inst.gt_classes, inst.difficult = Boxes(torch.from_numpy(boxes)), torch.from_numpy(cls), torch.from_numpy(diff)
+            gt[iid] = [(int(c), *[float(v) for v in bb], bool(d)) for c, bb, d in zip(cls, boxes, diff)]
+            db, dc, ds = [], [], []
+            for _ in range(int(rng.randint(8, 28))):
+                if m and rng.rand() < 0.7:
+                    j = int(rng.randint(m))
+                    bb, c = boxes[j] + rng.randn(4) * 3, (cls[j] if rng.rand() < 0.85 else rng.randint(K))
+                else:
+                    q = rng.rand(2) * 60
+                    bb, c = np.concatenate([q, q + 10 + rng.rand(2) * 40]), rng.randint(K)
+                db.append(bb), dc.append(int(c)), ds.append(round(float(rng.rand()), 2))
+            out = FreeInstances((128, 128))
+            out.pred_boxes, out.scores = Boxes(torch.tensor(np.array(db), dtype=torch.float32)), torch.tensor(ds, dtype=torch.float32)
+            out.pred_classes = torch.tensor(dc)
+            ev.process([{"image_id": iid, "instances": inst}], [{"instances": out}])
+            dets += [(iid, c, float(s), *[float(v) for v in bb]) for bb, c, s in zip(out.pred_boxes.tensor.numpy(), dc, out.scores.tolist())]
+        assert len(dets) >= 200
+        got, ref = ev.evaluate()["bbox"], voc.evaluate(dets, gt, K, is_2007=is07)
+        for k in ("AP", "AP50", "AP75"):
+            assert 5.0 < ref[k] < 95.0 and abs(got[k] - ref[k]) < 1e-9, (k, got, ref)
+
+
+def test_eval_hooks_flatten_student_and_teacher_results():
+    """reference trainer.py:529-542: student results suffixed `_student`, teacher results plain, flattened like D2's EvalHook"""
+    from types import SimpleNamespace
+    from probabilisticteacher_amd.engine.trainer import PTrainer
+    me = SimpleNamespace(cfg=None, model="S", model_teacher="T")
+    calls = []
+
+    def fake_test(cfg, model):
+        calls.append(model)
+        return {"bbox": {"AP": 10.0 if model == "S" else 20.0, "AP50": 30.0, "AP75": 5.0}, "per_class_AP50": {"car": 1.0}}
+    flat = PTrainer._run_eval_hooks(me, fake_test)
+    assert calls == ["S", "T"], "student first, then teacher"
+    assert flat["bbox_student/AP"] == 10.0 and flat["bbox/AP"] == 20.0 and flat["bbox_student/AP50"] == 30.0
+    assert flat["per_class_AP50_student/car"] == 1.0 and me._last_eval_results_teacher["bbox"]["AP"] == 20.0
+

@@ -493,8 +493,10 @@ def test_baseline_config0_800x600_supervised_step_vs_oracle():
 def test_voc_evaluation_of_the_eval_path_matches_the_oracle_detections():
     """SURVEY.md 8f-2 end to end: `PTrainer.test` = eval-mode inference (rcnn.py:33-34) + the VOC evaluator
     (trainer.py:127-137) on a few labelled synthetic records, against the same evaluator fed with the CPU oracle's
-    detections: AP / AP50 / AP75 agree (score ranks that differ in the last ulp can move a detection across a precision
-    step: 2 points of tolerance)."""
+    detections, and -- the evaluator itself -- against the INDEPENDENT protocol restatement oracle/voc.py on the HIP
+    detections: AP / AP50 / AP75 to 1e-9.  (HIP vs oracle MODEL under the metric: score ranks that differ in the last ulp can
+    move a detection across a precision step, 2 points; the model outputs themselves are compared in
+    test_eval_mode_inference_matches_oracle.)"""
     from probabilisticteacher_amd import modeling
     from probabilisticteacher_amd.config import setup_cfg
     from probabilisticteacher_amd.engine import PTrainer
@@ -521,6 +523,22 @@ def test_voc_evaluation_of_the_eval_path_matches_the_oracle_detections():
     names = [f"c{i}" for i in range(K)]
     res = PTrainer.test(cfg, model, batches, names)
     assert model.training, "the previous mode is restored"
+    # the product evaluator vs the independent restatement, on the HIP model's own detections
+    from oracle import voc
+    model.eval()
+    dets, gts = [], {}
+    with torch.no_grad():
+        for recs in batches:
+            for r, o in zip(recs, model(recs)):
+                inst, gt = o["instances"], r["instances"]
+                dets += [(r["image_id"], int(c), float(s), *[float(v) for v in b]) for b, c, s in
+                         zip(inst.pred_boxes.tensor.cpu().numpy(), inst.pred_classes.cpu().tolist(), inst.scores.cpu().tolist())]
+                gts[r["image_id"]] = [(int(c), *[float(v) for v in b], False) for b, c in
+                                      zip(gt.gt_boxes.tensor.cpu().numpy(), gt.gt_classes.cpu().tolist())]
+    model.train()
+    ind = voc.evaluate(dets, gts, K)
+    for k in ("AP", "AP50", "AP75"):
+        assert abs(res["bbox"][k] - ind[k]) < 1e-9, (k, res["bbox"], ind)
     ev = PascalVOCDetectionEvaluator(names)
     for recs in batches:
         ev.process(recs, opt.model_inference(ocfg, params, [{k: v for k, v in r.items() if k != "instances"} for r in recs]))
@@ -552,8 +570,8 @@ def test_amp_step_native_bf16_kernels_match_emulated_rounding():
             cfg.SOLVER.AMP.ENABLED = mode is not None
             ratios = [float(v) for v in z["it0_ratios"]]
             tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
-            assert ops._OPERAND_ROUNDING == ("bf16" if mode else None)        # what the config flag selects
-            ops.set_operand_rounding(mode)
+            assert tr.operand_rounding == ("bf16" if mode else None)          # what the config flag selects
+            tr.operand_rounding = mode
             _load_params(tr.model, params)
             _load_params(tr.model_teacher, params)
             data = tuple(_gpu_records(z, f"it0_{nm}", B) for nm in ("lq", "lk", "uq", "uk"))
@@ -576,3 +594,41 @@ def test_amp_step_native_bf16_kernels_match_emulated_rounding():
     assert abs(mn["loss_rpn_cls"] - mf["loss_rpn_cls"]) > 1e-5 or abs(mn["loss_rpn_loc"] - mf["loss_rpn_loc"]) > 1e-5
     for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"):
         close(torch.tensor(mn[k]), torch.tensor(mf[k]), 5e-2, 1e-3, "bf16 vs fp32 " + k)
+
+
+def test_rpn_loss_weight_quirk_matches_the_reference():
+    """MODEL.RPN.LOSS_WEIGHT = 2, BBOX_REG_LOSS_WEIGHT = 0.5: the product reproduces the reference's double application of the
+    RPN loss-weight dict to the supervised losses (rpn.py:141, :254) and none to the unsupervised ones -- against the losses
+    of the REAL reference model (tests/golden/rpn_loss_weight.npz)."""
+    from probabilisticteacher_amd import modeling
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    z = load("rpn_loss_weight")
+    K, tau = int(z["K"]), tuple(float(v) for v in z["tau"])
+    cfg = _cfg(K, "DefaultAnchorGenerator", tau)
+    cfg.defrost()
+    cfg.MODEL.RPN.LOSS_WEIGHT = float(z["loss_weight"])
+    cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT = float(z["bbox_reg_loss_weight"])
+    cfg.freeze()
+    model = modeling.build_model(cfg)
+    model.train()
+    _load_params(model, opt.golden_params(opt.Cfg(num_classes=K, tau=tau), int(z["seed"])))
+    try:
+        sampling.set_key_source(perm_key_source(opt.SeededPerm(91)))
+        losses, _, _, _ = model(_gpu_records(z, "sup", 2), branch="supervised")
+        for k, v in losses.items():
+            close(v.detach().cpu(), z["sup_" + k], 1e-4, 1e-6, "sup " + k)
+        strong = _gpu_records(z, "strong", 2)
+        for i, r in enumerate(strong):
+            inst = FreeInstances(tuple(r["image"].shape[-2:]))
+            inst.pseudo_boxes = Boxes(torch.from_numpy(z[f"pseudo{i}_pseudo_boxes"]))
+            inst.scores_logists = torch.from_numpy(z[f"pseudo{i}_scores_logists"])
+            inst.boxes_sigma = torch.from_numpy(z[f"pseudo{i}_boxes_sigma"])
+            r["instances"] = inst
+        sampling.set_key_source(perm_key_source(opt.SeededPerm(93)))
+        lu, _, _, _ = model(strong, branch="unsupervised", danchor=True)
+        for k, v in lu.items():
+            close(v.detach().cpu(), z["unsup_" + k], 1e-4, 1e-6, "unsup " + k)
+    finally:
+        sampling.set_key_source(None)
+

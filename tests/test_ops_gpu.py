@@ -189,6 +189,29 @@ def test_gemm_split_k(ops, ta, tb, m, n, k):
     close(out, plain, 1e-5, 2e-4 * math.sqrt(k / 1000.0), "split vs unsplit (summation order differs)")
 
 
+@pytest.mark.parametrize("m,n,k,batch", [(130, 200, 96, 1), (257, 72, 512, 3), (9, 130, 4099, 1), (200, 300, 5000, 1)])
+def test_gemm_never_writes_outside_its_output(ops, m, n, k, batch):
+    """Memory-safety canary for the buffer-store epilogue: the kernel advances rows through the store's scalar offset and
+    relies on the buffer descriptor's range check to drop rows >= M of the last (ragged) tile.  The output sits inside a
+    larger buffer filled with a sentinel: guard bands before it, after it and BETWEEN the batch items (stride_c > m * n) must
+    come back untouched -- single, batched and split-K launches, M % 128 != 0."""
+    gen = g(m + n + k)
+    a = torch.randn(batch, m, k, generator=gen)
+    b = torch.randn(batch, k, n, generator=gen)
+    ref = torch.bmm(a.double(), b.double()).float()
+    pad = 4096
+    stride_c = m * n + pad
+    buf = torch.full((pad + batch * stride_c + pad,), -12345.0, device=DEV)
+    out = buf[pad:pad + batch * stride_c].view(batch, stride_c)[:, : m * n]
+    ops.gemm(a.to(DEV).contiguous(), b.to(DEV).contiguous(), m, n, k, k, n, 0, 0, out=buf[pad:], batch=batch, stride_a=m * k,
+             stride_b=k * n, stride_c=stride_c)
+    close(out.reshape(batch, m, n), ref, 1e-4, 2e-4 * math.sqrt(max(k, 1000) / 1000.0), "gemm into a guarded buffer")
+    guard = torch.ones_like(buf, dtype=torch.bool)
+    for i in range(batch):
+        guard[pad + i * stride_c: pad + i * stride_c + m * n] = False
+    assert bool((buf[guard] == -12345.0).all()), f"{int((buf[guard] != -12345.0).sum())} guard elements were overwritten"
+
+
 def test_conv1x1(ops):
     gen = g(17)
     x = torch.randn(3, 96, 13, 21, generator=gen)

@@ -182,3 +182,32 @@ def test_run_step_matches_reference():
             close(state["student"][k].flatten()[:16], z[f"it{it}_s_head_{k}"], 1e-5, 1e-7, f"student head {k}")
             close(state["teacher"][k].double().sum(), z[f"it{it}_t_sum_{k}"], 1e-5, 1e-4, f"teacher sum {k}")
             close(state["teacher"][k].flatten()[:16], z[f"it{it}_t_head_{k}"], 1e-5, 1e-7, f"teacher head {k}")
+
+
+def test_rpn_loss_weight_is_applied_twice_to_supervised_losses_only():
+    """MODEL.RPN.LOSS_WEIGHT = 2, BBOX_REG_LOSS_WEIGHT = 0.5 on the REAL reference model (tests/golden/rpn_loss_weight.npz):
+    the supervised RPN losses carry the weight dict squared (rpn.py:254 and rpn.py:141), the unsupervised ones no weight
+    (rpn.py:347-360); the ROI losses are untouched."""
+    z = load("rpn_loss_weight")
+    cfg = opt.Cfg(num_classes=int(z["K"]), tau=tuple(float(v) for v in z["tau"]), rpn_loss_weight=float(z["loss_weight"]),
+                  rpn_bbox_reg_loss_weight=float(z["bbox_reg_loss_weight"]))
+    params = opt.golden_params(cfg, int(z["seed"]))
+    losses, _, _, _ = opt.model_forward(cfg, params, records(z, "sup", 2), "supervised", perm_fn=opt.SeededPerm(91))
+    for k, v in losses.items():
+        close(v.detach(), z["sup_" + k], RT, AT, "sup " + k)
+    # the same model with unit weights: cls x 2^2, loc x (0.5 * 2)^2
+    unit = opt.Cfg(num_classes=int(z["K"]), tau=tuple(float(v) for v in z["tau"]))
+    l1, _, _, _ = opt.model_forward(unit, params, records(z, "sup", 2), "supervised", perm_fn=opt.SeededPerm(91))
+    close(losses["loss_rpn_cls"].detach(), 4.0 * l1["loss_rpn_cls"].detach(), 1e-6, 0, "cls weight squared")
+    close(losses["loss_rpn_loc"].detach(), 1.0 * l1["loss_rpn_loc"].detach(), 1e-6, 0, "loc weight squared")
+    strong = records(z, "strong", 2)
+    for i, r in enumerate(strong):
+        inst = opt.FreeInstances(tuple(r["image"].shape[-2:]))
+        inst.pseudo_boxes = d2.Boxes(torch.from_numpy(z[f"pseudo{i}_pseudo_boxes"]))
+        inst.scores_logists = torch.from_numpy(z[f"pseudo{i}_scores_logists"])
+        inst.boxes_sigma = torch.from_numpy(z[f"pseudo{i}_boxes_sigma"])
+        r["instances"] = inst
+    lu, _, _, _ = opt.model_forward(cfg, params, strong, "unsupervised", danchor=True, perm_fn=opt.SeededPerm(93))
+    for k, v in lu.items():
+        close(v.detach(), z["unsup_" + k], RT, AT, "unsup " + k)
+

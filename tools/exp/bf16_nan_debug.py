@@ -44,7 +44,7 @@ for it in range(300):
     snap = (tr.student.flat.clone(), tr.teacher.flat.clone(), tr.momentum_buf.clone(), tr.iter, tr._first_step)
 
     def step(mode):
-        ops.set_operand_rounding(mode)
+        tr.operand_rounding = mode
         ratios[:] = list(rs)
         sampling.set_key_source(keyed_perm_source(opt.KeyedPerm(1000 + it, strict=False)))
         try:

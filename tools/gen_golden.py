@@ -255,7 +255,7 @@ def write_fake_vgg(params, path):
     torch.save(sd, path)
 
 
-def build_reference_model(K, anchor, tau, seed=0, burn=1):
+def build_reference_model(K, anchor, tau, seed=0, burn=1, cfg_edit=None):
     """Construct the real reference meta-arch and load the seeded parameter set."""
     import pt.modeling.meta_arch.rcnn  # noqa: F401 (registers)
     import pt.modeling.backbone.vgg  # noqa: F401
@@ -268,6 +268,8 @@ def build_reference_model(K, anchor, tau, seed=0, burn=1):
     vp = os.path.join(tmp, "vgg16_caffe.pth")
     write_fake_vgg(params, vp)
     cfg = build_cfg(K, anchor, tau, vp, burn)
+    if cfg_edit is not None:
+        cfg_edit(cfg)
     model = dm.build_model(cfg)
     missing = model.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
     model.train()
@@ -351,6 +353,46 @@ def gen_model_branches(anchor, tag):
             out["unsupgrad_norm_" + k] = gk.double().norm()
             out["unsupgrad_head_" + k] = gk.flatten()[:32].clone()
     save("model_" + tag, **out)
+
+
+def gen_rpn_loss_weight():
+    """MODEL.RPN.LOSS_WEIGHT != 1: the reference applies the RPN loss-weight dict TWICE to the supervised RPN losses
+    (rpn.py:254 inside `losses`, again at rpn.py:141 in `forward`) and not at all to the unsupervised ones (rpn.py:347-360).
+    Supervised + unsupervised branch losses of the real model with LOSS_WEIGHT = 2, BBOX_REG_LOSS_WEIGHT = 0.5."""
+    K, tau, seed = 8, (0.25, 0.25), 5
+    lw, bw = 2.0, 0.5
+
+    def edit(cfg):
+        cfg.MODEL.RPN.LOSS_WEIGHT = lw
+        cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT = bw
+    cfg, ocfg, params, model = build_reference_model(K, "DefaultAnchorGenerator", tau, seed, cfg_edit=edit)
+    g = torch.Generator().manual_seed(300)
+    H, W = 128, 176
+    recs = make_records(g, 2, H, W, K, m=3)
+    out = dict(seed=seed, K=K, tau=np.asarray(tau), loss_weight=lw, bbox_reg_loss_weight=bw)
+    out.update(records_to_arrays("sup", recs))
+    dm.PERM_FN = opt.SeededPerm(91)
+    losses, _, _, _ = model(recs, branch="supervised")
+    for k, v in losses.items():
+        out["sup_" + k] = v.detach()
+    weak = make_records(g, 2, H, W, K, labelled=False)
+    out.update(records_to_arrays("weak", weak))
+    dm.PERM_FN = opt.SeededPerm(92)
+    with torch.no_grad():
+        _, _, prop_roih, _ = model(weak, branch="unsup_data_weak")
+    from pt.engine.trainer import PTrainer
+    tr = PTrainer.__new__(PTrainer)
+    pseudo, _ = tr.process_pseudo_label(prop_roih, "roih", "all")
+    out.update(inst_arrays("pseudo", pseudo, ["pseudo_boxes", "scores_logists", "boxes_sigma"]))
+    strong = make_records(g, 2, H, W, K, labelled=False)
+    out.update(records_to_arrays("strong", strong))
+    for r, pz in zip(strong, pseudo):
+        r["instances"] = pz
+    dm.PERM_FN = opt.SeededPerm(93)
+    losses_u, _, _, _ = model(strong, branch="unsupervised", danchor=True)
+    for k, v in losses_u.items():
+        out["unsup_" + k] = v.detach()
+    save("rpn_loss_weight", **out)
 
 
 def gen_trainer_pieces():
@@ -614,7 +656,7 @@ def main():
     install_stubs()
     torch.Tensor.cuda = lambda self, *a, **k: self   # anchor_generator.py:69 hard-codes .cuda()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["codec", "pieces", "model", "step", "solver", "augment"]
+    which = sys.argv[1:] or ["codec", "pieces", "model", "step", "solver", "augment", "rpnweight"]
     if "codec" in which:
         gen_box_codec()
     if "pieces" in which:
@@ -628,6 +670,8 @@ def main():
         gen_solver_checkpoint()
     if "augment" in which:
         gen_augment()
+    if "rpnweight" in which:
+        gen_rpn_loss_weight()
 
 
 if __name__ == "__main__":

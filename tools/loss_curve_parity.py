@@ -94,8 +94,7 @@ def main():
     ratios = []
     tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
     if a.bf16 and a.emulate:
-        from probabilisticteacher_amd import ops
-        ops.set_operand_rounding("bf16_emulate")
+        tr.operand_rounding = "bf16_emulate"
     sd = tr.model.state_dict()
     tsd = tr.model_teacher.state_dict()
     with torch.no_grad():

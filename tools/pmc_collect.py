@@ -33,7 +33,7 @@ def short(name):
 
 def main():
     tag = sys.argv[1]
-    bench_flags = sys.argv[2:] or ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    bench_flags = (sys.argv[2:] or ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"]) + ["--pmc-traffic", "off"]
     os.environ["TMPDIR"] = "/tmp"
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(int)

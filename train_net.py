@@ -6,9 +6,12 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_net.py --config ... --synthetic
 
 Same flags as detectron2's default_argument_parser that the reference relies on (--config-file with argparse prefix
-matching, --num-gpus, opts); process launch is torchrun-style (one process per GPU, RCCL).  The reference's data
-pipeline (pt/data) is out of scope for this build: `--synthetic` feeds seeded synthetic
-two-crop batches in the reference's record format; a real loader can be passed to PTrainer(data_loader=...)."""
+matching, --num-gpus, opts); process launch is torchrun-style (one process per GPU, RCCL).
+
+Data: by default the datasets named by cfg.DATASETS.TRAIN_LABEL / TRAIN_UNLABEL / TEST (VOC-format directories registered
+under $DETECTRON2_DATASETS as in pt/data/datasets/builtin.py, or ad hoc with --register NAME=DIR:SPLIT:CLASSES) go through
+the host decoder + device two-crop mapper + aspect-ratio grouping (probabilisticteacher_amd/data, reference
+pt/data/build.py:107-217); `--synthetic` feeds seeded synthetic two-crop batches in the same record format instead."""
 import argparse
 import os
 import sys
@@ -40,6 +43,8 @@ def main():
     ap.add_argument("--resume", action="store_true",
                     help="continue from MODEL.WEIGHTS (or OUTPUT_DIR/last_checkpoint): weights, optimiser state, iteration")
     ap.add_argument("--eval-only", action="store_true")
+    ap.add_argument("--register", action="append", default=[], metavar="NAME=DIR:SPLIT:CLS1,CLS2",
+                    help="register a VOC-format directory as dataset NAME (Annotations/, JPEGImages/, ImageSets/Main/SPLIT.txt)")
     ap.add_argument("opts", nargs=argparse.REMAINDER)
     args = ap.parse_args()
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
@@ -51,17 +56,29 @@ def main():
     cfg = setup_cfg(args.config_file, ["MODEL.DEVICE", f"cuda:{local}"] + args.opts)
     if cfg.UNSUPNET.Trainer != "pt":
         raise ValueError("Trainer Name is not found.")
-    if not args.synthetic:
-        raise SystemExit("only --synthetic input is available in this build (the data pipeline is out of scope)")
+    from probabilisticteacher_amd.data import datasets
+    for spec in args.register:
+        name, rest = spec.split("=", 1)
+        dirname, split, classes = rest.split(":")
+        datasets.register_pascal_voc(name, dirname, split, tuple(classes.split(",")))
     torch.manual_seed(0)
-    trainer = PTrainer(cfg, data_loader=synthetic_loader(cfg, torch.device("cuda", local), rank, world))
+    if args.synthetic:
+        loader = synthetic_loader(cfg, torch.device("cuda", local), rank, world)
+    else:
+        loader = PTrainer.build_train_loader(cfg)              # trainer.py:139-141 -> pt/data/build.py:107
+    trainer = PTrainer(cfg, data_loader=loader)
     inc = trainer.resume_or_load(resume=args.resume)          # trainer.py:466-496 (no-op without MODEL.WEIGHTS / checkpoint)
     if inc is not None and rank == 0:
         print(f"loaded {cfg.MODEL.WEIGHTS or 'last_checkpoint'}: start_iter {trainer.start_iter}, "
               f"missing {len(inc.missing_keys)}, unexpected {len(inc.unexpected_keys)}, wrong shape {len(inc.incorrect_shapes)}",
               flush=True)
+    if args.eval_only and not args.synthetic:
+        # reference train_net.py:60-75: evaluate the STUDENT of the loaded ensemble on cfg.DATASETS.TEST
+        res = PTrainer.test(cfg, trainer.model)
+        if rank == 0:
+            print(res, flush=True)
+        return
     if args.eval_only:
-        # reference train_net.py:60-75: evaluate the STUDENT of the loaded ensemble; here on synthetic labelled batches
         n_batches = args.max_iter or 4
         loader = (next(trainer._data_iter)[1] for _ in range(n_batches))         # the weak labelled views
         names = [f"class{i}" for i in range(cfg.MODEL.ROI_HEADS.NUM_CLASSES)]
@@ -72,7 +89,8 @@ def main():
         if rank == 0:
             print({k: v for k, v in res.items() if k == "bbox"}, flush=True)
         return
-    trainer.train(max_iter=args.max_iter)                      # periodic checkpoints, metrics.json, model_final.pth
+    # periodic checkpoints, metrics.json, model_final.pth; the student / teacher eval hooks run on cfg.DATASETS.TEST
+    trainer.train(max_iter=args.max_iter, run_eval=not args.synthetic)
     if world > 1:
         dist.destroy_process_group()
 
