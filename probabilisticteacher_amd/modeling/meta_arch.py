@@ -70,7 +70,7 @@ class GuassianGeneralizedRCNN(nn.Module):
         images = self.preprocess_image(list(sup_inputs) + list(unsup_inputs))
         features = self.backbone(images.tensor)
         feats = [features[f] for f in self.proposal_generator.in_features]
-        obj, deltas = self.proposal_generator.rpn_head(feats)
+        obj, deltas = self.proposal_generator.head_outputs(feats)
         out = []
         for sl, inputs, branch, da in ((slice(0, ns), sup_inputs, "supervised", False),
                                        (slice(ns, None), unsup_inputs, "unsupervised", danchor)):

@@ -43,11 +43,25 @@ class GuassianRPNHead(nn.Module):
         self.anchor_deltas = _ConvP(num_anchors * box_dim, in_channels, 1)
 
     def forward(self, features: List[torch.Tensor]):
+        """D2's StandardRPNHead interface: lists of (N, A, H, W) logits and (N, 8A, H, W) deltas"""
         obj, deltas = [], []
         for x in features:
             t = ops.conv3x3(x, self.conv.weight, self.conv.bias, True)
             obj.append(ops.conv1x1(t, self.objectness_logits.weight, self.objectness_logits.bias))
             deltas.append(ops.conv1x1(t, self.anchor_deltas.weight, self.anchor_deltas.bias))
+        return obj, deltas
+
+    def forward_flat(self, features: List[torch.Tensor]):
+        """What GuassianRPN.forward makes of `forward`'s result (rpn.py:97-113) -- logits (N, H W A) and deltas (N, H W A, 8)
+        in anchor order -- computed in that layout directly (ops.rpn_head_1x1: the 1x1 convolutions as transposed GEMMs, no
+        permute copies).  GuassianRPN uses this method when the head has it."""
+        obj, deltas = [], []
+        for x in features:
+            t = ops.conv3x3(x, self.conv.weight, self.conv.bias, True)
+            lg, d8 = ops.rpn_head_1x1(t, self.objectness_logits.weight, self.objectness_logits.bias,
+                                      self.anchor_deltas.weight, self.anchor_deltas.bias)
+            obj.append(lg)
+            deltas.append(d8)
         return obj, deltas
 
 
@@ -111,6 +125,11 @@ class GuassianRPN(nn.Module):
         self.anchor_boundary_thresh = R.BOUNDARY_THRESH
         self.loss_weight = {"loss_rpn_cls": R.LOSS_WEIGHT, "loss_rpn_loc": R.BBOX_REG_LOSS_WEIGHT * R.LOSS_WEIGHT}
 
+    def head_outputs(self, feats):
+        """the head's outputs in the flat anchor-order layout when the head offers it (no permute copies), else D2's"""
+        flat = getattr(self.rpn_head, "forward_flat", None)
+        return flat(feats) if flat is not None else self.rpn_head(feats)
+
     # ------------------------------------------------------------------ forward (rpn.py:80-154)
     def forward(self, images, features, gt_instances: Optional[List[FreeInstances]] = None, compute_loss=True,
                 branch="", danchor=False, head_out=None):
@@ -121,11 +140,14 @@ class GuassianRPN(nn.Module):
         anchors = self.anchor_generator(feats)[0].tensor
         if not danchor:
             anchors = anchors.detach()      # grad_zero (rpn.py:91-94): the anchor table gets an all-zero gradient
-        obj, deltas = head_out if head_out is not None else self.rpn_head(feats)
-        n, a, h, w = obj[0].shape
-        # (N,A,H,W) -> (N,H*W*A);  (N,A*8,H,W) -> (N,H*W*A,8)   (rpn.py:97-113)
-        logits = obj[0].permute(0, 2, 3, 1).reshape(n, -1)
-        d8 = deltas[0].view(n, a, 8, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 8)
+        obj, deltas = head_out if head_out is not None else self.head_outputs(feats)
+        if obj[0].dim() == 2:               # already (N, H*W*A) and (N, H*W*A, 8): GuassianRPNHead.forward_flat
+            logits, d8 = obj[0], deltas[0]
+        else:
+            n, a, h, w = obj[0].shape
+            # (N,A,H,W) -> (N,H*W*A);  (N,A*8,H,W) -> (N,H*W*A,8)   (rpn.py:97-113)
+            logits = obj[0].permute(0, 2, 3, 1).reshape(n, -1)
+            d8 = deltas[0].view(n, a, 8, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 8)
 
         if branch == "unsupervised":
             losses = self._losses_unsup(anchors, logits, d8, gt_instances)

@@ -505,6 +505,63 @@ class _Conv1x1(torch.autograd.Function):
         return dx, dw, db
 
 
+class _RPNHead1x1(torch.autograd.Function):
+    """The two 1x1 convolutions of the RPN head (D2 StandardRPNHead: objectness 512 -> A, anchor deltas 512 -> 8A) WRITING
+    THE LAYOUTS THE RPN CONSUMES: the reference permutes (N, A, H, W) -> (N, HWA) and (N, 8A, H, W) -> (N, HWA, 8)
+    (rpn.py:97-113) with anchor index (y w + x) A + a -- i.e. the transposed GEMM.  Here each image's output is computed as
+    X^T (HW x 512) . W^T (512 x A | 8A) with the bias per column, so the GEMM's row-major C IS that layout: no permute
+    copies in forward, none of their transposes in backward."""
+
+    @staticmethod
+    def forward(ctx, x, w_obj, b_obj, w_del, b_del):
+        x = _chk(_rnd(x).contiguous())
+        n, ci, h, w = x.shape
+        hw = h * w
+        outs, w2s = [], []
+        for wt, b in ((w_obj, b_obj), (w_del, b_del)):
+            co = wt.shape[0]
+            w2 = _chk(_rnd(wt).reshape(co, ci).contiguous())
+            y = torch.empty((n, hw, co), dtype=F32, device=x.device)
+            # A = x[n] stored (K = ci, M = hw): ta = 1;  B = W stored (N = co, K = ci): tb = 1;  C (hw, co)
+            gemm(x, w2, hw, co, ci, hw, ci, 1, 1, bias=_chk(b.contiguous()), bias_mode=2, out=y, batch=n, stride_a=ci * hw,
+                 stride_b=0, stride_c=hw * co, ldc=co)
+            outs.append(y)
+            w2s.append(w2)
+        ctx.save_for_backward(x, *w2s)
+        ctx.shapes = (w_obj.shape, w_del.shape)
+        a = w_obj.shape[0]
+        return outs[0].view(n, hw * a), outs[1].view(n, hw * a, 8)
+
+    @staticmethod
+    def backward(ctx, g_obj, g_del):
+        x, w_o, w_d = ctx.saved_tensors
+        n, ci, h, w = x.shape
+        hw = h * w
+        dx = None
+        grads = []
+        first = True
+        for g, w2, shape in ((g_obj, w_o, ctx.shapes[0]), (g_del, w_d, ctx.shapes[1])):
+            co = w2.shape[0]
+            dy = _chk(_rnd_grad(g.reshape(n, hw, co)).contiguous())
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = torch.empty_like(x)
+                # dX (ci, hw) = W^T (ci, co) . dY^T (co, hw):  A = W stored (K = co, M = ci): ta = 1;  B = dY stored (N = hw, K = co): tb = 1
+                gemm(w2, dy, ci, hw, co, ci, co, 1, 1, out=dx, accumulate=not first, batch=n, stride_a=0, stride_b=hw * co,
+                     stride_c=ci * hw, ldc=hw)
+                first = False
+            # dW (co, ci) = dY^T (co, hw) . X^T (hw, ci) per image, then a fixed-order sum over the images
+            part = gemm(dy, x, co, ci, hw, co, hw, 1, 1, batch=n, stride_a=hw * co, stride_b=ci * hw, stride_c=co * ci)
+            grads.append(colsum(part.view(n, co * ci)).view(shape))
+            grads.append(colsum(dy.view(n * hw, co)))
+        return dx, grads[0], grads[1], grads[2], grads[3]
+
+
+def rpn_head_1x1(x, w_obj, b_obj, w_del, b_del):
+    """-> (objectness logits (N, H W A), anchor deltas (N, H W A, 8)) in the RPN's anchor order"""
+    return _RPNHead1x1.apply(x, w_obj, b_obj, w_del, b_del)
+
+
 def conv1x1(x, weight, bias):
     return _Conv1x1.apply(x, weight, bias)
 

@@ -212,6 +212,32 @@ def test_gemm_never_writes_outside_its_output(ops, m, n, k, batch):
     assert bool((buf[guard] == -12345.0).all()), f"{int((buf[guard] != -12345.0).sum())} guard elements were overwritten"
 
 
+def test_rpn_head_flat_layout_equals_conv1x1_plus_permutes(ops):
+    """ops.rpn_head_1x1 (the RPN head's two 1x1 convolutions as transposed GEMMs writing (N, HWA) / (N, HWA, 8) directly) against
+    conv1x1 + the reference's permutes (rpn.py:97-113) and against torch CPU: forward and all five gradients."""
+    gen = g(11)
+    n, ci, h, w, a = 2, 64, 13, 21, 9
+    x = torch.randn(n, ci, h, w, generator=gen)
+    wo, bo = torch.randn(a, ci, 1, 1, generator=gen) * 0.1, torch.randn(a, generator=gen) * 0.1
+    wd, bd = torch.randn(8 * a, ci, 1, 1, generator=gen) * 0.1, torch.randn(8 * a, generator=gen) * 0.1
+    ref_in = [t.clone().requires_grad_() for t in (x, wo, bo, wd, bd)]
+    lo = F.conv2d(ref_in[0], ref_in[1], ref_in[2]).permute(0, 2, 3, 1).reshape(n, -1)
+    d8 = F.conv2d(ref_in[0], ref_in[3], ref_in[4]).view(n, a, 8, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 8)
+    g1, g2 = torch.randn(lo.shape, generator=gen), torch.randn(d8.shape, generator=gen)
+    (lo * g1).sum().add((d8 * g2).sum()).backward()
+    dev_in = [t.to(DEV).requires_grad_() for t in (x, wo, bo, wd, bd)]
+    lo_d, d8_d = ops.rpn_head_1x1(*dev_in)
+    assert lo_d.shape == lo.shape and d8_d.shape == d8.shape and lo_d.is_contiguous() and d8_d.is_contiguous()
+    close(lo_d, lo, 1e-4, 1e-5, "flat logits")
+    close(d8_d, d8, 1e-4, 1e-5, "flat deltas")
+    (lo_d * g1.to(DEV)).sum().add((d8_d * g2.to(DEV)).sum()).backward()
+    for nm, a_, b_ in zip(("dx", "dW_obj", "db_obj", "dW_delta", "db_delta"), dev_in, ref_in):
+        close(a_.grad, b_.grad, 1e-4, 1e-4, "rpn head " + nm)
+    with torch.no_grad():
+        via = ops.conv1x1(dev_in[0], dev_in[1], dev_in[2]).permute(0, 2, 3, 1).reshape(n, -1)
+    close(lo_d, via, 1e-5, 1e-6, "flat vs conv1x1 + permute")
+
+
 def test_conv1x1(ops):
     gen = g(17)
     x = torch.randn(3, 96, 13, 21, generator=gen)
