@@ -87,6 +87,15 @@ int ptmi_conv3x3_wino_pack_weights(const float* w, float* wp, int w_cout, int w_
 int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
                           float* y, int n, int cin, int cout, int h, int w, int epilogue,
                           ptmi_stream_t s);
+/* Winograd-domain weight gradient (same contract as ptmi_conv3x3_wgrad; replaces cuDNN's Winograd-nonfused BWD_FILTER
+ * for the trainable 3x3 layers): dU_p[co][ci] = sum over tiles of (A dY A^T)_p V_p on v_mfma_f32_32x32x2_f32 (16 instead
+ * of 36 multiplies per tile and channel pair), split over contiguous tile ranges whose partials (workspace
+ * [split][16][Cout][Cin] fp32, ptmi_conv3x3_wino_wgrad_ws_floats) are summed in a fixed order and mapped back by
+ * dW = G^T dU G; db = sum of dy per channel (position (1,1) of A dY A^T is the tile's sum), accumulated by the same
+ * workgroups and appended to the workspace as [split][Cout].  Deterministic. */
+int64_t ptmi_conv3x3_wino_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
+int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n,
+                            int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
 /* dz = dy * (y > 0), elementwise (ReLU backward; F.relu_ at vgg.py:67). In-place allowed. */
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s);
 

@@ -462,6 +462,361 @@ __global__ void wino_pack_weights_kernel(const float* __restrict__ w, float* __r
     }
 }
 
+
+// ================================================================================================ weight gradient
+// dW through the same transform domain:  Y = A^T [U (.) V] A  =>  dU_p[co][ci] = sum over (image, tile) of W_p[co][tile] V_p[ci][tile]
+// with W = A dY A^T (the 2x2 output-gradient tile spread over the 16 positions) and V = B^T d B as in forward, then
+// dg = G^T dU G.  16 multiplies per tile and channel pair instead of 36 -- the same 2.25x as forward.
+//
+// GEMM per position: M = co, N = ci, K = tiles.  A workgroup owns 64 co x 64 ci (a wave 32 x 32 x 16 positions = 256
+// accumulator registers, one wave per SIMD) and a contiguous range of "chunks" -- (image, tile row, 32-column block) = 16
+// tiles = 8 k-steps of 2 tiles -- of the split it belongs to; partial dU go to the workspace [split][position][co][ci] and a
+// second kernel sums the splits in a fixed order (deterministic) and applies G^T . G.
+//   * MFMA operands: lane (co = lane & 31, kh = lane >> 5) transforms the 2x2 dY tile of ITS channel and tile 2 ks + kh
+//     (two 8-byte LDS reads, 12 additions), lane (ci, kh) the 4x4 input window of its channel and the same tile (twelve reads,
+//     32 additions): again no cross-lane traffic.  W is computed without its minus signs (row / column 3 of A dY A^T are
+//     negated sums); the reduction kernel multiplies position (i, j) by s_i s_j, s = (1, 1, 1, -1).
+//   * lanes of one MFMA operand differ in the CHANNEL, so the LDS plane pitches are odd multiples of 4 floats (68 / 164): the
+//     32 lanes of an 8-byte read fall on 16 distinct bank pairs (2-way; 16-byte DMA pieces allow no better).
+//   * two LDS stages; a chunk's operands are fetched (5 + 11 DMA instructions per lane: 64 channels x 2 x 32 pixels of dY,
+//     64 x 4 x 40 of x) four per k-step during the last two k-steps of chunk c - 2 and the first two of chunk c - 1; LDS reads
+//     run two k-steps ahead of the MFMAs and the transforms one, so the chunk hand-over (vmcnt(0), edge fix-ups, barrier) sits at
+//     k-step 6 of 8 with every own read four k-steps old.
+#ifndef WGX
+#define WGX 0          // timing experiments only (tools/exp): 1 no DMA, 2 no transforms, 4 no LDS reads, 8 no hand-over, 16 no MFMA
+#endif
+constexpr int GWC = 64;                  // channels per operand tile
+constexpr int GDYP = 68;                 // dY plane pitch: 2 rows x 32 columns + one pad piece
+constexpr int GXP = 164;                 // x plane pitch: 4 rows x 40 columns (x0-4 .. x0+35) + one pad piece
+constexpr int GDYR = 5 * 256 * 4;        // dY region of a stage: 1088 pieces padded to 5 DMA instructions per lane
+constexpr int GXR = 11 * 256 * 4;        // x region: 2624 pieces padded to 11
+constexpr int GSTAGE = GDYR + GXR;       // 16384 floats = 64 KB; two stages
+constexpr int GND = 5, GNX = 11;
+
+// packed fp32 additions on register pairs (VOP3P): the transforms cost half the VALU issue slots of scalar adds -- and VALU
+// time adds to fp32 MFMA time on this chip (measured: removing the transforms shortens the kernel by exactly their issue time)
+typedef __attribute__((address_space(3), aligned(4))) f32x2 wlds_f32x2_a4_t;     // 4-byte aligned pair: ds_read2_b32
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// (a.lo + b.hi, a.lo - b.hi)
+__device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+__global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, float* __restrict__ bpartial,
+    int N, int Cin, int Cout, int H, int W, int ciTiles, int S, int tilesY2, int colBlocks)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * GSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = H * W;
+    int bid = blockIdx.x;
+    const int split = bid % S; bid /= S;
+    const int cit = bid % ciTiles, cot = bid / ciTiles;
+    const int co0 = cot * GWC, ci0 = cit * GWC;
+    // this split's contiguous range of the chunk list (image, tile row, column block; column block fastest)
+    const int nChunksAll = N * tilesY2 * colBlocks;
+    const int per = (nChunksAll + S - 1) / S;
+    const int cBegin = split * per;
+    const int nC = max(min(cBegin + per, nChunksAll) - cBegin, 0);
+
+    // ---- per-lane DMA pieces (fetch order: 11 of x, then 5 of dY), relative to the chunk's origin: x (y0 - 1, x0 - 4), dY (y0, x0).
+    // Validity is (channel) & (column, by the class of the column block: first / interior / last) & (row, by the tile row):
+    // bit masks over the lane's 16 pieces, built once; a chunk combines them with a handful of wave-uniform selects.
+    unsigned voff[GNX + GND];
+    unsigned m_ch = 0, m_first = 0, m_last = 0;          // channel inside the tensor; column valid in the first / last column block
+    unsigned m_r0 = 0, m_r2 = 0, m_r3 = 0, m_d1 = 0;     // x pieces of window row 0 / 2 / 3, dY pieces of row 1
+    unsigned long long fix_last = 0;                     // last column block: words past the image edge, bits 4 i + e
+    const int wvl = W - (colBlocks - 1) * WTW;           // width of the last column block (1 .. 32)
+#pragma unroll
+    for (int i = 0; i < GNX; ++i) {
+        const int px = tid + i * WNT;
+        const int ch = px / 41, rem = px - ch * 41;
+        const int r = rem / 10, q4 = 4 * (rem - r * 10) - 4;
+        const bool ok = px < GWC * 41 && rem < 40 && ci0 + ch < Cin;
+        voff[i] = (unsigned)(ch * HW + r * W + q4 + 4) * 4u;
+        m_ch |= (unsigned)ok << i;
+        m_first |= (unsigned)(q4 >= 0) << i;
+        m_last |= (unsigned)(q4 < wvl) << i;
+        m_r0 |= (unsigned)(r == 0) << i;
+        m_r2 |= (unsigned)(r == 2) << i;
+        m_r3 |= (unsigned)(r == 3) << i;
+        if (ok && q4 < wvl && q4 + 4 > wvl)
+            for (int e = 1; e < 4; ++e) fix_last |= (q4 + e >= wvl) ? (1ull << (4 * i + e)) : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < GND; ++i) {
+        const int pd = tid + i * WNT;
+        const int ch = pd / 17, rem = pd - ch * 17;
+        const int r = rem >> 3, q4 = 4 * (rem & 7);
+        const bool ok = pd < GWC * 17 && rem < 16 && co0 + ch < Cout;
+        voff[GNX + i] = (unsigned)(ch * HW + r * W + q4) * 4u;
+        m_ch |= (unsigned)ok << (GNX + i);
+        m_first |= 1u << (GNX + i);
+        m_last |= (unsigned)(q4 < wvl) << (GNX + i);
+        m_d1 |= (unsigned)(r == 1) << (GNX + i);
+        if (ok && q4 < wvl && q4 + 4 > wvl)
+            for (int e = 1; e < 4; ++e) fix_last |= (q4 + e >= wvl) ? (1ull << (4 * (GNX + i) + e)) : 0ull;
+    }
+    const char* x_end = (const char*)(x + (size_t)N * Cin * HW);
+    const char* dy_end = (const char*)(dy + (size_t)N * Cout * HW);
+    auto clamp_rec = [](long long rem) { return (int)(rem > 0xFFFFFFFEll ? 0xFFFFFFFEll : (rem < 0 ? 0 : rem)); };
+
+    // ---- the fetch in progress: descriptors, effective per-piece offsets, fix-up mask
+    int f_cb, f_ty, f_n;                                 // coordinates of the NEXT chunk to set up
+    {
+        const int g = min(cBegin, max(nChunksAll - 1, 0));
+        f_cb = g % colBlocks;
+        const int t = g / colBlocks;
+        f_ty = t % tilesY2;
+        f_n = t / tilesY2;
+    }
+    int f_left = nC;                                     // chunks of this split not yet set up
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(x), 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = rx;
+    unsigned eoff[GNX + GND];
+    unsigned long long fix = 0;
+    auto fetch_setup = [&]() {
+        const bool any = f_left > 0;
+        const int y0 = 2 * f_ty, x0 = f_cb * WTW;
+        const float* xb = x + ((size_t)f_n * Cin + ci0) * HW + ((ptrdiff_t)y0 - 1) * W + (x0 - 4);
+        const float* db = dy + ((size_t)f_n * Cout + co0) * HW + (size_t)y0 * W + x0;
+        rx = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(xb), 0, clamp_rec(x_end - (const char*)xb), 0x00020000);
+        rd = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(db), 0, clamp_rec(dy_end - (const char*)db), 0x00020000);
+        const bool first = f_cb == 0, last = f_cb == colBlocks - 1;
+        const bool top = y0 == 0, bot2 = y0 + 1 >= H, bot3 = y0 + 2 >= H;
+        if (any && !first && !last && !top && !bot3) {   // interior chunk: only the channel mask
+            fix = 0;
+#pragma unroll
+            for (int i = 0; i < GNX + GND; ++i) eoff[i] = (m_ch >> i) & 1 ? voff[i] : 0xFFFFFFFFu;
+        } else {
+            unsigned m = any ? m_ch : 0u;
+            m &= first ? m_first : ~0u;
+            m &= last ? m_last : ~0u;
+            m &= top ? ~m_r0 : ~0u;
+            m &= bot2 ? ~(m_r2 | m_d1) : ~0u;
+            m &= bot3 ? ~m_r3 : ~0u;
+            fix = (any && last) ? fix_last : 0ull;
+            // (a piece whose row or channel is masked needs no fix-up: zeroing zeros is harmless)
+#pragma unroll
+            for (int i = 0; i < GNX + GND; ++i) eoff[i] = (m >> i) & 1 ? voff[i] : 0xFFFFFFFFu;
+        }
+        --f_left;
+        if (++f_cb == colBlocks) {
+            f_cb = 0;
+            if (++f_ty == tilesY2) { f_ty = 0; ++f_n; }
+        }
+    };
+    auto fetch_piece = [&](int idx, int stage) {
+        if (idx < GNX)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (wlds_void_t*)(lds + stage * GSTAGE + GDYR + wave * 256 + idx * WNT * 4), 16,
+                                                     (int)eoff[idx], 0, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (wlds_void_t*)(lds + stage * GSTAGE + wave * 256 + (idx - GNX) * WNT * 4), 16,
+                                                     (int)eoff[idx], 0, 0, 0);
+    };
+    auto fixup = [&](int stage, unsigned long long fm) {
+        if ((unsigned)fm | (unsigned)(fm >> 32)) {
+#pragma unroll
+            for (int i = 0; i < GNX + GND; ++i) {
+                float* pc = lds + stage * GSTAGE + (i < GNX ? GDYR + (tid + i * WNT) * 4 : (tid + (i - GNX) * WNT) * 4);
+#pragma unroll
+                for (int e = 1; e < 4; ++e)
+                    if (fm & (1ull << (4 * i + e))) pc[e] = 0.f;
+            }
+        }
+    };
+
+    // ---- the lane's role in the MFMAs
+    const int wm = wave >> 1, wn = wave & 1;                 // co half / ci half of the 64 x 64 tile
+    const int nl = lane & 31, kh = lane >> 5;
+    const int a_off = (wm * 32 + nl) * GDYP + 2 * kh;                                    // + 4 ks  (tile 2 ks + kh), + 32 r
+    const int b_off = GDYR + (wn * 32 + nl) * GXP + 2 * kh + 3;                          // + 4 ks, + 40 a + 2 t   (odd: ds_read2_b32)
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
+    f32x2 RA[2][2], RB[2][8];              // raw operands of two k-steps in flight: the 2x2 dY tile, the 4x4 window (row a: 2 a, 2 a + 1)
+    // transformed operands of two consecutive k-steps.  Position p = 4 i + j:
+    //   W' = A dY A^T (signs dropped): WR[i] = (w_i0, w_i3), WZ[i] = (w_i1, w_i2);   V = B^T d B: VX[i] = (v_i0, v_i3), VY[i] = (v_i1, v_i2)
+    f32x2 WR[2][4], WZ[2][4], VX[2][4], VY[2][4];
+    f32x2 T[4][2];                         // B^T d, rows i, column pairs (0, 1), (2, 3)
+    float bsum = 0.f;                      // sum of this lane's dY tiles: position (1, 1) of W' is d00 + d01 + d10 + d11
+
+    auto raw_read = [&](const float* stage, int ks, f32x2 (&ra)[2], f32x2 (&rb)[8], int P) {      // one read per MFMA slot P = 0..9
+        if (P < 2) ra[P] = *(const volatile wlds_f32x2_t*)(stage + a_off + 4 * ks + 32 * P);
+        else if (P < 10) rb[P - 2] = *(const volatile wlds_f32x2_a4_t*)(stage + b_off + 4 * ks + ((P - 2) >> 1) * 40 + 2 * ((P - 2) & 1));
+    };
+    auto xform_a_rows = [&](const f32x2 (&ra)[2], f32x2 (&wr)[4]) {
+        wr[0] = ra[0];
+        wr[1] = pk_add(ra[0], ra[1]);
+        wr[2] = pk_sub(ra[0], ra[1]);
+        wr[3] = ra[1];
+    };
+    auto xform_a_col = [&](const f32x2 (&wr)[4], f32x2 (&wz)[4], int i) { wz[i] = pk_lo_pm_hi(wr[i], wr[i]); };
+    auto xform_b_rows = [&](const f32x2 (&rb)[8], int c) {      // column pair c of all four rows
+        T[0][c] = pk_sub(rb[0 + c], rb[4 + c]);
+        T[1][c] = pk_add(rb[2 + c], rb[4 + c]);
+        T[2][c] = pk_sub(rb[4 + c], rb[2 + c]);
+        T[3][c] = pk_sub(rb[2 + c], rb[6 + c]);
+    };
+    auto xform_b_col = [&](f32x2 (&vx)[4], f32x2 (&vy)[4], int i) {
+        vx[i] = pk_sub(T[i][0], T[i][1]);                 // (t0 - t2, t1 - t3)
+        vy[i] = pk_lo_pm_hi(T[i][1], T[i][0]);            // (t2 + t1, t2 - t1)
+    };
+    auto opa = [&](int M, int p) -> float { const int i = p >> 2, j = p & 3; return (j == 0 || j == 3) ? WR[M][i][j == 3] : WZ[M][i][j == 2]; };
+    auto opb = [&](int M, int p) -> float { const int i = p >> 2, j = p & 3; return (j == 0 || j == 3) ? VX[M][i][j == 3] : VY[M][i][j == 2]; };
+
+    if (nC > 0) {
+        // ---- start: chunk 0 entirely, chunk 1's first two quarters
+        fetch_setup();
+#pragma unroll
+        for (int idx = 0; idx < GNX + GND; ++idx) fetch_piece(idx, 0);
+        const unsigned long long fix0 = fix;
+        fetch_setup();
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) fetch_piece(idx, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        fixup(0, fix0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        unsigned long long fix_h = fix;          // fix-ups of the next chunk to be handed over (chunk 1)
+        {   // operands of k-step 0 (transformed) and raw operands of k-step 1
+#pragma unroll
+            for (int P = 0; P < 10; ++P) raw_read(lds, 0, RA[0], RB[0], P);
+            xform_a_rows(RA[0], WR[0]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xform_a_col(WR[0], WZ[0], i);
+            xform_b_rows(RB[0], 0);
+            xform_b_rows(RB[0], 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xform_b_col(VX[0], VY[0], i);
+#pragma unroll
+            for (int P = 0; P < 10; ++P) raw_read(lds, 1, RA[1], RB[1], P);
+        }
+        // k-step KS of the chunk in stage `cur`: MFMAs on the operands [KS & 1]; raw reads of k-step KS + 2 into R[KS & 1]; transforms
+        // of k-step KS + 1 (raw R[(KS + 1) & 1], read one k-step ago) into the operands [(KS + 1) & 1]
+        auto kstep = [&](auto ks_c, int cur) {
+            constexpr int KS = decltype(ks_c)::value;
+            constexpr int M = KS & 1, O = M ^ 1;
+            const float* src = lds + ((KS < 6) ? cur : cur ^ 1) * GSTAGE;
+            constexpr int KR = (KS + 2) & 7;
+            auto step = [&](auto p_c) {
+                constexpr int P = decltype(p_c)::value;
+                if (!(WGX & 16)) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(M, P), opb(M, P), acc[P], 0, 0, 0);
+                if constexpr (P == 15) bsum += WZ[M][1][0];
+                if constexpr (P == 0 && KS == 6) {
+                    // hand-over: the next chunk's pieces (all issued by k-step 1) have landed; edge fix-ups; barrier; then the
+                    // stage this chunk occupied is free (its last raw reads were k-step 5's) and the fetch of chunk + 2 starts
+                    if (!(WGX & 8)) {
+                        wino_vmwait0();
+                        fixup(cur ^ 1, fix_h);
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+                    fetch_setup();
+                    fix_h = fix;
+                }
+                if constexpr (P < 10) { if (!(WGX & 4)) raw_read(src, KR, RA[M], RB[M], P); }
+                // fetch of chunk + 2 (k-steps 6, 7) / of chunk + 1 (k-steps 0, 1): four DMA instructions per k-step
+                if constexpr ((KS == 6 || KS == 7 || KS == 0 || KS == 1) && (P == 1 || P == 8 || P == 9 || P == 14)) {
+                    constexpr int part = KS == 6 ? 0 : (KS == 7 ? 1 : (KS == 0 ? 2 : 3));
+                    constexpr int sub = P == 1 ? 0 : (P == 8 ? 1 : (P == 9 ? 2 : 3));
+                    if (!(WGX & 1)) fetch_piece(part * 4 + sub, (KS >= 6) ? cur : cur ^ 1);
+                }
+                // transforms of k-step KS + 1
+                if (!(WGX & 2)) {
+                    if constexpr (P == 2) xform_a_rows(RA[O], WR[O]);
+                    if constexpr (P == 3) { xform_a_col(WR[O], WZ[O], 0); xform_a_col(WR[O], WZ[O], 1); xform_a_col(WR[O], WZ[O], 2); xform_a_col(WR[O], WZ[O], 3); }
+                    if constexpr (P == 4 || P == 5) xform_b_rows(RB[O], 0 + (P - 4));
+                    if constexpr (P >= 10 && P <= 13) xform_b_col(VX[O], VY[O], P - 10);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});
+            step(std::integral_constant<int, 2>{});  step(std::integral_constant<int, 3>{});
+            step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
+            step(std::integral_constant<int, 6>{});  step(std::integral_constant<int, 7>{});
+            step(std::integral_constant<int, 8>{});  step(std::integral_constant<int, 9>{});
+            step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+            step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+            step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+        };
+        for (int chunk = 0; chunk < nC; ++chunk) {
+            const int cur = chunk & 1;
+            kstep(std::integral_constant<int, 0>{}, cur);
+            kstep(std::integral_constant<int, 1>{}, cur);
+            kstep(std::integral_constant<int, 2>{}, cur);
+            kstep(std::integral_constant<int, 3>{}, cur);
+            kstep(std::integral_constant<int, 4>{}, cur);
+            kstep(std::integral_constant<int, 5>{}, cur);
+            kstep(std::integral_constant<int, 6>{}, cur);
+            kstep(std::integral_constant<int, 7>{}, cur);
+        }
+        wino_vmwait0();           // the last (empty) fetches must have landed before the workgroup gives up its LDS
+    }
+    // ---- partial db: [split][co], from the workgroups of ci tile 0 (every ci tile sees the same dY)
+    bsum += __shfl_xor(bsum, 32);
+    if (cit == 0 && wn == 0 && kh == 0 && co0 + wm * 32 + nl < Cout) bpartial[(size_t)split * Cout + co0 + wm * 32 + nl] = bsum;
+    // ---- partial dU' (signs applied by the reduction): [split][position][co][ci]
+    const int ci = ci0 + wn * 32 + nl;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        float* dst = partial + ((size_t)split * 16 + p) * Cout * Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (co < Cout && ci < Cin) dst[(size_t)co * Cin + ci] = acc[p][r];
+        }
+    }
+}
+
+// dW[co][ci][3][3] (+)= G^T ( sum_splits dU'[split] (.) S ) G,  S_ij = s_i s_j, s = (1, 1, 1, -1)
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial,
+                                         float* __restrict__ dw, float* __restrict__ db, int Cout, int Cin, int S, int accumulate)
+{
+    const int64_t cc = (int64_t)Cout * Cin;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < cc; i += (int64_t)gridDim.x * blockDim.x) {
+        if (db && i < Cout) {
+            float sum = 0.f;
+            for (int s = 0; s < S; ++s) sum += bpartial[(size_t)s * Cout + i];
+            db[i] = accumulate ? db[i] + sum : sum;
+        }
+        float u[4][4];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            float sum = 0.f;
+            for (int s = 0; s < S; ++s) sum += partial[((size_t)s * 16 + p) * cc + i];
+            const bool neg = ((p >> 2) == 3) != ((p & 3) == 3);
+            u[p >> 2][p & 3] = neg ? -sum : sum;
+        }
+        float t[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+            t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+            t[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float g0 = t[k][0] + 0.5f * (t[k][1] + t[k][2]);
+            const float g1 = 0.5f * (t[k][1] - t[k][2]);
+            const float g2 = 0.5f * (t[k][1] + t[k][2]) + t[k][3];
+            float* o = dw + i * 9 + k * 3;
+            o[0] = accumulate ? o[0] + g0 : g0;
+            o[1] = accumulate ? o[1] + g1 : g1;
+            o[2] = accumulate ? o[2] + g2 : g2;
+        }
+    }
+}
+
+// splits per (co tile, ci tile): fill the chip's 256 one-workgroup-per-CU slots a whole number of times
+static int wino_wgrad_splits(int n, int cin, int cout, int h, int w)
+{
+    const int pairs = cdiv(cout, GWC) * cdiv(cin, GWC);
+    const int64_t chunks = (int64_t)n * cdiv(h, 2) * cdiv(w, WTW);
+    int S = cdiv(256, pairs);
+    if (S > chunks) S = (int)chunks;
+    return S < 1 ? 1 : S;
+}
+
 }  // namespace
 
 extern "C" {
@@ -501,6 +856,30 @@ int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, co
     hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n, cin, cout, h, w,
                        nChunks, epilogue);
     PTMI_LAUNCH_CHECK("conv3x3_wino_fwd");
+    return 0;
+}
+
+
+int64_t ptmi_conv3x3_wino_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
+{
+    return (int64_t)wino_wgrad_splits(n, cin, cout, h, w) * (16 * (int64_t)cout * cin + cout);
+}
+
+int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h,
+                            int w, int accumulate, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino_wgrad: bad args");
+    PTMI_CHECK_ARG((int64_t)(GWC + 1) * h * w * 4 < (1ll << 31), "conv3x3_wino_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
+    const int S = wino_wgrad_splits(n, cin, cout, h, w);
+    const int coTiles = cdiv(cout, GWC), ciTiles = cdiv(cin, GWC);
+    hipStream_t st = (hipStream_t)s;
+    float* bws = ws + (size_t)S * 16 * cout * cin;
+    hipLaunchKernelGGL(conv3x3_wino_wgrad_kernel, dim3((unsigned)(coTiles * ciTiles * S)), dim3(WNT), 0, st, x, dy, ws, bws, n, cin, cout, h, w,
+                       ciTiles, S, cdiv(h, 2), cdiv(w, WTW));
+    PTMI_LAUNCH_CHECK("conv3x3_wino_wgrad");
+    const int64_t cc = (int64_t)cout * cin;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, st, ws, bws, dw, db, cout, cin, S, accumulate);
+    PTMI_LAUNCH_CHECK("conv3x3_wino_wgrad_reduce");
     return 0;
 }
 

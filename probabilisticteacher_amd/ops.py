@@ -158,6 +158,25 @@ def _conv_fwd_sym() -> str:
     return "ptmi_conv3x3_fwd_bf16" if _native_bf16() else "ptmi_conv3x3_fwd"
 
 
+def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
+    """(dW, db) of a 3x3 s1 p1 convolution from its input and output gradient (N1 wgrad): the Winograd-domain kernel on
+    the fp32 64+-channel layers, the direct split-K kernel otherwise (and under bf16 operand rounding)."""
+    n, cin, h, w = x.shape
+    dw = torch.empty(cout, cin, 3, 3, dtype=F32, device=x.device)
+    db = torch.empty(cout, dtype=F32, device=x.device)
+    lib = _lib.load()
+    if _use_wino(cin) and cin >= _WINO_WGRAD_MIN_C and cout >= _WINO_WGRAD_MIN_C:
+        ws = _ws("wgrad", lib.ptmi_conv3x3_wino_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+        with _prof("conv3x3_wino_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino_wgrad_issued_flops(n, cin, cout, h, w)):
+            _lib.call("ptmi_conv3x3_wino_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
+                      _stream())
+    else:
+        ws = _ws("wgrad", lib.ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+        with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
+            _lib.call(_conv_wgrad_sym(), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0, _stream())
+    return dw, db
+
+
 def _conv_wgrad_sym() -> str:
     return "ptmi_conv3x3_wgrad_bf16" if _native_bf16() else "ptmi_conv3x3_wgrad"
 
@@ -169,6 +188,7 @@ def _conv_wgrad_sym() -> str:
 # kernels (their parity statement -- products of rounded operands are exact in fp32 -- does not survive a transform).
 _CONV_ALGO = "auto"
 _WINO_MIN_CIN = 32
+_WINO_WGRAD_MIN_C = 64         # the wgrad workgroup owns 64 co x 64 ci
 
 
 def set_conv_algo(mode: str) -> None:
@@ -185,6 +205,14 @@ def wino_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
     co_tiles, tiles_x, chunks = -(-cout // 64), -(-w // 32), -(-cin // 8)
     waves = n * co_tiles * tiles_x * (-(-h // 4)) * 2
     return float(waves) * chunks * 4 * 16 * 4096
+
+
+def wino_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
+    """FLOPs of the MFMAs one ptmi_conv3x3_wino_wgrad launch issues: per 64 co x 64 ci pair and chunk (one tile row x 32
+    columns = 16 tiles) 8 k-steps x 16 positions x 4 waves x 4096 FLOP"""
+    pairs = -(-cout // 64) * -(-cin // 64)
+    chunks = n * -(-h // 2) * -(-w // 32)
+    return float(pairs) * chunks * 8 * 16 * 4 * 4096
 
 
 def _use_wino(conv_cin: int) -> bool:
@@ -287,13 +315,7 @@ class _Conv3x3(torch.autograd.Function):
         cout = weight.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.empty_like(weight)
-            db = torch.empty(cout, dtype=F32, device=x.device)
-            nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w)
-            ws = _ws("wgrad", nws * 4, x.device)
-            with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
-                _lib.call(_conv_wgrad_sym(), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
-                          _stream())
+            dw, db = conv3x3_wgrad(x, dz, cout)
         if ctx.needs_input_grad[0]:
             wpd = conv3x3_pack(weight, 1, 2)
             dx = conv3x3_raw(dz, wpd, None, None, cin, 2)
@@ -376,13 +398,7 @@ class _VGGBlock(torch.autograd.Function):
             n, cin, h, wd = xin.shape
             cout = w.shape[0]
             if ctx.needs_input_grad[2 + 2 * (j - 1)] or ctx.needs_input_grad[3 + 2 * (j - 1)]:
-                dw = torch.empty_like(w)
-                db = torch.empty(cout, dtype=F32, device=xin.device)
-                nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, wd)
-                wsb = _ws("wgrad", nws * 4, xin.device)
-                with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * wd * n):
-                    _lib.call(_conv_wgrad_sym(), _ptr(xin), _ptr(dz), _ptr(dw), _ptr(db), _ptr(wsb), n, cin, cout, h,
-                              wd, 0, _stream())
+                dw, db = conv3x3_wgrad(xin, dz, cout)
                 grads[2 * (j - 1)], grads[2 * (j - 1) + 1] = dw, db
             if j > 1:
                 dz = conv3x3_raw(dz, conv3x3_pack(w, 1, 3), None, xin, cin, 3)      # dgrad + ReLU mask of layer j-1

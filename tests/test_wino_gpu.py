@@ -130,3 +130,63 @@ def test_wino_baseline_layer_shapes():
             ref = F.relu(F.conv2d(x[:, :, y0:y1, x0:x1], wt, b, padding=1))
             ref = ref[:, :, ys.start - y0: ys.start - y0 + (ys.stop - ys.start), xs.start - x0: xs.start - x0 + (xs.stop - xs.start)]
             close(got[:, :, ys, xs], ref, 1e-4, 1e-4, f"layer {cin}->{cout} {h}x{w} crop {ys} {xs}")
+
+
+def _wino_wgrad(x, gy, cout, accumulate_into=None):
+    from probabilisticteacher_amd import _lib, ops
+    call, ptr, stream = _lib.call, ops._ptr, ops._stream
+    n, cin, h, w = x.shape
+    ws = torch.full((_lib.load().ptmi_conv3x3_wino_wgrad_ws_floats(n, cin, cout, h, w),), float("nan"), device=DEV)
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV) if accumulate_into is None else accumulate_into[0]
+    db = torch.full((cout,), float("nan"), device=DEV) if accumulate_into is None else accumulate_into[1]
+    call("ptmi_conv3x3_wino_wgrad", ptr(x), ptr(gy), ptr(dw), ptr(db), ptr(ws), n, cin, cout, h, w,
+         0 if accumulate_into is None else 1, stream())
+    return dw, db
+
+
+WGRAD_SHAPES = SHAPES + [
+    (2, 64, 64, 6, 64),       # exact chunks: two column blocks, three tile rows
+    (3, 128, 64, 7, 100),     # several chunks per split, odd H, ragged last column block
+    (1, 64, 192, 2, 36),      # the last column block holds only the 4 rightmost columns
+    (2, 70, 100, 9, 37),      # ragged channel tiles both sides
+    (4, 64, 64, 40, 45),      # many chunks per split: the steady-state pipeline over both LDS stages
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", WGRAD_SHAPES)
+def test_wino_wgrad(n, cin, cout, h, w):
+    """dW, db of the Winograd-domain weight gradient against torch CPU fp32 autograd.  Tolerance: 1e-4 of the gradient's
+    scale + 1e-4 relative (K = N H W products per weight; the transform-domain sums differ from direct summation by fp32
+    rounding only)."""
+    gen = g(11 + n * 1000 + cin + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.05).requires_grad_()
+    b = torch.zeros(cout, requires_grad=True)
+    gy = torch.randn(n, cout, h, w, generator=gen)
+    F.conv2d(x, wt, b, padding=1).backward(gy)
+    dw, db = _wino_wgrad(x.to(DEV), gy.to(DEV), cout)
+    scale = float(wt.grad.abs().max())
+    close(dw, wt.grad, 1e-4, 1e-4 * scale, "dW")
+    close(db, b.grad, 1e-4, 1e-4 * float(b.grad.abs().max()), "db")
+    # accumulate = 1 adds to the existing gradient; identical launches are bit-identical (fixed reduction order)
+    dw2, db2 = _wino_wgrad(x.to(DEV), gy.to(DEV), cout)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    acc = (dw.clone(), db.clone())
+    _wino_wgrad(x.to(DEV), gy.to(DEV), cout, accumulate_into=acc)
+    close(acc[0], 2 * wt.grad, 1e-4, 2e-4 * scale, "dW accumulate")
+
+
+def test_wino_wgrad_layer_shape_vs_direct_kernel():
+    """A trainable layer at the 1333x800 map size (conv4: 256 -> 512 at 100x166, 2 images) against the direct split-K kernel"""
+    from probabilisticteacher_amd import _lib, ops
+    gen = g(5)
+    x = torch.randn(2, 256, 100, 166, generator=gen).to(DEV)
+    gy = torch.randn(2, 512, 100, 166, generator=gen).to(DEV)
+    dw, db = _wino_wgrad(x, gy, 512)
+    ws = torch.empty(_lib.load().ptmi_conv3x3_wgrad_ws_floats(2, 256, 512, 100, 166), device=DEV)
+    dw_d, db_d = torch.empty_like(dw), torch.empty_like(db)
+    _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x), ops._ptr(gy), ops._ptr(dw_d), ops._ptr(db_d), ops._ptr(ws), 2, 256, 512,
+              100, 166, 0, ops._stream())
+    scale = float(dw_d.abs().max())
+    close(dw, dw_d, 1e-4, 1e-4 * scale, "dW wino vs direct")
+    close(db, db_d, 1e-4, 1e-4 * float(db_d.abs().max()), "db")

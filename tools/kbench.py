@@ -73,6 +73,14 @@ def main():
                           cout, h, w, 0, ops._stream())
             ms = timeit(f, a.iters)
             print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}")
+            if a.algo == "auto" and cout >= 64:
+                ws2 = torch.empty(_lib.load().ptmi_conv3x3_wino_wgrad_ws_floats(a.n, cin, cout, h, w), device=dev)
+
+                def f2():
+                    _lib.call("ptmi_conv3x3_wino_wgrad", ops._ptr(x), ops._ptr(dy), ops._ptr(dw), None, ops._ptr(ws2), a.n,
+                              cin, cout, h, w, 0, ops._stream())
+                ms = timeit(f2, a.iters)
+                print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}  (winograd)")
         del x
     if "gemm" in which:
         for r in (512 * a.n, 1024 * a.n, 2000 * a.n):
