@@ -32,6 +32,10 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef WINO_COLOCATE_MAX_COTILES
+#define WINO_COLOCATE_MAX_COTILES 4
+#endif
+
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -91,17 +95,33 @@ __device__ __forceinline__ void wino_xform(const f32x2 (&D)[12], float (&V)[16])
 
 __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
-    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi)
+    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi,
+    int coTiles, int tilesY, int nPix, int colocate)
 {
     __shared__ __attribute__((aligned(16))) float lds[3 * WSTAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // grid = (coTiles, N * tilesY, tilesX) as conv.hip: the channel tiles of a pixel tile are neighbours in time (shared
-    // patch in L2 / MALL) and, with 8 channel tiles, each XCD (linear id mod 8) keeps ONE channel tile's U slabs in its L2
-    const int cot = blockIdx.x;
-    const int ty = blockIdx.y / N, n = blockIdx.y - ty * N;
-    const int tx = blockIdx.z;
+    // Workgroup -> (channel tile, pixel tile).  Workgroups go to XCDs round robin (linear id mod 8), each XCD has its own
+    // 4 MB L2, and a pixel tile's patch is wanted by every channel tile:
+    //   colocate = 0 (8 channel tiles, 512 output channels): id = pixel tile * coTiles + channel tile -- every XCD keeps ONE
+    //       channel tile's U slabs (2 MB at Cin = 512) in its L2 and each patch is fetched by all eight L2s;
+    //   colocate = 1 (<= 4 channel tiles: all their U slabs fit one L2): the channel tiles of a pixel tile run back to back
+    //       on ONE XCD (id mod 8 = pixel tile mod 8): the patch leaves HBM / MALL once instead of coTiles times.
+    // Pixel tiles are numbered (tile column, tile row, image) with the image fastest: the light right-edge column comes last.
+    int cot, pix;
+    if (colocate) {
+        const int slot = blockIdx.x >> 3;
+        cot = slot % coTiles;
+        pix = (slot / coTiles) * 8 + (blockIdx.x & 7);
+        if (pix >= nPix) return;
+    } else {
+        cot = blockIdx.x % coTiles;
+        pix = blockIdx.x / coTiles;
+    }
+    const int nyTotal = N * tilesY;
+    const int tx = pix / nyTotal, ny = pix - tx * nyTotal;
+    const int ty = ny / N, n = ny - ty * N;
     const int x0 = tx * WTW, y0 = ty * WTH;
     const int HW = H * W;
     const int wv = W - x0;                                   // valid columns right of x0 (> 0)
@@ -852,9 +872,12 @@ int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, co
     PTMI_CHECK_ARG(epilogue != 4 || bias, "conv3x3_wino_fwd: bias required for epilogue 4");
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_wino_fwd: mask_ref required for epilogue 3");
     const int tilesX = cdiv(w, WTW), tilesY = cdiv(h, WTH), coTiles = cdiv(cout, WBM), nChunks = cdiv(cin, WKC);
-    const dim3 grid((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
-    hipLaunchKernelGGL(conv3x3_wino_kernel, grid, dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n, cin, cout, h, w,
-                       nChunks, epilogue);
+    const int64_t nPix = (int64_t)n * tilesY * tilesX;
+    const int colocate = WINO_COLOCATE_MAX_COTILES >= coTiles;
+    const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;
+    PTMI_CHECK_ARG(nWg < (1ll << 31), "conv3x3_wino_fwd: too many tiles");
+    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)nWg), dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n, cin,
+                       cout, h, w, nChunks, epilogue, coTiles, tilesY, (int)nPix, colocate);
     PTMI_LAUNCH_CHECK("conv3x3_wino_fwd");
     return 0;
 }
