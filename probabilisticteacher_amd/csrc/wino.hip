@@ -62,35 +62,42 @@ constexpr int WUI = WUS / 4 / WNT;     // U DMA instructions per lane and chunk 
 constexpr int WPI = (WPS / 4 + WNT - 1) / WNT;   // patch DMA instructions per lane and chunk (4; the last one waves 0-2 only)
 
 __device__ __forceinline__ void wino_vmwait0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// The main loop's input-transform additions, one VALU instruction each and opaque to the optimiser: the SLP vectoriser
-// otherwise packs them into v_pk_add_f32 and pays with register shuffles (v_mov / v_pk_mov) between the MFMAs -- 25 VALU in
-// one MFMA slot of a one-wave-per-SIMD kernel (the epilogue keeps its packed arithmetic).
-__device__ __forceinline__ float wino_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float wino_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-// V = B^T d B for the lane's (tile, channel): d rows a = 0..3 arrive as three 8-byte reads each, D[3a + t] = LDS columns
-// 2 ttx + 2 + 2t, + 1; the window's columns b = 0..3 are elements 1..4 of that row of six.
-__device__ __forceinline__ void wino_xform(const f32x2 (&D)[12], float (&V)[16])
+// packed fp32 additions on register pairs (VOP3P): the transforms cost half the VALU issue slots of scalar adds -- and VALU
+// time adds to fp32 MFMA time on this chip (measured: removing the transforms shortens the kernel by exactly their issue time)
+typedef __attribute__((address_space(3), aligned(4))) f32x2 wlds_f32x2_a4_t;     // 4-byte aligned pair: ds_read2_b32
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// (a.lo + b.hi, a.lo - b.hi)
+__device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// V = B^T d B for the lane's (tile, channel): window row a arrives as two 4-byte-aligned pairs (ds_read2_b32), D[2a + c] =
+// window columns (2c, 2c + 1) = LDS columns 2 ttx + 3 + 2c, + 1.  Output pairs: V[2i] = (v_i0, v_i3), V[2i + 1] = (v_i1, v_i2).
+__device__ __forceinline__ void wino_xform_rows(const f32x2 (&D)[8], f32x2 (&T)[4][2], int c)
 {
-    float t[4][4];
+    T[0][c] = pk_sub(D[0 + c], D[4 + c]);
+    T[1][c] = pk_add(D[2 + c], D[4 + c]);
+    T[2][c] = pk_sub(D[4 + c], D[2 + c]);
+    T[3][c] = pk_sub(D[2 + c], D[6 + c]);
+}
+__device__ __forceinline__ void wino_xform_col(const f32x2 (&T)[4][2], f32x2 (&V)[8], int i)
+{
+    V[2 * i] = pk_sub(T[i][0], T[i][1]);                  // (t0 - t2, t1 - t3)
+    V[2 * i + 1] = pk_lo_pm_hi(T[i][1], T[i][0]);         // (t2 + t1, t2 - t1)
+}
+__device__ __forceinline__ void wino_xform(const f32x2 (&D)[8], f32x2 (&V)[8])
+{
+    f32x2 T[4][2];
+    wino_xform_rows(D, T, 0);
+    wino_xform_rows(D, T, 1);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const float d0 = ((b + 1) & 1) ? D[0 + ((b + 1) >> 1)][1] : D[0 + ((b + 1) >> 1)][0];
-        const float d1 = ((b + 1) & 1) ? D[3 + ((b + 1) >> 1)][1] : D[3 + ((b + 1) >> 1)][0];
-        const float d2 = ((b + 1) & 1) ? D[6 + ((b + 1) >> 1)][1] : D[6 + ((b + 1) >> 1)][0];
-        const float d3 = ((b + 1) & 1) ? D[9 + ((b + 1) >> 1)][1] : D[9 + ((b + 1) >> 1)][0];
-        t[0][b] = d0 - d2;
-        t[1][b] = d1 + d2;
-        t[2][b] = d2 - d1;
-        t[3][b] = d1 - d3;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        V[4 * i + 0] = t[i][0] - t[i][2];
-        V[4 * i + 1] = t[i][1] + t[i][2];
-        V[4 * i + 2] = t[i][2] - t[i][1];
-        V[4 * i + 3] = t[i][1] - t[i][3];
-    }
+    for (int i = 0; i < 4; ++i) wino_xform_col(T, V, i);
+}
+// operand of position p = 4 i + j from the pairs above
+__device__ __forceinline__ float wino_vop(const f32x2 (&V)[8], int p)
+{
+    const int i = p >> 2, j = p & 3;
+    return (j == 0 || j == 3) ? V[2 * i][j == 3] : V[2 * i + 1][j == 2];
 }
 
 __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const int ttx = nl & 15, tty = nl >> 4;                  // tile column / row inside the wave's 16 x 2 tiles
     const bool active = y0 + 4 * wn < H;                     // (wave-uniform) some of the wave's rows lie inside the image
     const int a_off = kh * (4 * WBM * 4) + (wm * 32 + nl) * 4;                               // + ks * 2048 + i * 256
-    const int b_off = WUS + kh * WPL + (wn * 4 + tty * 2) * WPP + 2 * ttx + 2;              // + ks * 960 + a * 48 + 2 t
+    const int b_off = WUS + kh * WPL + (wn * 4 + tty * 2) * WPP + 2 * ttx + 3;              // + ks * 960 + a * 48 + 2 c   (odd: ds_read2_b32)
 
     f32x16 acc[16];
 #pragma unroll
@@ -199,22 +206,22 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
 
     if (active) {
         f32x4 A0[4], A1[4];
-        f32x2 D0[12], D1[12];
-        float V0[16], V1[16];
-        float tt[4][4];
+        f32x2 D0[8], D1[8];
+        f32x2 V0[8], V1[8];
+        f32x2 T[4][2];
         // One k-step = 16 MFMAs on (A, V), one per position, with the rest of the wave's work placed between them (one
         // wave per SIMD: whatever is not issued in the shadow of an MFMA leaves the matrix pipe idle):
         //   P = 0      in the chunk's LAST k-step the hand-over (this k-step's operands are already in registers): own DMA
         //              pieces of the next chunk landed (counted vmcnt), edge fix-ups, workgroup barrier
-        //   P = 0..7   the next k-step's twelve 8-byte window reads (two per slot, then one)
+        //   P = 0..7   the next k-step's eight window reads (one 4-byte-aligned pair each)
         //   P = 4..7   one DMA instruction each for the chunk AFTER the next (k-steps 0..2 carry its 4 + 8 instructions)
-        //   P = 8..11  the next k-step's four 16-byte A reads;  P = 10, 11  input transform, rows (two columns each)
-        //   P = 12..15 input transform, columns (one position row each) -- every LDS read is at least four MFMAs old when
-        //              the k-step ends, so the hand-over's lgkmcnt(0) costs nothing
+        //   P = 8..11  the next k-step's four 16-byte A reads
+        //   P = 12, 13 input transform, rows (one column pair each: 4 packed additions);  P = 14, 15  columns (two position
+        //              rows each: 4 packed additions) -- 16 VALU instructions per k-step: VALU time ADDS to fp32 MFMA time
         // (s_memtime probes, tools/exp: with the hand-over's reads still in flight, the edge fix-up branches in the main
         // body and two LDS stages the chunk's last k-step took 1.8k cycles against 1.1-1.2k for the others.)
-        auto kstep = [&](auto ks_c, auto more_c, auto more2_c, auto edge_c, const f32x4 (&A)[4], const float (&V)[16],
-                         f32x4 (&An)[4], f32x2 (&Dn)[12], float (&Vn)[16], int cur, int nxt, int nn) {
+        auto kstep = [&](auto ks_c, auto more_c, auto more2_c, auto edge_c, const f32x4 (&A)[4], const f32x2 (&V)[8],
+                         f32x4 (&An)[4], f32x2 (&Dn)[8], f32x2 (&Vn)[8], int cur, int nxt, int nn) {
             constexpr int KS = decltype(ks_c)::value;
             constexpr bool more = decltype(more_c)::value;        // a chunk follows this one
             constexpr bool more2 = decltype(more2_c)::value;      // ... and another one after it (its DMA is issued here)
@@ -223,10 +230,15 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
             const float* src = lds + (KS < 3 ? cur : nxt) * WSTAGE;
             const float* ap = src + a_off + ((KS + 1) & 3) * (2 * 4 * WBM * 4);
             const float* bp = src + b_off + ((KS + 1) & 3) * (2 * WPL);
-            auto dread = [&](int e) { Dn[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3)); };
+            {   // one address register for the k-step's eight window reads: ds_read2_b32 offsets are 8-bit dword counts
+                unsigned bpa = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)bp;
+                asm volatile("" : "+v"(bpa));
+                bp = (const float*)(const __attribute__((address_space(3))) float*)(size_t)bpa;
+            }
+            auto dread = [&](int e) { Dn[e] = *(const volatile wlds_f32x2_a4_t*)(bp + (e >> 1) * WPP + 2 * (e & 1)); };
             auto step = [&](auto p_c) {
                 constexpr int P = decltype(p_c)::value;
-                acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], V[P], acc[P], 0, 0, 0);
+                acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], wino_vop(V, P), acc[P], 0, 0, 0);
                 if constexpr (P == 0 && KS == 3 && more) {
                     // chunk + 1 was issued a whole chunk ago; the WPI + WUI DMA instructions of chunk + 2 are newer
                     if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + WUI) : "memory");
@@ -234,39 +246,23 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
                     if (EDGE) fixup(nxt);
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
-                if constexpr (P <= 11) {                      // ONE window read per slot
+                if constexpr (P <= 7) {                       // ONE window read per slot
                     if (next) dread(P);
                 }
-                if constexpr (P >= 12) {                      // ONE A read per slot
-                    if (next) An[P - 12] = *(const volatile wlds_f32x4_t*)(ap + (P - 12) * (WBM * 4));
+                if constexpr (P >= 8 && P <= 11) {            // ONE A read per slot
+                    if (next) An[P - 8] = *(const volatile wlds_f32x4_t*)(ap + (P - 8) * (WBM * 4));
                 }
                 if constexpr (P >= 4 && P <= 7) {
                     if (KS < 3 && more2) dma_piece(KS * 4 + (P - 4), nn);
                     if (P == 7 && KS == 2 && more2) advance();
                 }
-                if constexpr (P == 13) {
-                    if (next) {
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const int k = b + 1;
-                            const float d0 = Dn[0 + (k >> 1)][k & 1], d1 = Dn[3 + (k >> 1)][k & 1];
-                            const float d2 = Dn[6 + (k >> 1)][k & 1], d3 = Dn[9 + (k >> 1)][k & 1];
-                            tt[0][b] = wino_sub(d0, d2);
-                            tt[1][b] = wino_add(d1, d2);
-                            tt[2][b] = wino_sub(d2, d1);
-                            tt[3][b] = wino_sub(d1, d3);
-                        }
-                    }
+                if constexpr (P == 12 || P == 13) {
+                    if (next) wino_xform_rows(Dn, T, P - 12);
                 }
                 if constexpr (P >= 14) {
                     if (next) {
-#pragma unroll
-                        for (int i = 2 * (P - 14); i < 2 * (P - 14) + 2; ++i) {
-                            Vn[4 * i + 0] = wino_sub(tt[i][0], tt[i][2]);
-                            Vn[4 * i + 1] = wino_add(tt[i][1], tt[i][2]);
-                            Vn[4 * i + 2] = wino_sub(tt[i][2], tt[i][1]);
-                            Vn[4 * i + 3] = wino_sub(tt[i][1], tt[i][3]);
-                        }
+                        wino_xform_col(T, Vn, 2 * (P - 14));
+                        wino_xform_col(T, Vn, 2 * (P - 14) + 1);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -296,7 +292,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) A0[i] = *(const volatile wlds_f32x4_t*)(ap + i * (WBM * 4));
 #pragma unroll
-            for (int e = 0; e < 12; ++e) D0[e] = *(const volatile wlds_f32x2_t*)(bp + (e / 3) * WPP + 2 * (e % 3));
+            for (int e = 0; e < 8; ++e) D0[e] = *(const volatile wlds_f32x2_a4_t*)(bp + (e >> 1) * WPP + 2 * (e & 1));
             wino_xform(D0, V0);
         }
         // three stages in LDS: chunk c is computed from stage c % 3 while chunk c + 1 sits complete (or landing) in the next
@@ -513,14 +509,6 @@ constexpr int GXR = 11 * 256 * 4;        // x region: 2624 pieces padded to 11
 constexpr int GSTAGE = GDYR + GXR;       // 16384 floats = 64 KB; two stages
 constexpr int GND = 5, GNX = 11;
 
-// packed fp32 additions on register pairs (VOP3P): the transforms cost half the VALU issue slots of scalar adds -- and VALU
-// time adds to fp32 MFMA time on this chip (measured: removing the transforms shortens the kernel by exactly their issue time)
-typedef __attribute__((address_space(3), aligned(4))) f32x2 wlds_f32x2_a4_t;     // 4-byte aligned pair: ds_read2_b32
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// (a.lo + b.hi, a.lo - b.hi)
-__device__ __forceinline__ f32x2 pk_lo_pm_hi(f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
-
 __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, float* __restrict__ bpartial,
     int N, int Cin, int Cout, int H, int W, int ciTiles, int S, int tilesY2, int colBlocks)
@@ -553,7 +541,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
         const int ch = px / 41, rem = px - ch * 41;
         const int r = rem / 10, q4 = 4 * (rem - r * 10) - 4;
         const bool ok = px < GWC * 41 && rem < 40 && ci0 + ch < Cin;
-        voff[i] = (unsigned)(ch * HW + r * W + q4 + 4) * 4u;
+        voff[i] = ok ? (unsigned)(ch * HW + r * W + q4 + 4) * 4u : 0xFFFFFFFFu;
         m_ch |= (unsigned)ok << i;
         m_first |= (unsigned)(q4 >= 0) << i;
         m_last |= (unsigned)(q4 < wvl) << i;
@@ -569,7 +557,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
         const int ch = pd / 17, rem = pd - ch * 17;
         const int r = rem >> 3, q4 = 4 * (rem & 7);
         const bool ok = pd < GWC * 17 && rem < 16 && co0 + ch < Cout;
-        voff[GNX + i] = (unsigned)(ch * HW + r * W + q4) * 4u;
+        voff[GNX + i] = ok ? (unsigned)(ch * HW + r * W + q4) * 4u : 0xFFFFFFFFu;
         m_ch |= (unsigned)ok << (GNX + i);
         m_first |= 1u << (GNX + i);
         m_last |= (unsigned)(q4 < wvl) << (GNX + i);
@@ -593,7 +581,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
     int f_left = nC;                                     // chunks of this split not yet set up
     __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(x), 0, 0, 0x00020000);
     __amdgpu_buffer_rsrc_t rd = rx;
-    unsigned eoff[GNX + GND];
+    unsigned eoff[GNX + GND];                            // effective offsets of a chunk on the image border (else voff)
+    bool f_plain = false;
     unsigned long long fix = 0;
     auto fetch_setup = [&]() {
         const bool any = f_left > 0;
@@ -604,10 +593,9 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
         rd = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(db), 0, clamp_rec(dy_end - (const char*)db), 0x00020000);
         const bool first = f_cb == 0, last = f_cb == colBlocks - 1;
         const bool top = y0 == 0, bot2 = y0 + 1 >= H, bot3 = y0 + 2 >= H;
-        if (any && !first && !last && !top && !bot3) {   // interior chunk: only the channel mask
+        f_plain = any && !first && !last && !top && !bot3;
+        if (f_plain) {                                   // interior chunk: only the channel mask (already in voff)
             fix = 0;
-#pragma unroll
-            for (int i = 0; i < GNX + GND; ++i) eoff[i] = (m_ch >> i) & 1 ? voff[i] : 0xFFFFFFFFu;
         } else {
             unsigned m = any ? m_ch : 0u;
             m &= first ? m_first : ~0u;
@@ -627,12 +615,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
         }
     };
     auto fetch_piece = [&](int idx, int stage) {
-        if (idx < GNX)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (wlds_void_t*)(lds + stage * GSTAGE + GDYR + wave * 256 + idx * WNT * 4), 16,
-                                                     (int)eoff[idx], 0, 0, 0);
-        else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (wlds_void_t*)(lds + stage * GSTAGE + wave * 256 + (idx - GNX) * WNT * 4), 16,
-                                                     (int)eoff[idx], 0, 0, 0);
+        // (a scalar branch instead of a per-lane select: every VALU instruction in the loop costs MFMA time)
+        wlds_void_t* dst = (wlds_void_t*)(lds + stage * GSTAGE + (idx < GNX ? GDYR + wave * 256 + idx * WNT * 4 : wave * 256 + (idx - GNX) * WNT * 4));
+        if (f_plain) __builtin_amdgcn_raw_ptr_buffer_load_lds(idx < GNX ? rx : rd, dst, 16, (int)voff[idx], 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(idx < GNX ? rx : rd, dst, 16, (int)eoff[idx], 0, 0, 0);
     };
     auto fixup = [&](int stage, unsigned long long fm) {
         if ((unsigned)fm | (unsigned)(fm >> 32)) {
@@ -662,9 +648,15 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
     f32x2 T[4][2];                         // B^T d, rows i, column pairs (0, 1), (2, 3)
     float bsum = 0.f;                      // sum of this lane's dY tiles: position (1, 1) of W' is d00 + d01 + d10 + d11
 
-    auto raw_read = [&](const float* stage, int ks, f32x2 (&ra)[2], f32x2 (&rb)[8], int P) {      // one read per MFMA slot P = 0..9
+    // one address register per k-step for the eight window reads (ds_read2_b32 offsets are 8-bit dword counts)
+    auto window_base = [&](const float* stage, int ks) {
+        unsigned a = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)(stage + b_off + 4 * ks);
+        asm volatile("" : "+v"(a));
+        return (const float*)(const __attribute__((address_space(3))) float*)(size_t)a;
+    };
+    auto raw_read = [&](const float* stage, const float* wb, int ks, f32x2 (&ra)[2], f32x2 (&rb)[8], int P) {      // one read per MFMA slot P = 0..9
         if (P < 2) ra[P] = *(const volatile wlds_f32x2_t*)(stage + a_off + 4 * ks + 32 * P);
-        else if (P < 10) rb[P - 2] = *(const volatile wlds_f32x2_a4_t*)(stage + b_off + 4 * ks + ((P - 2) >> 1) * 40 + 2 * ((P - 2) & 1));
+        else if (P < 10) rb[P - 2] = *(const volatile wlds_f32x2_a4_t*)(wb + ((P - 2) >> 1) * 40 + 2 * ((P - 2) & 1));
     };
     auto xform_a_rows = [&](const f32x2 (&ra)[2], f32x2 (&wr)[4]) {
         wr[0] = ra[0];
@@ -701,7 +693,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
         unsigned long long fix_h = fix;          // fix-ups of the next chunk to be handed over (chunk 1)
         {   // operands of k-step 0 (transformed) and raw operands of k-step 1
 #pragma unroll
-            for (int P = 0; P < 10; ++P) raw_read(lds, 0, RA[0], RB[0], P);
+            for (int P = 0; P < 10; ++P) raw_read(lds, window_base(lds, 0), 0, RA[0], RB[0], P);
             xform_a_rows(RA[0], WR[0]);
 #pragma unroll
             for (int i = 0; i < 4; ++i) xform_a_col(WR[0], WZ[0], i);
@@ -710,7 +702,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) xform_b_col(VX[0], VY[0], i);
 #pragma unroll
-            for (int P = 0; P < 10; ++P) raw_read(lds, 1, RA[1], RB[1], P);
+            for (int P = 0; P < 10; ++P) raw_read(lds, window_base(lds, 1), 1, RA[1], RB[1], P);
         }
         // k-step KS of the chunk in stage `cur`: MFMAs on the operands [KS & 1]; raw reads of k-step KS + 2 into R[KS & 1]; transforms
         // of k-step KS + 1 (raw R[(KS + 1) & 1], read one k-step ago) into the operands [(KS + 1) & 1]
@@ -719,6 +711,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
             constexpr int M = KS & 1, O = M ^ 1;
             const float* src = lds + ((KS < 6) ? cur : cur ^ 1) * GSTAGE;
             constexpr int KR = (KS + 2) & 7;
+            const float* wb = window_base(src, KR);
             auto step = [&](auto p_c) {
                 constexpr int P = decltype(p_c)::value;
                 if (!(WGX & 16)) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(M, P), opb(M, P), acc[P], 0, 0, 0);
@@ -734,7 +727,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
                     fetch_setup();
                     fix_h = fix;
                 }
-                if constexpr (P < 10) { if (!(WGX & 4)) raw_read(src, KR, RA[M], RB[M], P); }
+                if constexpr (P < 10) { if (!(WGX & 4)) raw_read(src, wb, KR, RA[M], RB[M], P); }
                 // fetch of chunk + 2 (k-steps 6, 7) / of chunk + 1 (k-steps 0, 1): four DMA instructions per k-step
                 if constexpr ((KS == 6 || KS == 7 || KS == 0 || KS == 1) && (P == 1 || P == 8 || P == 9 || P == 14)) {
                     constexpr int part = KS == 6 ? 0 : (KS == 7 ? 1 : (KS == 0 ? 2 : 3));
