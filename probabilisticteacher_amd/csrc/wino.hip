@@ -358,17 +358,28 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         if (epi <= 1 || epi == 4)
             bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, half4 * 4, (co_w + g * 8) * 4, 0));
     }
-    auto inverse = [&](int r, float (&o)[4]) {
-        float s0[4], s1[4];
+    // Two accumulator rows (channels r, r + 1: adjacent registers of every position tile) at a time on packed additions, all
+    // opaque to the optimiser (left to itself the compiler spends ~1 270 instructions per lane here -- 590 accumulator reads for
+    // 256 values, 250 register moves around its own packed operations -- and the epilogue is 5-20 % of the kernel).
+    auto inverse2 = [&](auto rp_c, f32x2 (&o)[4]) {
+        constexpr int r = 2 * decltype(rp_c)::value;
+        f32x2 s0[4], s1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s0[j] = (acc[j][r] + acc[4 + j][r]) + acc[8 + j][r];
-            s1[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
+            const f32x2 m0 = {acc[j][r], acc[j][r + 1]}, m1 = {acc[4 + j][r], acc[4 + j][r + 1]};
+            const f32x2 m2 = {acc[8 + j][r], acc[8 + j][r + 1]}, m3 = {acc[12 + j][r], acc[12 + j][r + 1]};
+            s0[j] = pk_add(pk_add(m0, m1), m2);
+            s1[j] = pk_sub(pk_sub(m1, m2), m3);
         }
-        o[0] = (s0[0] + s0[1]) + s0[2];
-        o[1] = (s0[1] - s0[2]) - s0[3];
-        o[2] = (s1[0] + s1[1]) + s1[2];
-        o[3] = (s1[1] - s1[2]) - s1[3];
+        o[0] = pk_add(pk_add(s0[0], s0[1]), s0[2]);
+        o[1] = pk_sub(pk_sub(s0[1], s0[2]), s0[3]);
+        o[2] = pk_add(pk_add(s1[0], s1[1]), s1[2]);
+        o[3] = pk_sub(pk_sub(s1[1], s1[2]), s1[3]);
+    };
+    auto for_row_pairs = [&](auto&& f) {
+        f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{});
+        f(std::integral_constant<int, 3>{}); f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 5>{});
+        f(std::integral_constant<int, 6>{}); f(std::integral_constant<int, 7>{});
     };
     if (epi == 4) {
         // bias + ReLU + 2x2/2 max pool (floor mode): the tile's four outputs are one pool window
@@ -376,15 +387,18 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)Cout * (unsigned)OHW * 4u);
         const int oy = py >> 1, ox = px >> 1;
         const unsigned pv = (oy < OH && ox < OW) ? (unsigned)(half4 * OHW + oy * OW + ox) * 4u : 0xFFFFFFFFu;
+        for_row_pairs([&](auto rp_c) {
+            constexpr int r = 2 * decltype(rp_c)::value;
+            f32x2 o[4];
+            inverse2(rp_c, o);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int soff = (co_w + (r & 3) + 8 * (r >> 2)) * OHW * 4;
-            const float b = bv[r >> 2][r & 3];
-            float o[4];
-            inverse(r, o);
-            const float m = fmaxf(fmaxf(fmaxf(o[0] + b, o[1] + b), fmaxf(o[2] + b, o[3] + b)), 0.f);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ry, (int)pv, soff, 0);
-        }
+            for (int h = 0; h < 2; ++h) {
+                const int soff = (co_w + ((r + h) & 3) + 8 * ((r + h) >> 2)) * OHW * 4;
+                const float b = bv[(r + h) >> 2][(r + h) & 3];
+                const float m = fmaxf(fmaxf(fmaxf(o[0][h] + b, o[1][h] + b), fmaxf(o[2][h] + b, o[3][h] + b)), 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ry, (int)pv, soff, 0);
+            }
+        });
         return;
     }
     const unsigned img_bytes = (unsigned)Cout * (unsigned)HW * 4u;
@@ -401,34 +415,56 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         pv1[a] = (rok && px + 1 == W) ? o : 0xFFFFFFFFu;
     }
     const bool odd_edge = (W & 1) && x0 + WTW > W;                     // (workgroup-uniform) a lane may hold a single column
+    auto store_rows = [&](auto epi_c) {
+        constexpr int EPI = decltype(epi_c)::value;
+        for_row_pairs([&](auto rp_c) {
+            constexpr int r = 2 * decltype(rp_c)::value;
+            f32x2 mk[2][2];
+            float ms[2][2];
+            if constexpr (EPI == 3) {                                  // the producer's activations first: their latency hides
+#pragma unroll                                                         // behind the inverse transform
+                for (int h = 0; h < 2; ++h) {
+                    const int soff = (co_w + ((r + h) & 3) + 8 * ((r + h) >> 2)) * HW * 4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int soff = (co_w + (r & 3) + 8 * (r >> 2)) * HW * 4;
-        const float b = bv[r >> 2][r & 3];
-        float o[4];
-        inverse(r, o);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            float v0 = o[2 * a], v1 = o[2 * a + 1];
-            if (epi <= 1) {
-                v0 += b;
-                v1 += b;
-                if (epi == 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-            } else if (epi == 3) {
-                const f32x2 mk = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)pv2[a], soff, 0));
-                float m0 = mk[0];
-                if (odd_edge) {
-                    const float ms = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)pv1[a], soff, 0));
-                    m0 = (pv1[a] != 0xFFFFFFFFu) ? ms : m0;
+                    for (int a = 0; a < 2; ++a) {
+                        mk[h][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)pv2[a], soff, 0));
+                        if (odd_edge) ms[h][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)pv1[a], soff, 0));
+                    }
                 }
-                v0 = (m0 > 0.f) ? v0 : 0.f;
-                v1 = (mk[1] > 0.f) ? v1 : 0.f;
             }
-            const f32x2 st = {v0, v1};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, st), ry, (int)pv2[a], soff, 0);
-            if (odd_edge) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, (int)pv1[a], soff, 0);
-        }
-    }
+            f32x2 o[4];
+            inverse2(rp_c, o);
+            if constexpr (EPI <= 1) {
+                const f32x2 b2 = {bv[r >> 2][r & 3], bv[r >> 2][(r & 3) + 1]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = pk_add(o[k], b2);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int soff = (co_w + ((r + h) & 3) + 8 * ((r + h) >> 2)) * HW * 4;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v0 = o[2 * a][h], v1 = o[2 * a + 1][h];
+                    if constexpr (EPI == 1) {
+                        v0 = fmaxf(v0, 0.f);
+                        v1 = fmaxf(v1, 0.f);
+                    } else if constexpr (EPI == 3) {
+                        float m0 = mk[h][a][0];
+                        if (odd_edge) m0 = (pv1[a] != 0xFFFFFFFFu) ? ms[h][a] : m0;
+                        v0 = (m0 > 0.f) ? v0 : 0.f;
+                        v1 = (mk[h][a][1] > 0.f) ? v1 : 0.f;
+                    }
+                    const f32x2 st = {v0, v1};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, st), ry, (int)pv2[a], soff, 0);
+                    if (odd_edge) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, (int)pv1[a], soff, 0);
+                }
+            }
+        });
+    };
+    if (epi == 0) store_rows(std::integral_constant<int, 0>{});
+    else if (epi == 1) store_rows(std::integral_constant<int, 1>{});
+    else if (epi == 2) store_rows(std::integral_constant<int, 2>{});
+    else store_rows(std::integral_constant<int, 3>{});
 }
 
 // U = G g G^T with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], laid out as the kernel's LDS image:
