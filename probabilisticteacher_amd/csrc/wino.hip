@@ -538,17 +538,30 @@ __global__ void wino_pack_weights_kernel(const float* __restrict__ w, float* __r
 #define WGX 0          // timing experiments only (tools/exp): 1 no DMA, 2 no transforms, 4 no LDS reads, 8 no hand-over, 16 no MFMA
 #endif
 constexpr int GWC = 64;                  // channels per operand tile
-constexpr int GDYP = 68;                 // dY plane pitch: 2 rows x 32 columns + one pad piece
-constexpr int GXP = 164;                 // x plane pitch: 4 rows x 40 columns (x0-4 .. x0+35) + one pad piece
-constexpr int GDYR = 5 * 256 * 4;        // dY region of a stage: 1088 pieces padded to 5 DMA instructions per lane
-constexpr int GXR = 11 * 256 * 4;        // x region: 2624 pieces padded to 11
-constexpr int GSTAGE = GDYR + GXR;       // 16384 floats = 64 KB; two stages
-constexpr int GND = 5, GNX = 11;
+// geometry of a chunk of KSN k-steps (= 2 KSN tiles = 4 KSN columns of one tile row).  KSN = 8: 32 columns; KSN = 7: 28 columns,
+// which tiles W = 83 / 166 / 333 (21 / 42 / 84 tile pairs per row) without the 12.5 / 12.5 / 4.5 % of padded k-steps of KSN = 8
+template <int KSN> struct WG {
+    static constexpr int COLS = 4 * KSN;
+    static constexpr int XPR = KSN + 2;              // 16-B pieces per x row: columns x0 - 4 .. x0 + 4 KSN + 3
+    static constexpr int XPC = 4 * XPR + 1;          // pieces per x channel plane: 4 rows + one pad piece
+    static constexpr int DPC = 2 * KSN + 1;          // pieces per dY channel plane: 2 rows + one pad piece
+    static constexpr int GXP = 4 * XPC;              // x plane pitch in floats (164 / 148: an odd multiple of 4)
+    static constexpr int GDYP = 4 * DPC;             // dY plane pitch (68 / 60)
+    static constexpr int GNX = (GWC * XPC + 255) / 256;      // x DMA instructions per lane and chunk (11 / 10)
+    static constexpr int GND = (GWC * DPC + 255) / 256;      // dY DMA instructions (5 / 4)
+    static constexpr int NP = GNX + GND;
+    static constexpr int GDYR = GND * 1024;          // floats of the dY region of a stage (regions padded to whole instructions)
+    static constexpr int GXR = GNX * 1024;
+    static constexpr int GSTAGE = GDYR + GXR;        // 64 KB / 56 KB; two stages
+};
 
+template <int KSN>
 __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, float* __restrict__ bpartial,
     int N, int Cin, int Cout, int H, int W, int ciTiles, int S, int tilesY2, int colBlocks)
 {
+    using G = WG<KSN>;
+    constexpr int GNX = G::GNX, GND = G::GND, GDYR = G::GDYR, GSTAGE = G::GSTAGE, GXP = G::GXP, GDYP = G::GDYP;
     __shared__ __attribute__((aligned(16))) float lds[2 * GSTAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -570,13 +583,13 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
     unsigned m_ch = 0, m_first = 0, m_last = 0;          // channel inside the tensor; column valid in the first / last column block
     unsigned m_r0 = 0, m_r2 = 0, m_r3 = 0, m_d1 = 0;     // x pieces of window row 0 / 2 / 3, dY pieces of row 1
     unsigned long long fix_last = 0;                     // last column block: words past the image edge, bits 4 i + e
-    const int wvl = W - (colBlocks - 1) * WTW;           // width of the last column block (1 .. 32)
+    const int wvl = W - (colBlocks - 1) * G::COLS;       // width of the last column block (1 .. 4 KSN)
 #pragma unroll
     for (int i = 0; i < GNX; ++i) {
         const int px = tid + i * WNT;
-        const int ch = px / 41, rem = px - ch * 41;
-        const int r = rem / 10, q4 = 4 * (rem - r * 10) - 4;
-        const bool ok = px < GWC * 41 && rem < 40 && ci0 + ch < Cin;
+        const int ch = px / G::XPC, rem = px - ch * G::XPC;
+        const int r = rem / G::XPR, q4 = 4 * (rem - r * G::XPR) - 4;
+        const bool ok = px < GWC * G::XPC && rem < 4 * G::XPR && ci0 + ch < Cin;
         voff[i] = ok ? (unsigned)(ch * HW + r * W + q4 + 4) * 4u : 0xFFFFFFFFu;
         m_ch |= (unsigned)ok << i;
         m_first |= (unsigned)(q4 >= 0) << i;
@@ -590,9 +603,9 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < GND; ++i) {
         const int pd = tid + i * WNT;
-        const int ch = pd / 17, rem = pd - ch * 17;
-        const int r = rem >> 3, q4 = 4 * (rem & 7);
-        const bool ok = pd < GWC * 17 && rem < 16 && co0 + ch < Cout;
+        const int ch = pd / G::DPC, rem = pd - ch * G::DPC;
+        const int r = rem / KSN, q4 = 4 * (rem - r * KSN);
+        const bool ok = pd < GWC * G::DPC && rem < 2 * KSN && co0 + ch < Cout;
         voff[GNX + i] = ok ? (unsigned)(ch * HW + r * W + q4) * 4u : 0xFFFFFFFFu;
         m_ch |= (unsigned)ok << (GNX + i);
         m_first |= 1u << (GNX + i);
@@ -622,7 +635,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
     unsigned long long fix = 0;
     auto fetch_setup = [&]() {
         const bool any = f_left > 0;
-        const int y0 = 2 * f_ty, x0 = f_cb * WTW;
+        const int y0 = 2 * f_ty, x0 = f_cb * G::COLS;
         const float* xb = x + ((size_t)f_n * Cin + ci0) * HW + ((ptrdiff_t)y0 - 1) * W + (x0 - 4);
         const float* db = dy + ((size_t)f_n * Cout + co0) * HW + (size_t)y0 * W + x0;
         rx = __builtin_amdgcn_make_buffer_rsrc(ptmi_uniform_ptr(xb), 0, clamp_rec(x_end - (const char*)xb), 0x00020000);
@@ -691,8 +704,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
         return (const float*)(const __attribute__((address_space(3))) float*)(size_t)a;
     };
     auto raw_read = [&](const float* stage, const float* wb, int ks, f32x2 (&ra)[2], f32x2 (&rb)[8], int P) {      // one read per MFMA slot P = 0..9
-        if (P < 2) ra[P] = *(const volatile wlds_f32x2_t*)(stage + a_off + 4 * ks + 32 * P);
-        else if (P < 10) rb[P - 2] = *(const volatile wlds_f32x2_a4_t*)(wb + ((P - 2) >> 1) * 40 + 2 * ((P - 2) & 1));
+        if (P < 2) ra[P] = *(const volatile wlds_f32x2_t*)(stage + a_off + 4 * ks + G::COLS * P);
+        else if (P < 10) rb[P - 2] = *(const volatile wlds_f32x2_a4_t*)(wb + ((P - 2) >> 1) * (4 * G::XPR) + 2 * ((P - 2) & 1));
     };
     auto xform_a_rows = [&](const f32x2 (&ra)[2], f32x2 (&wr)[4]) {
         wr[0] = ra[0];
@@ -740,21 +753,23 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
 #pragma unroll
             for (int P = 0; P < 10; ++P) raw_read(lds, window_base(lds, 1), 1, RA[1], RB[1], P);
         }
-        // k-step KS of the chunk in stage `cur`: MFMAs on the operands [KS & 1]; raw reads of k-step KS + 2 into R[KS & 1]; transforms
-        // of k-step KS + 1 (raw R[(KS + 1) & 1], read one k-step ago) into the operands [(KS + 1) & 1]
-        auto kstep = [&](auto ks_c, int cur) {
+        // k-step KS of the chunk in stage `cur`, operand parity PAR: MFMAs on the operands [M], M = (KS + PAR) & 1; raw reads of k-step
+        // KS + 2 into R[M]; transforms of k-step KS + 1 (raw R[M ^ 1], read one k-step ago) into the operands [M ^ 1].  With an odd
+        // number of k-steps per chunk the parity alternates from chunk to chunk: the loop body is then two chunks.
+        auto kstep = [&](auto ks_c, auto par_c, int cur) {
             constexpr int KS = decltype(ks_c)::value;
-            constexpr int M = KS & 1, O = M ^ 1;
-            const float* src = lds + ((KS < 6) ? cur : cur ^ 1) * GSTAGE;
-            constexpr int KR = (KS + 2) & 7;
+            constexpr int M = (KS + decltype(par_c)::value) & 1, O = M ^ 1;
+            constexpr bool late = KS >= KSN - 2;                 // after the hand-over: reads come from the next chunk's stage
+            const float* src = lds + (late ? cur ^ 1 : cur) * GSTAGE;
+            constexpr int KR = (KS + 2) % KSN;
             const float* wb = window_base(src, KR);
             auto step = [&](auto p_c) {
                 constexpr int P = decltype(p_c)::value;
                 if (!(WGX & 16)) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(M, P), opb(M, P), acc[P], 0, 0, 0);
                 if constexpr (P == 15) bsum += WZ[M][1][0];
-                if constexpr (P == 0 && KS == 6) {
+                if constexpr (P == 0 && KS == KSN - 2) {
                     // hand-over: the next chunk's pieces (all issued by k-step 1) have landed; edge fix-ups; barrier; then the
-                    // stage this chunk occupied is free (its last raw reads were k-step 5's) and the fetch of chunk + 2 starts
+                    // stage this chunk occupied is free (its last raw reads were k-step KSN - 3's) and the fetch of chunk + 2 starts
                     if (!(WGX & 8)) {
                         wino_vmwait0();
                         fixup(cur ^ 1, fix_h);
@@ -764,11 +779,13 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
                     fix_h = fix;
                 }
                 if constexpr (P < 10) { if (!(WGX & 4)) raw_read(src, wb, KR, RA[M], RB[M], P); }
-                // fetch of chunk + 2 (k-steps 6, 7) / of chunk + 1 (k-steps 0, 1): four DMA instructions per k-step
-                if constexpr ((KS == 6 || KS == 7 || KS == 0 || KS == 1) && (P == 1 || P == 8 || P == 9 || P == 14)) {
-                    constexpr int part = KS == 6 ? 0 : (KS == 7 ? 1 : (KS == 0 ? 2 : 3));
+                // fetch of chunk + 2 (last two k-steps) / of chunk + 1 (k-steps 0, 1): four DMA instructions per k-step
+                if constexpr ((late || KS == 0 || KS == 1) && (P == 1 || P == 8 || P == 9 || P == 14)) {
+                    constexpr int part = KS == KSN - 2 ? 0 : (KS == KSN - 1 ? 1 : (KS == 0 ? 2 : 3));
                     constexpr int sub = P == 1 ? 0 : (P == 8 ? 1 : (P == 9 ? 2 : 3));
-                    if (!(WGX & 1)) fetch_piece(part * 4 + sub, (KS >= 6) ? cur : cur ^ 1);
+                    if constexpr (part * 4 + sub < G::NP) {
+                        if (!(WGX & 1)) fetch_piece(part * 4 + sub, late ? cur : cur ^ 1);
+                    }
                 }
                 // transforms of k-step KS + 1
                 if (!(WGX & 2)) {
@@ -788,16 +805,24 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
             step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
             step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
         };
-        for (int chunk = 0; chunk < nC; ++chunk) {
-            const int cur = chunk & 1;
-            kstep(std::integral_constant<int, 0>{}, cur);
-            kstep(std::integral_constant<int, 1>{}, cur);
-            kstep(std::integral_constant<int, 2>{}, cur);
-            kstep(std::integral_constant<int, 3>{}, cur);
-            kstep(std::integral_constant<int, 4>{}, cur);
-            kstep(std::integral_constant<int, 5>{}, cur);
-            kstep(std::integral_constant<int, 6>{}, cur);
-            kstep(std::integral_constant<int, 7>{}, cur);
+        auto chunk_body = [&](auto par_c, int cur) {
+            kstep(std::integral_constant<int, 0>{}, par_c, cur);
+            kstep(std::integral_constant<int, 1>{}, par_c, cur);
+            kstep(std::integral_constant<int, 2>{}, par_c, cur);
+            kstep(std::integral_constant<int, 3>{}, par_c, cur);
+            kstep(std::integral_constant<int, 4>{}, par_c, cur);
+            kstep(std::integral_constant<int, 5>{}, par_c, cur);
+            kstep(std::integral_constant<int, 6>{}, par_c, cur);
+            if constexpr (KSN == 8) kstep(std::integral_constant<int, 7>{}, par_c, cur);
+        };
+        if constexpr (KSN & 1) {
+            // (an odd chunk count runs one empty chunk: its stage was filled by an all-invalid fetch, i.e. with zeros)
+            for (int chunk = 0; chunk < nC; chunk += 2) {
+                chunk_body(std::integral_constant<int, 0>{}, 0);
+                chunk_body(std::integral_constant<int, 1>{}, 1);
+            }
+        } else {
+            for (int chunk = 0; chunk < nC; ++chunk) chunk_body(std::integral_constant<int, 0>{}, chunk & 1);
         }
         wino_vmwait0();           // the last (empty) fetches must have landed before the workgroup gives up its LDS
     }
@@ -856,11 +881,18 @@ __global__ void wino_wgrad_reduce_kernel(const float* __restrict__ partial, cons
     }
 }
 
+// k-steps per chunk: the choice with fewer (padded) k-steps per tile row
+static int wino_wgrad_ksn(int w)
+{
+    const int pairs = cdiv(cdiv(w, 2), 2);
+    return cdiv(pairs, 7) * 7 < cdiv(pairs, 8) * 8 ? 7 : 8;
+}
+
 // splits per (co tile, ci tile): fill the chip's 256 one-workgroup-per-CU slots a whole number of times
 static int wino_wgrad_splits(int n, int cin, int cout, int h, int w)
 {
     const int pairs = cdiv(cout, GWC) * cdiv(cin, GWC);
-    const int64_t chunks = (int64_t)n * cdiv(h, 2) * cdiv(w, WTW);
+    const int64_t chunks = (int64_t)n * cdiv(h, 2) * cdiv(w, 4 * wino_wgrad_ksn(w));
     int S = cdiv(256, pairs);
     if (S > chunks) S = (int)chunks;
     return S < 1 ? 1 : S;
@@ -926,8 +958,12 @@ int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* d
     const int coTiles = cdiv(cout, GWC), ciTiles = cdiv(cin, GWC);
     hipStream_t st = (hipStream_t)s;
     float* bws = ws + (size_t)S * 16 * cout * cin;
-    hipLaunchKernelGGL(conv3x3_wino_wgrad_kernel, dim3((unsigned)(coTiles * ciTiles * S)), dim3(WNT), 0, st, x, dy, ws, bws, n, cin, cout, h, w,
-                       ciTiles, S, cdiv(h, 2), cdiv(w, WTW));
+    if (wino_wgrad_ksn(w) == 7)
+        hipLaunchKernelGGL(conv3x3_wino_wgrad_kernel<7>, dim3((unsigned)(coTiles * ciTiles * S)), dim3(WNT), 0, st, x, dy, ws, bws, n, cin, cout,
+                           h, w, ciTiles, S, cdiv(h, 2), cdiv(w, 28));
+    else
+        hipLaunchKernelGGL(conv3x3_wino_wgrad_kernel<8>, dim3((unsigned)(coTiles * ciTiles * S)), dim3(WNT), 0, st, x, dy, ws, bws, n, cin, cout,
+                           h, w, ciTiles, S, cdiv(h, 2), cdiv(w, 32));
     PTMI_LAUNCH_CHECK("conv3x3_wino_wgrad");
     const int64_t cc = (int64_t)cout * cin;
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, st, ws, bws, dw, db, cout, cin, S, accumulate);

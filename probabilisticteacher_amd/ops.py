@@ -208,11 +208,14 @@ def wino_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
 
 
 def wino_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
-    """FLOPs of the MFMAs one ptmi_conv3x3_wino_wgrad launch issues: per 64 co x 64 ci pair and chunk (one tile row x 32
-    columns = 16 tiles) 8 k-steps x 16 positions x 4 waves x 4096 FLOP"""
+    """FLOPs of the MFMAs one ptmi_conv3x3_wino_wgrad launch issues: per 64 co x 64 ci pair and chunk (one tile row x KSN
+    tile pairs; KSN = 7 or 8, whichever pads a tile row less -- csrc/wino.hip: wino_wgrad_ksn) KSN k-steps x 16 positions x
+    4 waves x 4096 FLOP"""
     pairs = -(-cout // 64) * -(-cin // 64)
-    chunks = n * -(-h // 2) * -(-w // 32)
-    return float(pairs) * chunks * 8 * 16 * 4 * 4096
+    tile_pairs = -(-(-(-w // 2)) // 2)
+    ksn = 7 if -(-tile_pairs // 7) * 7 < -(-tile_pairs // 8) * 8 else 8
+    chunks = n * -(-h // 2) * -(-w // (4 * ksn))
+    return float(pairs) * chunks * ksn * 16 * 4 * 4096
 
 
 def _use_wino(conv_cin: int) -> bool:

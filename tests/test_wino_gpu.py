@@ -150,6 +150,9 @@ WGRAD_SHAPES = SHAPES + [
     (1, 64, 192, 2, 36),      # the last column block holds only the 4 rightmost columns
     (2, 70, 100, 9, 37),      # ragged channel tiles both sides
     (4, 64, 64, 40, 45),      # many chunks per split: the steady-state pipeline over both LDS stages
+    (4, 64, 64, 40, 64),      # the same with 8 k-steps per chunk (W = 32, 64, 666, 1333 take KSN = 8, the others 7)
+    (1, 64, 64, 6, 84),       # KSN = 7, three exact 28-column blocks, 9 chunks over 9 splits
+    (5, 64, 64, 22, 56),      # KSN = 7, odd chunk counts per split (one empty chunk closes the two-chunk loop body)
 ]
 
 
