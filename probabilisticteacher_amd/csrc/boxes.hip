@@ -3,6 +3,7 @@
 // bit-exact against the CPU oracle, so the fp32 expression trees below mirror the reference's
 // (pt/modeling/box_regression.py, D2 pairwise_iou / Matcher -- SURVEY.md A.2/A.3) op for op.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -277,8 +278,10 @@ __global__ __launch_bounds__(256) void iou_match_pass2_batched(const float* __re
 
 // D2 subsample_labels for a batch of label vectors without host round trips.  Element j of image i
 // carries a random key; the sample is the (at most) n_pos positives and n_neg negatives with the smallest keys --
-// the first entries of the permutation argsort(keys[candidates]) -- written in ascending key order.  One workgroup
-// per image ranks its candidates with an O(P^2) count over LDS (P <= 12 288: a few thousand proposals).
+// the first entries of the permutation argsort(keys[candidates]) -- written in ascending key order.  An image's
+// candidates are ranked with an O(P^2) count over LDS (P <= 12 288: a few thousand proposals) by gridDim.y workgroups:
+// each stages all P keys and ranks every gridDim.y-th block of 256 candidates (one workgroup per image was 1.7 ms of
+// pure latency per call at 2 000 proposals).
 constexpr int SAMPLE_MAXP = 12288;
 
 __global__ __launch_bounds__(256) void sample_by_keys_kernel(const int64_t* __restrict__ cls, const float* __restrict__ keys,
@@ -290,6 +293,7 @@ __global__ __launch_bounds__(256) void sample_by_keys_kernel(const int64_t* __re
     extern __shared__ float skey[];                        // P keys, then P type bytes
     __shared__ int scnt[2];
     const int img = blockIdx.x, tid = threadIdx.x;
+    const int part = blockIdx.y, parts = gridDim.y;
     const int p0 = off[img], P = off[img + 1] - p0;
     unsigned char* stype = reinterpret_cast<unsigned char*>(skey + P);
     if (tid < 2) scnt[tid] = 0;
@@ -308,8 +312,8 @@ __global__ __launch_bounds__(256) void sample_by_keys_kernel(const int64_t* __re
     __syncthreads();
     const int n_f = min(scnt[0], num_pos_max);
     const int n_b = min(scnt[1], num_samples - n_f);
-    if (tid == 0) { counts[2 * img] = n_f; counts[2 * img + 1] = n_b; }
-    for (int i = tid; i < P; i += 256) {
+    if (tid == 0 && part == 0) { counts[2 * img] = n_f; counts[2 * img + 1] = n_b; }
+    for (int i = part * 256 + tid; i < P; i += 256 * parts) {
         const unsigned char t = stype[i];
         if (t == 0) continue;
         const float k = skey[i];
@@ -583,7 +587,8 @@ int ptmi_sample_by_keys(const int64_t* cls_all, const float* keys_all, const int
     PTMI_CHECK_ARG(max_count >= 0 && max_count <= SAMPLE_MAXP, "sample_by_keys: %lld candidates per image exceed %d",
                    (long long)max_count, SAMPLE_MAXP);
     const int kf = num_pos_max > 0 ? num_pos_max : 1;
-    hipLaunchKernelGGL(sample_by_keys_kernel, dim3(nimg), dim3(256), (size_t)max_count * 5 + 16, (hipStream_t)s, cls_all,
+    const int parts = (int)std::min<int64_t>(16, std::max<int64_t>(1, (max_count + 255) / 256));
+    hipLaunchKernelGGL(sample_by_keys_kernel, dim3(nimg, parts), dim3(256), (size_t)max_count * 5 + 16, (hipStream_t)s, cls_all,
                        keys_all, offsets, num_samples, num_pos_max, bg_label, kf, num_samples, out_fg, out_bg, counts);
     PTMI_LAUNCH_CHECK("sample_by_keys");
     return 0;
