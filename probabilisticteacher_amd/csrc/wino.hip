@@ -103,7 +103,7 @@ __device__ __forceinline__ float wino_vop(const f32x2 (&V)[8], int p)
 __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi,
-    int coTiles, int tilesY, int nPix, int colocate)
+    int coTiles, int bands, int period, int nPix, int colocate)
 {
     __shared__ __attribute__((aligned(16))) float lds[3 * WSTAGE];
 
@@ -115,7 +115,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     //       channel tile's U slabs (2 MB at Cin = 512) in its L2 and each patch is fetched by all eight L2s;
     //   colocate = 1 (<= 4 channel tiles: all their U slabs fit one L2): the channel tiles of a pixel tile run back to back
     //       on ONE XCD (id mod 8 = pixel tile mod 8): the patch leaves HBM / MALL once instead of coTiles times.
-    // Pixel tiles are numbered (tile column, tile row, image) with the image fastest: the light right-edge column comes last.
+    // Pixel tiles are FLAT: every (image, 8-row band) is a strip of `period` columns (W rounded up to a multiple of 4 with at
+    // least one zero column: the strips' shared halo), the strips are concatenated, and workgroup `pix` owns tile columns
+    // 16 pix .. 16 pix + 15 of that line -- it may straddle strips (bands, images).  Padding is paid once per launch instead
+    // of once per row of workgroups: a 32-column grid cost 14 % of the MFMAs on W = 166 / 83 and 5 % on W = 333.
     int cot, pix;
     if (colocate) {
         const int slot = blockIdx.x >> 3;
@@ -126,14 +129,14 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         cot = blockIdx.x % coTiles;
         pix = blockIdx.x / coTiles;
     }
-    const int nyTotal = N * tilesY;
-    const int tx = pix / nyTotal, ny = pix - tx * nyTotal;
-    const int ty = ny / N, n = ny - ty * N;
-    const int x0 = tx * WTW, y0 = ty * WTH;
     const int HW = H * W;
-    const int wv = W - x0;                                   // valid columns right of x0 (> 0)
+    const int nStrips = N * bands;
+    const int u0 = pix * WTW;                                // flat column of the workgroup's first output column
+    const int s_first = u0 / period;                         // strip of the first tile column; its image is the address base
+    const int n = s_first / bands;
 
     // ---- DMA descriptors: this lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first plane
+    // of image n.  LDS column c of the patch <-> flat column u0 - 4 + c; periods are multiples of 4, so a piece lies in ONE strip.
     unsigned pvoff[WPI];
     int fix = 0;                                             // words 1..3 of piece i (bits 4i+1 .. 4i+3) beyond the image edge
 #pragma unroll
@@ -141,20 +144,32 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         const int pidx = tid + i * WNT;
         const int ci = pidx / (WPR * 12), rem = pidx - ci * (WPR * 12);
         const int r = rem / 12, q = rem - r * 12;
-        const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * q;
+        const int u = u0 - 4 + 4 * q;
+        const int st = u >= 0 ? u / period : -1;
+        const int gx = u - st * period;
+        const int sn = st / bands, gy = (st - sn * bands) * WTH - 1 + r;
         pvoff[i] = 0xFFFFFFFFu;
-        if (pidx < WPS / 4 && q < 10 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            pvoff[i] = (unsigned)(ci * HW + gy * W + gx) * 4u;
+        if (pidx < WPS / 4 && q < 10 && st >= 0 && st < nStrips && gy >= 0 && gy < H && gx < W) {
+            pvoff[i] = (unsigned)(((sn - n) * Cin + ci) * HW + gy * W + gx) * 4u;
 #pragma unroll
             for (int e = 1; e < 4; ++e) fix |= (gx + e >= W) ? (1 << (4 * i + e)) : 0;
         }
     }
     const unsigned wvoff = (unsigned)tid * 16u;
-    const bool edge = wv < 36;                               // some loaded piece may straddle the right image edge
+    // (workgroup-uniform, computed on the scalar unit -- a __syncthreads_or would add a second LDS object, after which the
+    // compiler no longer tells the DMA's LDS writes from the operand reads and puts a vmcnt(0) in front of every read: 2x slower)
+    bool edge = false;                                       // some loaded piece may straddle the right edge of an image row
+    if (W & 3) {
+        const int e0 = W & ~3;                               // strip-local first column of the straddling piece
+        for (int st = (u0 > 4 ? u0 - 4 : 0) / period; st < nStrips && st * period + e0 < u0 + 36; ++st)
+            edge |= st * period + e0 >= u0 - 4;
+    }
 
     const char* xc = (const char*)(x + (size_t)n * Cin * HW);
     const char* wc = (const char*)(wp + (size_t)cot * nChunks * WUS);
-    unsigned xleft = (unsigned)Cin * (unsigned)HW * 4u;      // bytes from xc to the end of image n (< 2^32: launcher)
+    // bytes from xc to the end of the tensor, clamped (offsets reach into the next image: (Cin + 8) HW 4 < 2^32, launcher)
+    const long long xtail = (long long)(N - n) * Cin * HW * 4;
+    unsigned xleft = (unsigned)(xtail > 0xFFFFFFFEll ? 0xFFFFFFFEll : xtail);
 
     // one DMA instruction of a chunk: idx 0 .. WPI-1 = patch pieces, WPI .. WPI+WUI-1 = U pieces
     auto dma_piece = [&](int idx, int buf) {
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     auto advance = [&]() {
         wc += WUS * 4;
         xc += (size_t)WKC * HW * 4;
-        xleft -= (unsigned)WKC * (unsigned)HW * 4u;
+        xleft = xleft == 0xFFFFFFFEu ? xleft : xleft - (unsigned)WKC * (unsigned)HW * 4u;
     };
     auto issue = [&](int buf) {
 #pragma unroll
@@ -196,7 +211,22 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const int wm = wave >> 1, wn = wave & 1;                 // channel half (32) / row half (4 rows = 2 tile rows) of the tile
     const int nl = lane & 31, kh = lane >> 5;
     const int ttx = nl & 15, tty = nl >> 4;                  // tile column / row inside the wave's 16 x 2 tiles
-    const bool active = y0 + 4 * wn < H;                     // (wave-uniform) some of the wave's rows lie inside the image
+    // the lane's tile: strip (image, band), first output pixel.  Evaluated here for `active` and AGAIN in the epilogue (from an
+    // opaque copy of u0: keeping five more values alive across the main loop spills, and with scratch in the kernel the
+    // compiler puts a vmcnt(0) in front of every LDS read that follows a DMA -- 2x slower)
+    auto tile_geometry = [&](int u0v, int& tsn_o, int& py_o, int& px_o) {
+        const int tu = u0v + 2 * ttx;
+        const int tst = tu / period;
+        tsn_o = tst / bands;
+        py_o = (tst - tsn_o * bands) * WTH + wn * 4 + tty * 2;
+        px_o = tu - tst * period;
+        return tst < nStrips && px_o < W && py_o < H;
+    };
+    bool active;
+    {
+        int a0, a1, a2;
+        active = __any(tile_geometry(u0, a0, a1, a2));        // (wave-uniform) some tile of the wave lies inside an image
+    }
     const int a_off = kh * (4 * WBM * 4) + (wm * 32 + nl) * 4;                               // + ks * 2048 + i * 256
     const int b_off = WUS + kh * WPL + (wn * 4 + tty * 2) * WPP + 2 * ttx + 3;              // + ks * 960 + a * 48 + 2 c   (odd: ds_read2_b32)
 
@@ -206,7 +236,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
 
     if (active) {
         f32x4 A0[4], A1[4];
-        f32x2 D0[8], D1[8];
+        f32x2 D0[8];                       // raw window of the NEXT k-step: read (slots 0-7) and transformed (12-15) within one k-step
         f32x2 V0[8], V1[8];
         f32x2 T[4][2];
         // One k-step = 16 MFMAs on (A, V), one per position, with the rest of the wave's work placed between them (one
@@ -301,9 +331,9 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         // copy of the loop with the fix-up writes in the hand-over; the common copy is branch-free.
         auto main_loop = [&](auto edge_c) {
             auto chunk_body = [&](auto more_c, auto more2_c, int cur, int nxt, int nn) {
-                kstep(std::integral_constant<int, 0>{}, more_c, more2_c, edge_c, A0, V0, A1, D1, V1, cur, nxt, nn);
+                kstep(std::integral_constant<int, 0>{}, more_c, more2_c, edge_c, A0, V0, A1, D0, V1, cur, nxt, nn);
                 kstep(std::integral_constant<int, 1>{}, more_c, more2_c, edge_c, A1, V1, A0, D0, V0, cur, nxt, nn);
-                kstep(std::integral_constant<int, 2>{}, more_c, more2_c, edge_c, A0, V0, A1, D1, V1, cur, nxt, nn);
+                kstep(std::integral_constant<int, 2>{}, more_c, more2_c, edge_c, A0, V0, A1, D0, V1, cur, nxt, nn);
                 kstep(std::integral_constant<int, 3>{}, more_c, more2_c, edge_c, A1, V1, A0, D0, V0, cur, nxt, nn);
             };
             int cur = 0, nxt = 1, nn = 2;
@@ -347,9 +377,16 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
 
     // ---- epilogue: Y = A^T M A per (channel, tile) in registers, then bias / ReLU / mask / pool and buffer stores.
     // Accumulator element r of a lane: channel (r & 3) + 8 (r >> 2) + 4 kh of the wave's 32, tile nl.
-    const int py = y0 + wn * 4 + tty * 2, px = x0 + ttx * 2;          // the tile's first output pixel
+    int tsn, py, px;
+    int u0e = u0;
+    asm volatile("" : "+s"(u0e));
+    const bool tile_ok = tile_geometry(u0e, tsn, py, px);
     const int half4 = 4 * kh;
     const int co_w = cot * WBM + wm * 32;                              // wave-uniform first channel
+    // channel row rr of this lane lies inside the tensor (the descriptors below reach to the END of the tensor -- a lane's tile
+    // may belong to a later image than the workgroup's first -- so the range check no longer drops channels >= Cout)
+    const int cmax = Cout - co_w - half4;
+    auto crow = [&](int rr) { return (rr & 3) + 8 * (rr >> 2) < cmax; };
     const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
     f32x4 bv[4];
 #pragma unroll
@@ -366,8 +403,11 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         f32x2 s0[4], s1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x2 m0 = {acc[j][r], acc[j][r + 1]}, m1 = {acc[4 + j][r], acc[4 + j][r + 1]};
-            const f32x2 m2 = {acc[8 + j][r], acc[8 + j][r + 1]}, m3 = {acc[12 + j][r], acc[12 + j][r + 1]};
+            // (explicit reads: an element extracted in C++ makes the compiler copy the WHOLE 16-register tile to VGPRs, all 16
+            // tiles up front -- 256 live VGPRs at the head of the epilogue, spills of the DMA offsets in the main loop)
+            auto rd = [](float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; };
+            const f32x2 m0 = {rd(acc[j][r]), rd(acc[j][r + 1])}, m1 = {rd(acc[4 + j][r]), rd(acc[4 + j][r + 1])};
+            const f32x2 m2 = {rd(acc[8 + j][r]), rd(acc[8 + j][r + 1])}, m3 = {rd(acc[12 + j][r]), rd(acc[12 + j][r + 1])};
             s0[j] = pk_add(pk_add(m0, m1), m2);
             s1[j] = pk_sub(pk_sub(m1, m2), m3);
         }
@@ -384,9 +424,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     if (epi == 4) {
         // bias + ReLU + 2x2/2 max pool (floor mode): the tile's four outputs are one pool window
         const int OH = H >> 1, OW = W >> 1, OHW = OH * OW;
-        const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)Cout * (unsigned)OHW * 4u);
+        const long long ytail = (long long)(N - n) * Cout * OHW * 4;
+        const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail));
         const int oy = py >> 1, ox = px >> 1;
-        const unsigned pv = (oy < OH && ox < OW) ? (unsigned)(half4 * OHW + oy * OW + ox) * 4u : 0xFFFFFFFFu;
+        const unsigned pv = (tile_ok && oy < OH && ox < OW) ? (unsigned)(((tsn - n) * Cout + half4) * OHW + oy * OW + ox) * 4u : 0xFFFFFFFFu;
         for_row_pairs([&](auto rp_c) {
             constexpr int r = 2 * decltype(rp_c)::value;
             f32x2 o[4];
@@ -396,12 +437,14 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
                 const int soff = (co_w + ((r + h) & 3) + 8 * ((r + h) >> 2)) * OHW * 4;
                 const float b = bv[(r + h) >> 2][(r + h) & 3];
                 const float m = fmaxf(fmaxf(fmaxf(o[0][h] + b, o[1][h] + b), fmaxf(o[2][h] + b, o[3][h] + b)), 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ry, (int)pv, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m), ry, crow(r + h) ? (int)pv : -1, soff, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         });
         return;
     }
-    const unsigned img_bytes = (unsigned)Cout * (unsigned)HW * 4u;
+    const long long ytail = (long long)(N - n) * Cout * HW * 4;
+    const unsigned img_bytes = (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail);     // to the end of the tensor, clamped
     const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * HW, img_bytes);
     const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(epi == 3 ? mref + (size_t)n * Cout * HW : y, epi == 3 ? img_bytes : 0u);
     // per-lane byte offsets of the tile's two rows: pair = both columns inside the image (8-byte access), single = only
@@ -409,12 +452,12 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     unsigned pv2[2], pv1[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        const bool rok = py + a < H;
-        const unsigned o = (unsigned)(half4 * HW + (py + a) * W + px) * 4u;
+        const bool rok = tile_ok && py + a < H;
+        const unsigned o = (unsigned)(((tsn - n) * Cout + half4) * HW + (py + a) * W + px) * 4u;
         pv2[a] = (rok && px + 1 < W) ? o : 0xFFFFFFFFu;
         pv1[a] = (rok && px + 1 == W) ? o : 0xFFFFFFFFu;
     }
-    const bool odd_edge = (W & 1) && x0 + WTW > W;                     // (workgroup-uniform) a lane may hold a single column
+    const bool odd_edge = (W & 1) && __any(pv1[0] != 0xFFFFFFFFu);    // (wave-uniform) a lane holds a single column
     auto store_rows = [&](auto epi_c) {
         constexpr int EPI = decltype(epi_c)::value;
         for_row_pairs([&](auto rp_c) {
@@ -427,8 +470,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
                     const int soff = (co_w + ((r + h) & 3) + 8 * ((r + h) >> 2)) * HW * 4;
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
-                        mk[h][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)pv2[a], soff, 0));
-                        if (odd_edge) ms[h][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, (int)pv1[a], soff, 0));
+                        mk[h][a] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, crow(r + h) ? (int)pv2[a] : -1, soff, 0));
+                        if (odd_edge) ms[h][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, crow(r + h) ? (int)pv1[a] : -1, soff, 0));
                     }
                 }
             }
@@ -455,10 +498,11 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
                         v1 = (mk[h][a][1] > 0.f) ? v1 : 0.f;
                     }
                     const f32x2 st = {v0, v1};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, st), ry, (int)pv2[a], soff, 0);
-                    if (odd_edge) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, (int)pv1[a], soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, st), ry, crow(r + h) ? (int)pv2[a] : -1, soff, 0);
+                    if (odd_edge) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ry, crow(r + h) ? (int)pv1[a] : -1, soff, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);          // one row pair at a time: hoisted accumulator reads of later pairs spill
         });
     };
     if (epi == 0) store_rows(std::integral_constant<int, 0>{});
@@ -925,20 +969,23 @@ int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, co
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino_fwd: bad args");
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_wino_fwd: bad epilogue %d", epilogue);
-    PTMI_CHECK_ARG((int64_t)(cin + WKC) * h * w * 4 < (1ll << 32) && ((int64_t)cout + WBM) * h * w * 4 < (1ll << 32) &&
-                   (int64_t)n * cdiv(h, WTH) < 65536 && cdiv(w, WTW) < 65536,
+    // a workgroup's 32 flat columns may reach into the strips of later images: per-lane offsets are relative to the first one
+    const int64_t img_span = 32 / ((w + 4) & ~3) + 2;
+    PTMI_CHECK_ARG((img_span * cin + WKC) * h * w * 4 < (1ll << 32) && (img_span * cout + WBM) * h * w * 4 < (1ll << 32),
                    "conv3x3_wino_fwd: image too large for 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d)", n, cin,
                    cout, h, w);
     PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_wino_fwd: bias required for epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue != 4 || bias, "conv3x3_wino_fwd: bias required for epilogue 4");
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_wino_fwd: mask_ref required for epilogue 3");
-    const int tilesX = cdiv(w, WTW), tilesY = cdiv(h, WTH), coTiles = cdiv(cout, WBM), nChunks = cdiv(cin, WKC);
-    const int64_t nPix = (int64_t)n * tilesY * tilesX;
+    const int bands = cdiv(h, WTH), coTiles = cdiv(cout, WBM), nChunks = cdiv(cin, WKC);
+    const int period = (w + 1 + 3) & ~3;                     // strip length: W + at least one zero column, a multiple of 4
+    const int64_t nPix = cdiv64((int64_t)n * bands * period, WTW);
+    PTMI_CHECK_ARG(nPix * WTW < (1ll << 31), "conv3x3_wino_fwd: too many tiles");
     const int colocate = WINO_COLOCATE_MAX_COTILES >= coTiles;
     const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;
     PTMI_CHECK_ARG(nWg < (1ll << 31), "conv3x3_wino_fwd: too many tiles");
     hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)nWg), dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n, cin,
-                       cout, h, w, nChunks, epilogue, coTiles, tilesY, (int)nPix, colocate);
+                       cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate);
     PTMI_LAUNCH_CHECK("conv3x3_wino_fwd");
     return 0;
 }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import functools
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -198,13 +199,25 @@ def set_conv_algo(mode: str) -> None:
     _CONV_ALGO = mode
 
 
+@functools.lru_cache(maxsize=256)
 def wino_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
     """FLOPs of the v_mfma_f32_32x32x2_f32 instructions one ptmi_conv3x3_wino_fwd launch issues: a wave runs 16 MFMAs
-    (4096 FLOP each) per 2-channel k-step for its 32 channels x 32 tiles (= 4 rows x 32 columns of pixels); waves whose rows
-    lie wholly below the image issue none.  (Checked against SQ_INSTS_VALU_MFMA_MOPS_F32, profiles/r03_*.)"""
-    co_tiles, tiles_x, chunks = -(-cout // 64), -(-w // 32), -(-cin // 8)
-    waves = n * co_tiles * tiles_x * (-(-h // 4)) * 2
-    return float(waves) * chunks * 4 * 16 * 4096
+    (4096 FLOP each) per 2-channel k-step for its 32 channels x 32 tiles (2 tile rows x 16 tile columns of the FLAT tile line:
+    every (image, 8-row band) is a strip of `period` columns, csrc/wino.hip); waves none of whose tiles lies inside an image
+    issue none.  (Checked against SQ_INSTS_VALU_MFMA_MOPS_F32, profiles/r03_*.)"""
+    import numpy as np
+    co_tiles, chunks, bands = -(-cout // 64), -(-cin // 8), -(-h // 8)
+    period = (w + 4) & ~3
+    n_strips = n * bands
+    n_pix = -(-(n_strips * period) // 32)
+    tu = (np.arange(n_pix, dtype=np.int64)[:, None] * 32 + 2 * np.arange(16, dtype=np.int64)[None, :])
+    st, px = tu // period, tu % period
+    col_ok = (st < n_strips) & (px < w)
+    band = st % bands
+    waves = 0
+    for wn in (0, 1):
+        waves += int((col_ok & (band * 8 + 4 * wn < h)).any(axis=1).sum())
+    return float(waves) * 2 * co_tiles * chunks * 4 * 16 * 4096
 
 
 def wino_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
