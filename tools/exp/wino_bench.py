@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--trace", action="store_true", help="libs built with -DWINO_TRACE: print the k-step timestamps of one wave")
     ap.add_argument("--slots", action="store_true", help="libs built from wino_v5s.hip: slot-level stamps of KS1 / KS3")
     ap.add_argument("--coarse", action="store_true", help="libs built from wino_v5c.hip: entry / loop / epilogue stamps")
+    ap.add_argument("--stream", action="store_true", help="libs built with -DWINO_TRACE from the streaming kernel: per-tile loop / epilogue stamps")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     vp = ctypes.c_void_p
@@ -39,11 +40,11 @@ def main():
             st = vp(torch.cuda.current_stream().cuda_stream)
             lib.ptmi_conv3x3_wino_pack_weights(vp(wt.data_ptr()), vp(wp.data_ptr()), cout, cin, 0, st)
 
-            tr = torch.zeros(4096, dtype=torch.int64, device="cuda:0") if (a.trace or a.slots or a.coarse) else None
+            tr = torch.zeros(4096, dtype=torch.int64, device="cuda:0") if (a.trace or a.slots or a.coarse or a.stream) else None
 
             def f():
                 rc = lib.ptmi_conv3x3_wino_fwd(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()),
-                                               vp(tr.data_ptr()) if (a.trace or a.slots or a.coarse) else None, vp(y.data_ptr()),
+                                               vp(tr.data_ptr()) if (a.trace or a.slots or a.coarse or a.stream) else None, vp(y.data_ptr()),
                                                a.n, cin, cout, h, w, 1, st)
                 assert rc == 0
             f()
@@ -55,6 +56,11 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
+            if a.stream:
+                t = tr.cpu().tolist()
+                for w in range(4):
+                    v = t[w * 8: w * 8 + 4]
+                    print(f"wave {w}: tile main loop {v[0]-v[3]}  epilogue issue {v[1]-v[0]}  store drain {v[2]-v[1]}")
             if a.coarse:
                 t = tr.cpu().tolist()
                 for g in range(2):
