@@ -132,6 +132,11 @@ int ptmi_gemm_bf16(const float* a, const float* b, float* c, const float* bias, 
                    int64_t stride_c, float* ws, int64_t ws_floats, ptmi_stream_t s);
 /* column sums: out[j] (+)= sum_i a[i][j]  (bias gradients), a is (rows, cols) row-major. */
 int ptmi_colsum(const float* a, float* out, int rows, int cols, int accumulate, ptmi_stream_t s);
+/* the same for tall matrices (rows >> cols: the 1x1 RPN heads' bias gradients, rpn.py:96 backward): row ranges are summed by
+ * separate workgroups into ws (ptmi_colsum_ws_floats(rows, cols) floats; 0 = not worth splitting), then reduced in a fixed
+ * order.  ws == NULL falls back to ptmi_colsum. */
+int64_t ptmi_colsum_ws_floats(int rows, int cols);
+int ptmi_colsum_ws(const float* a, float* out, float* ws, int rows, int cols, int accumulate, ptmi_stream_t s);
 /* row sums over the inner dim: out[i] (+)= sum_j a[i][j] for each of `batch` slabs summed. */
 int ptmi_rowsum_batched(const float* a, float* out, int batch, int rows, int cols, int accumulate,
                         ptmi_stream_t s);

@@ -41,6 +41,8 @@ SIGNATURES = {
     "ptmi_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _vp, _i64, _vp]),
     "ptmi_gemm_ws_floats": (_i64, [_i, _i, _i, _i]),
     "ptmi_colsum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ptmi_colsum_ws_floats": (_i64, [_i, _i]),
+    "ptmi_colsum_ws": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ptmi_rowsum_batched": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ptmi_roi_align_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ptmi_roi_align_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),

@@ -344,6 +344,45 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
     }
 }
 
+// tall matrices (bias gradients of the 1x1 RPN heads: 200 000 rows x 15 / 60 columns): S row ranges -> partial[S][cols],
+// then colsum_kernel over the partials (fixed order: deterministic).  One workgroup per 16 columns took ~1 ms per call.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, float* __restrict__ partial,
+                                                              int rows, int cols, int per)
+{
+    __shared__ float sm[16][17];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const int r0 = blockIdx.y * per, r1 = min(r0 + per, rows);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    if (c < cols) {
+        int r = r0 + part;
+        for (; r + 48 < r1; r += 64) {
+            acc0 += a[(size_t)r * cols + c];
+            acc1 += a[(size_t)(r + 16) * cols + c];
+            acc2 += a[(size_t)(r + 32) * cols + c];
+            acc3 += a[(size_t)(r + 48) * cols + c];
+        }
+        for (; r < r1; r += 16) acc0 += a[(size_t)r * cols + c];
+    }
+    sm[part][cl] = (acc0 + acc1) + (acc2 + acc3);
+    __syncthreads();
+    if (part == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += sm[p][cl];
+        partial[(size_t)blockIdx.y * cols + c] = t;
+    }
+}
+
+static int colsum_splits(int rows, int cols)
+{
+    const int groups = cdiv(cols, 16);
+    if (groups >= 128 || rows < 4096) return 1;
+    int s = cdiv(512, groups);
+    if (s > cdiv(rows, 1024)) s = cdiv(rows, 1024);
+    return s < 1 ? 1 : s;
+}
+
 __global__ __launch_bounds__(256) void rowsum_batched_kernel(const float* __restrict__ a, float* __restrict__ out,
                                                              int batch, int rows, int cols, int accumulate)
 {
@@ -439,6 +478,23 @@ int ptmi_colsum(const float* a, float* out, int rows, int cols, int accumulate, 
                        accumulate);
     PTMI_LAUNCH_CHECK("colsum");
     return 0;
+}
+
+int64_t ptmi_colsum_ws_floats(int rows, int cols)
+{
+    const int S = colsum_splits(rows, cols);
+    return S > 1 ? (int64_t)S * cols : 0;
+}
+
+int ptmi_colsum_ws(const float* a, float* out, float* ws, int rows, int cols, int accumulate, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(a && out && rows >= 0 && cols > 0, "colsum_ws: bad args");
+    const int S = colsum_splits(rows, cols);
+    if (S <= 1 || !ws) return ptmi_colsum(a, out, rows, cols, accumulate, s);
+    const int per = cdiv(rows, S);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 16), S), dim3(256), 0, (hipStream_t)s, a, ws, rows, cols, per);
+    PTMI_LAUNCH_CHECK("colsum_partial");
+    return ptmi_colsum(ws, out, S, cols, accumulate, s);
 }
 
 int ptmi_rowsum_batched(const float* a, float* out, int batch, int rows, int cols, int accumulate,

@@ -455,7 +455,9 @@ def colsum(a: torch.Tensor) -> torch.Tensor:
     out = torch.empty(cols, dtype=F32, device=a.device)
     if rows == 0:
         return out.zero_()
-    _lib.call("ptmi_colsum", _ptr(a), _ptr(out), rows, cols, 0, _stream())
+    nws = _lib.load().ptmi_colsum_ws_floats(rows, cols)                     # > 0: tall matrix, summed by row ranges
+    ws = _ws("colsum", nws * 4, a.device) if nws else None
+    _lib.call("ptmi_colsum_ws", _ptr(a), _ptr(out), _ptr(ws), rows, cols, 0, _stream())
     return out
 
 

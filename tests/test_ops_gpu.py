@@ -189,6 +189,31 @@ def test_gemm_split_k(ops, ta, tb, m, n, k):
     close(out, plain, 1e-5, 2e-4 * math.sqrt(k / 1000.0), "split vs unsplit (summation order differs)")
 
 
+@pytest.mark.parametrize("rows,cols", [(199200, 15), (199200, 60), (5000, 7), (4095, 60), (70000, 1024), (3, 5), (0, 4)])
+def test_colsum_tall_and_plain(ops, rows, cols):
+    """ptmi_colsum_ws: tall matrices (the RPN 1x1 heads' bias gradients) are summed by row ranges and reduced in a fixed
+    order; short / wide ones take the one-kernel path.  fp64 reference, bitwise reproducible, accumulate honoured."""
+    from probabilisticteacher_amd import _lib
+    gen = g(rows + cols)
+    a = torch.randn(rows, cols, generator=gen)
+    ref = a.double().sum(0)
+    ad = a.to(DEV)
+    out = ops.colsum(ad)
+    close(out, ref.float(), 1e-5, 1e-5 * math.sqrt(max(rows, 1)), "colsum")
+    assert torch.equal(out, ops.colsum(ad))
+    nws = _lib.load().ptmi_colsum_ws_floats(rows, cols)
+    assert (nws > 0) == (rows >= 4096 and cols < 2048)
+    if rows:
+        call, _p, _stream = _raw()
+        acc = torch.ones(cols, device=DEV)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        call("ptmi_colsum_ws", _p(ad), _p(acc), _p(ws), rows, cols, 1, _stream())
+        close(acc, (ref + 1).float(), 1e-5, 1e-5 * math.sqrt(rows), "colsum accumulate")
+        plain = torch.empty(cols, device=DEV)
+        call("ptmi_colsum_ws", _p(ad), _p(plain), None, rows, cols, 0, _stream())          # no workspace: one-kernel path
+        close(plain, ref.float(), 1e-5, 1e-5 * math.sqrt(rows), "colsum without workspace")
+
+
 @pytest.mark.parametrize("m,n,k,batch", [(130, 200, 96, 1), (257, 72, 512, 3), (9, 130, 4099, 1), (200, 300, 5000, 1)])
 def test_gemm_never_writes_outside_its_output(ops, m, n, k, batch):
     """Memory-safety canary for the buffer-store epilogue: the kernel advances rows through the store's scalar offset and
