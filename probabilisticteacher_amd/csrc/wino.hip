@@ -1,5 +1,6 @@
 // wino.hip -- fused Winograd F(2x2, 3x3) convolution for gfx950 (CDNA4): 3x3 s1 p1, fp32 in / fp32 accumulate on
-// v_mfma_f32_32x32x2_f32, forward and dgrad of the 64..512-channel layers.
+// v_mfma_f32_32x32x2_f32: forward and dgrad (conv3x3_wino_kernel) and the weight gradient (conv3x3_wino_wgrad_kernel, second
+// half of the file) of the 32..512-channel layers.
 //
 // Replaces the cuDNN conv2d (+bias, +ReLU) the reference reaches at pt/modeling/backbone/vgg.py:45-53,66-69 (conv1_2 ..
 // conv5_3) and the 3x3 conv of D2's StandardRPNHead (pt/modeling/proposal_generator/rpn.py:96) -- cuDNN itself runs these
@@ -10,23 +11,27 @@
 //   * transform domain: for each of the 16 positions p = (i, j) of the 4x4 tile, M_p[co][tile] = sum_ci U_p[co][ci] V_p[ci][tile]
 //     with U = G g G^T (packed once per call by wino_pack_weights_kernel), V = B^T d B (computed per lane from LDS) and
 //     Y = A^T M A (epilogue, in registers);
-//   * a workgroup = 4 wave64s owns 64 output channels x (8 rows x 32 columns) of one image = 64 tiles; a wave owns
+//   * a workgroup = 4 wave64s owns 64 output channels x (8 rows x 32 columns) = 64 tiles of the FLAT tile line (every (image,
+//     8-row band) is a strip of `period` columns; the strips are concatenated; a workgroup may straddle strips); a wave owns
 //     32 channels x 32 tiles (16 tile columns x 2 tile rows) x 16 positions = sixteen 32x32 accumulator tiles = 256
-//     accumulator registers: ONE wave per SIMD, the whole unified register file of it (512 per lane);
+//     accumulator registers: ONE wave per SIMD, the whole accumulator file of it;
 //   * v_mfma_f32_32x32x2_f32 takes A[co = lane & 31][k = lane >> 5] and B[k = lane >> 5][tile = lane & 31]: a lane IS one
-//     (tile, channel) pair, so it reads its own 4x4 input window from the LDS patch (twelve 8-byte reads), applies B^T d B
-//     with 32 additions and holds the B operands of all 16 positions' MFMAs -- no cross-lane movement, no transform-domain
-//     tensor anywhere.  The A operands of the 16 positions are 64 contiguous bytes per (channel, ci) in the packed slab
-//     (four ds_read_b128);
-//   * K is walked in 8-channel chunks (four k-steps of 2 channels = 64 MFMAs = 4096 matrix-pipe cycles per wave and chunk),
-//     double buffered in LDS, operands arrive with `buffer_load_dwordx4 ... lds` (per-lane offsets are loop invariants;
+//     (tile, channel) pair, so it reads its own 4x4 input window from the LDS patch (eight 4-byte-aligned pairs: ds_read2_b32),
+//     applies B^T d B with 16 packed additions and holds the B operands of all 16 positions' MFMAs -- no cross-lane movement,
+//     no transform-domain tensor anywhere.  The A operands of the 16 positions are 64 contiguous bytes per (channel, ci) in
+//     the packed slab (four ds_read_b128);
+//   * K is walked in 8-channel chunks (four k-steps of 2 channels = 64 MFMAs = 4096 matrix-pipe cycles per wave and chunk)
+//     through THREE LDS stages; operands arrive with `buffer_load_dwordx4 ... lds` (per-lane offsets are loop invariants;
 //     halo rows / columns and padded channels carry offset 0xFFFFFFFF and are zero-filled by the buffer range check), ONE
-//     workgroup barrier per chunk, placed inside the last k-step's MFMA stream whose operands are already in registers;
+//     workgroup barrier per chunk behind a counted vmcnt, placed inside the last k-step's MFMA stream whose operands are
+//     already in registers;
 //   * the next k-step's LDS reads and input transform are issued between the current k-step's MFMAs (software pipeline in
-//     source order, pinned with sched_barrier): with one wave per SIMD nothing else hides them;
+//     source order, pinned with sched_barrier): with one wave per SIMD nothing else hides them -- and VALU time adds to fp32
+//     MFMA time, so every instruction in the loop is paid for;
 //   * epilogue: inverse transform in registers (the 16 positions of a (channel, tile) pair live in the same lane and register
-//     index of the 16 accumulator tiles), then the epilogues of conv.hip: bias / bias+ReLU / none / ReLU mask of the
-//     producer (dgrad) / bias+ReLU+2x2 max pool (a Winograd tile IS a pool window).
+//     index of the 16 accumulator tiles; explicit v_accvgpr_read, two channel rows per packed addition), then the epilogues of
+//     conv.hip: bias / bias+ReLU / none / ReLU mask of the producer (dgrad) / bias+ReLU+2x2 max pool (a Winograd tile IS a
+//     pool window).
 // dgrad = the same kernel on dY with the flipped / transposed filter (pack mode 1), as in conv.hip.
 
 #include "common.h"
@@ -46,8 +51,8 @@ typedef __attribute__((address_space(3))) void wlds_void_t;
 
 constexpr int WKC = 8;                 // input channels per chunk
 constexpr int WBM = 64;                // output channels per workgroup
-constexpr int WTH = 8, WTW = 32;       // output pixels per workgroup: 8 rows x 32 columns = 4 x 16 Winograd tiles
-constexpr int WPP = 48;                // patch row pitch in floats: 10 loaded 16-B pieces (image columns x0-4 .. x0+35) + 2 pad
+constexpr int WTH = 8, WTW = 32;       // output pixels per workgroup: 8 rows x 32 (flat) columns = 4 x 16 Winograd tiles
+constexpr int WPP = 48;                // patch row pitch in floats: 10 loaded 16-B pieces (flat columns u0-4 .. u0+35) + 2 pad
                                        // pieces; 2 rows = 96 floats = 32 banks (mod 64): the two tile rows of a wave read
                                        // disjoint bank halves with ds_read_b64
 constexpr int WPR = WTH + 2;           // patch rows (image rows y0-1 .. y0+8)
