@@ -190,10 +190,23 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
                                                      (int)wvoff, i * WNT * 16, 0, 0);
         }
     };
+    // Cin not a multiple of 8: the last chunk's channels >= Cin are the NEXT image's first planes (the descriptor reaches to the
+    // end of the tensor) -- their weights are packed as zeros, but 0 x Inf is not 0: those pieces are switched off for the last chunk
+    int chunks_left = nChunks;                               // chunks not yet issued
+    auto mask_ragged_channels = [&]() {
+        if ((Cin & (WKC - 1)) && chunks_left == 1) {
+#pragma unroll
+            for (int i = 0; i < WPI; ++i)
+                if ((tid + i * WNT) / (WPR * 12) >= (Cin & (WKC - 1))) pvoff[i] = 0xFFFFFFFFu;
+        }
+    };
+    mask_ragged_channels();
     auto advance = [&]() {
         wc += WUS * 4;
         xc += (size_t)WKC * HW * 4;
         xleft = xleft == 0xFFFFFFFEu ? xleft : xleft - (unsigned)WKC * (unsigned)HW * 4u;
+        --chunks_left;
+        mask_ragged_channels();
     };
     auto issue = [&](int buf) {
 #pragma unroll

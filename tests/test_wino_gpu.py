@@ -91,6 +91,24 @@ def test_wino_dgrad_with_relu_mask(n, cin, cout, h, w):
     close(got3, xr.grad * (mask_src > 0), 1e-4, 2e-4, "dgrad + relu mask")
 
 
+def test_wino_ragged_channels_do_not_read_the_next_image():
+    """Cin not a multiple of the 8-channel chunk: the last chunk's padding channels must be zeros, not the next image's first
+    planes (whose packed weights are zero -- but 0 x NaN is NaN).  Image 1 is all NaN; image 0's output must be unaffected."""
+    gen = g(99)
+    x = torch.randn(2, 20, 9, 35, generator=gen)
+    wt = torch.randn(70, 20, 3, 3, generator=gen) * 0.1
+    b = torch.randn(70, generator=gen) * 0.1
+    ref = F.relu(F.conv2d(x[:1], wt, b, padding=1))
+    x[1] = float("nan")
+    got = _wino(x.to(DEV), wt.to(DEV), b.to(DEV), None, 1)
+    close(got[:1], ref, 1e-4, 1e-4, "image 0 next to a NaN image")
+    # (image 1 itself: the fused ReLU is v_max_f32, which returns 0 for NaN where torch.relu propagates it -- non-finite
+    # activations are outside the parity domain; the heads' outputs pass through no ReLU and the step aborts on them as the
+    # reference does)
+    got2 = _wino(x.to(DEV), wt.to(DEV), b.to(DEV), None, 0)
+    assert torch.isnan(got2[1]).all() and torch.isfinite(got2[0]).all()
+
+
 def test_wino_equals_direct_kernel_closely():
     """Same inputs through both algorithms (ops.set_conv_algo): forward, dgrad and the fused block agree to fp32 rounding."""
     from probabilisticteacher_amd import ops
