@@ -211,3 +211,25 @@ def test_wino_wgrad_layer_shape_vs_direct_kernel():
     scale = float(dw_d.abs().max())
     close(dw, dw_d, 1e-4, 1e-4 * scale, "dW wino vs direct")
     close(db, db_d, 1e-4, 1e-4 * float(db_d.abs().max()), "db")
+
+
+def test_training_step_runs_on_the_winograd_kernels():
+    """Routing guard: one fp32 VGG block forward + backward through the production autograd nodes launches the Winograd forward /
+    dgrad and weight-gradient kernels (and no direct conv kernel), and their issued-FLOP models are the ones the bench reports."""
+    from probabilisticteacher_amd import ops
+    gen = g(21)
+    x = torch.randn(2, 64, 40, 83, generator=gen).to(DEV).requires_grad_()
+    w1 = (torch.randn(128, 64, 3, 3, generator=gen) * 0.05).to(DEV).requires_grad_()
+    b1 = torch.zeros(128, device=DEV, requires_grad=True)
+    w2 = (torch.randn(128, 128, 3, 3, generator=gen) * 0.05).to(DEV).requires_grad_()
+    b2 = torch.zeros(128, device=DEV, requires_grad=True)
+    ops.profile_start()
+    y = ops.conv3x3(ops.conv3x3(x, w1, b1, True), w2, b2, True)
+    y.sum().backward()
+    prof = ops.profile_stop()
+    assert prof["conv3x3_wino"]["calls"] == 4 and prof["conv3x3_wino_wgrad"]["calls"] == 2, prof.keys()
+    assert "conv3x3_mfma" not in prof and "conv3x3_wgrad" not in prof
+    assert prof["conv3x3_wino"]["issued"] == 2 * ops.wino_issued_flops(2, 64, 128, 40, 83) + 2 * ops.wino_issued_flops(2, 128, 128, 40, 83)
+    assert prof["conv3x3_wino_wgrad"]["issued"] == ops.wino_wgrad_issued_flops(2, 64, 128, 40, 83) + ops.wino_wgrad_issued_flops(2, 128, 128, 40, 83)
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x.detach().cpu(), w1.detach().cpu(), None, padding=1)), w2.detach().cpu(), None, padding=1))
+    close(y, ref, 1e-4, 1e-4, "two-layer block")
