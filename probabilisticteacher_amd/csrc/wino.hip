@@ -248,6 +248,21 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const int a_off = kh * (4 * WBM * 4) + (wm * 32 + nl) * 4;                               // + ks * 2048 + i * 256
     const int b_off = WUS + kh * WPL + (wn * 4 + tty * 2) * WPP + 2 * ttx + 3;              // + ks * 960 + a * 48 + 2 c   (odd: ds_read2_b32)
 
+    // the lane's 16 biases, fetched BEFORE the first DMA (in-order vmcnt: they have landed long before anything the loop waits
+    // for): loaded at the head of the epilogue their latency was exposed once per workgroup -- 2.7 k cycles, 4 % at Cin = 64
+    const int half4 = 4 * kh;
+    const int co_w = cot * WBM + wm * 32;                    // wave-uniform first channel
+    f32x4 bv[4];
+    {
+        const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bv[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (epi <= 1 || epi == 4)
+                bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, half4 * 4, (co_w + g * 8) * 4, 0));
+        }
+    }
+
     f32x16 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
@@ -399,20 +414,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     int u0e = u0;
     asm volatile("" : "+s"(u0e));
     const bool tile_ok = tile_geometry(u0e, tsn, py, px);
-    const int half4 = 4 * kh;
-    const int co_w = cot * WBM + wm * 32;                              // wave-uniform first channel
     // channel row rr of this lane lies inside the tensor (the descriptors below reach to the END of the tensor -- a lane's tile
     // may belong to a later image than the workgroup's first -- so the range check no longer drops channels >= Cout)
     const int cmax = Cout - co_w - half4;
     auto crow = [&](int rr) { return (rr & 3) + 8 * (rr >> 2) < cmax; };
-    const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
-    f32x4 bv[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        bv[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (epi <= 1 || epi == 4)
-            bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, half4 * 4, (co_w + g * 8) * 4, 0));
-    }
     // Two accumulator rows (channels r, r + 1: adjacent registers of every position tile) at a time on packed additions, all
     // opaque to the optimiser (left to itself the compiler spends ~1 270 instructions per lane here -- 590 accumulator reads for
     // 256 values, 250 register moves around its own packed operations -- and the epilogue is 5-20 % of the kernel).
