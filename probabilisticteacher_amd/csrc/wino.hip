@@ -263,9 +263,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         }
     }
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) acc[p] = (f32x16){0};
+    f32x16 acc[16];                        // defined by the first k-step's MFMAs (zero C operand)
 
     if (active) {
         f32x4 A0[4], A1[4];
@@ -283,12 +281,13 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         //              rows each: 4 packed additions) -- 16 VALU instructions per k-step: VALU time ADDS to fp32 MFMA time
         // (s_memtime probes, tools/exp: with the hand-over's reads still in flight, the edge fix-up branches in the main
         // body and two LDS stages the chunk's last k-step took 1.8k cycles against 1.1-1.2k for the others.)
-        auto kstep = [&](auto ks_c, auto more_c, auto more2_c, auto edge_c, const f32x4 (&A)[4], const f32x2 (&V)[8],
+        auto kstep = [&](auto ks_c, auto more_c, auto more2_c, auto edge_c, auto zc_c, const f32x4 (&A)[4], const f32x2 (&V)[8],
                          f32x4 (&An)[4], f32x2 (&Dn)[8], f32x2 (&Vn)[8], int cur, int nxt, int nn) {
             constexpr int KS = decltype(ks_c)::value;
             constexpr bool more = decltype(more_c)::value;        // a chunk follows this one
             constexpr bool more2 = decltype(more2_c)::value;      // ... and another one after it (its DMA is issued here)
             constexpr bool EDGE = decltype(edge_c)::value;        // right-edge workgroup: DMA pieces may need fix-ups
+            constexpr bool ZC = decltype(zc_c)::value;            // a tile's very first k-step: zero C operand instead of 256 accumulator writes
             constexpr bool next = KS < 3 || more;
             const float* src = lds + (KS < 3 ? cur : nxt) * WSTAGE;
             const float* ap = src + a_off + ((KS + 1) & 3) * (2 * 4 * WBM * 4);
@@ -301,7 +300,8 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
             auto dread = [&](int e) { Dn[e] = *(const volatile wlds_f32x2_a4_t*)(bp + (e >> 1) * WPP + 2 * (e & 1)); };
             auto step = [&](auto p_c) {
                 constexpr int P = decltype(p_c)::value;
-                acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], wino_vop(V, P), acc[P], 0, 0, 0);
+                if constexpr (ZC) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], wino_vop(V, P), (f32x16){0}, 0, 0, 0);
+                else acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[P >> 2][P & 3], wino_vop(V, P), acc[P], 0, 0, 0);
                 if constexpr (P == 0 && KS == 3 && more) {
                     // chunk + 1 was issued a whole chunk ago; the WPI + WUI DMA instructions of chunk + 2 are newer
                     if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPI + WUI) : "memory");
@@ -363,22 +363,34 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         // the hand-over that waits for it.  Right-edge workgroups (some 16-B piece straddles the image edge) run their own
         // copy of the loop with the fix-up writes in the hand-over; the common copy is branch-free.
         auto main_loop = [&](auto edge_c) {
-            auto chunk_body = [&](auto more_c, auto more2_c, int cur, int nxt, int nn) {
-                kstep(std::integral_constant<int, 0>{}, more_c, more2_c, edge_c, A0, V0, A1, D0, V1, cur, nxt, nn);
-                kstep(std::integral_constant<int, 1>{}, more_c, more2_c, edge_c, A1, V1, A0, D0, V0, cur, nxt, nn);
-                kstep(std::integral_constant<int, 2>{}, more_c, more2_c, edge_c, A0, V0, A1, D0, V1, cur, nxt, nn);
-                kstep(std::integral_constant<int, 3>{}, more_c, more2_c, edge_c, A1, V1, A0, D0, V0, cur, nxt, nn);
+            auto chunk_body = [&](auto more_c, auto more2_c, auto zc_c, int cur, int nxt, int nn) {
+                kstep(std::integral_constant<int, 0>{}, more_c, more2_c, edge_c, zc_c, A0, V0, A1, D0, V1, cur, nxt, nn);
+                kstep(std::integral_constant<int, 1>{}, more_c, more2_c, edge_c, std::false_type{}, A1, V1, A0, D0, V0, cur, nxt, nn);
+                kstep(std::integral_constant<int, 2>{}, more_c, more2_c, edge_c, std::false_type{}, A0, V0, A1, D0, V1, cur, nxt, nn);
+                kstep(std::integral_constant<int, 3>{}, more_c, more2_c, edge_c, std::false_type{}, A1, V1, A0, D0, V0, cur, nxt, nn);
             };
+            const std::true_type T{};
+            const std::false_type F{};
             int cur = 0, nxt = 1, nn = 2;
-            for (int chunk = 0; chunk + 2 < nChunks; ++chunk) {
-                chunk_body(std::true_type{}, std::true_type{}, cur, nxt, nn);
-                const int t = cur; cur = nxt; nxt = nn; nn = t;
-            }
-            if (nChunks > 1) {
-                chunk_body(std::true_type{}, std::false_type{}, cur, nxt, nn);
+            auto rotate = [&]() { const int t = cur; cur = nxt; nxt = nn; nn = t; };
+            // the first chunk's first k-step defines the accumulators (zero C operand)
+            if (nChunks > 2) {
+                chunk_body(T, T, T, cur, nxt, nn);
+                rotate();
+                for (int chunk = 1; chunk + 2 < nChunks; ++chunk) {
+                    chunk_body(T, T, F, cur, nxt, nn);
+                    rotate();
+                }
+                chunk_body(T, F, F, cur, nxt, nn);
                 cur = nxt;
+                chunk_body(F, F, F, cur, nxt, nn);
+            } else if (nChunks == 2) {
+                chunk_body(T, F, T, cur, nxt, nn);
+                cur = nxt;
+                chunk_body(F, F, F, cur, nxt, nn);
+            } else {
+                chunk_body(F, F, T, cur, nxt, nn);
             }
-            chunk_body(std::false_type{}, std::false_type{}, cur, nxt, nn);
         };
         if (edge) main_loop(std::true_type{});
         else main_loop(std::false_type{});
