@@ -105,6 +105,9 @@ __device__ __forceinline__ float wino_vop(const f32x2 (&V)[8], int p)
     return (j == 0 || j == 3) ? V[2 * i][j == 3] : V[2 * i + 1][j == 2];
 }
 
+// RAGGED: Cin is not a multiple of the 8-channel chunk (tests and odd layers only: the production instantiation carries none of
+// that bookkeeping -- it cost 1 % of the step in scalar registers and loop instructions)
+template <bool RAGGED>
 __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi,
@@ -192,12 +195,14 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     };
     // Cin not a multiple of 8: the last chunk's channels >= Cin are the NEXT image's first planes (the descriptor reaches to the
     // end of the tensor) -- their weights are packed as zeros, but 0 x Inf is not 0: those pieces are switched off for the last chunk
-    int chunks_left = nChunks;                               // chunks not yet issued
+    int chunks_left = nChunks;                               // chunks not yet issued (RAGGED only)
     auto mask_ragged_channels = [&]() {
-        if ((Cin & (WKC - 1)) && chunks_left == 1) {
+        if constexpr (RAGGED) {
+            if (chunks_left == 1) {
 #pragma unroll
-            for (int i = 0; i < WPI; ++i)
-                if ((tid + i * WNT) / (WPR * 12) >= (Cin & (WKC - 1))) pvoff[i] = 0xFFFFFFFFu;
+                for (int i = 0; i < WPI; ++i)
+                    if ((tid + i * WNT) / (WPR * 12) >= (Cin & (WKC - 1))) pvoff[i] = 0xFFFFFFFFu;
+            }
         }
     };
     mask_ragged_channels();
@@ -205,8 +210,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         wc += WUS * 4;
         xc += (size_t)WKC * HW * 4;
         xleft = xleft == 0xFFFFFFFEu ? xleft : xleft - (unsigned)WKC * (unsigned)HW * 4u;
-        --chunks_left;
-        mask_ragged_channels();
+        if constexpr (RAGGED) {
+            --chunks_left;
+            mask_ragged_channels();
+        }
     };
     auto issue = [&](int buf) {
 #pragma unroll
@@ -1019,8 +1026,12 @@ int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, co
     const int colocate = WINO_COLOCATE_MAX_COTILES >= coTiles;
     const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;
     PTMI_CHECK_ARG(nWg < (1ll << 31), "conv3x3_wino_fwd: too many tiles");
-    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)nWg), dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n, cin,
-                       cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate);
+    if (cin & (WKC - 1))
+        hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3((unsigned)nWg), dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
+                           cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate);
+    else
+        hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3((unsigned)nWg), dim3(WNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
+                           cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate);
     PTMI_LAUNCH_CHECK("conv3x3_wino_fwd");
     return 0;
 }
