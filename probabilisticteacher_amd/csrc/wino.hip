@@ -142,6 +142,10 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     const int u0 = pix * WTW;                                // flat column of the workgroup's first output column
     const int s_first = u0 / period;                         // strip of the first tile column; its image is the address base
     const int n = s_first / bands;
+    // (scalar) strip / image / band of the patch's first column: per-lane positions are reached from it by short walks instead of
+    // two vector integer divisions per piece and tile -- 300 VALU instructions per workgroup, 2 % of a 64-channel tile
+    const int s0 = (u0 > 4 ? u0 - 4 : 0) / period;
+    const int n0 = s0 / bands, b0 = s0 - n0 * bands;
 
     // ---- DMA descriptors: this lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first plane
     // of image n.  LDS column c of the patch <-> flat column u0 - 4 + c; periods are multiples of 4, so a piece lies in ONE strip.
@@ -152,12 +156,12 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         const int pidx = tid + i * WNT;
         const int ci = pidx / (WPR * 12), rem = pidx - ci * (WPR * 12);
         const int r = rem / 12, q = rem - r * 12;
-        const int u = u0 - 4 + 4 * q;
-        const int st = u >= 0 ? u / period : -1;
-        const int gx = u - st * period;
-        const int sn = st / bands, gy = (st - sn * bands) * WTH - 1 + r;
+        int gx = u0 - 4 + 4 * q - s0 * period, band = b0, sn = n0;       // gx < 0 only in the very first patch (u0 = 0, q = 0)
+        while (gx >= period) { gx -= period; ++band; }
+        while (band >= bands) { band -= bands; ++sn; }
+        const int gy = band * WTH - 1 + r;
         pvoff[i] = 0xFFFFFFFFu;
-        if (pidx < WPS / 4 && q < 10 && st >= 0 && st < nStrips && gy >= 0 && gy < H && gx < W) {
+        if (pidx < WPS / 4 && q < 10 && gx >= 0 && sn < N && gy >= 0 && gy < H && gx < W) {
             pvoff[i] = (unsigned)(((sn - n) * Cin + ci) * HW + gy * W + gx) * 4u;
 #pragma unroll
             for (int e = 1; e < 4; ++e) fix |= (gx + e >= W) ? (1 << (4 * i + e)) : 0;
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     bool edge = false;                                       // some loaded piece may straddle the right edge of an image row
     if (W & 3) {
         const int e0 = W & ~3;                               // strip-local first column of the straddling piece
-        for (int st = (u0 > 4 ? u0 - 4 : 0) / period; st < nStrips && st * period + e0 < u0 + 36; ++st)
+        for (int st = s0; st < nStrips && st * period + e0 < u0 + 36; ++st)
             edge |= st * period + e0 >= u0 - 4;
     }
 
@@ -240,12 +244,14 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
     // opaque copy of u0: keeping five more values alive across the main loop spills, and with scratch in the kernel the
     // compiler puts a vmcnt(0) in front of every LDS read that follows a DMA -- 2x slower)
     auto tile_geometry = [&](int u0v, int& tsn_o, int& py_o, int& px_o) {
-        const int tu = u0v + 2 * ttx;
-        const int tst = tu / period;
-        tsn_o = tst / bands;
-        py_o = (tst - tsn_o * bands) * WTH + wn * 4 + tty * 2;
-        px_o = tu - tst * period;
-        return tst < nStrips && px_o < W && py_o < H;
+        const int sf = u0v / period;                         // (scalar divisions) strip / image / band of the first tile column
+        int px_t = u0v + 2 * ttx - sf * period, sn = sf / bands, band = sf - sn * bands;
+        while (px_t >= period) { px_t -= period; ++band; }
+        while (band >= bands) { band -= bands; ++sn; }
+        tsn_o = sn;
+        py_o = band * WTH + wn * 4 + tty * 2;
+        px_o = px_t;
+        return sn < N && px_o < W && py_o < H;
     };
     bool active;
     {
