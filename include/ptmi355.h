@@ -73,7 +73,7 @@ int ptmi_conv3x3_fwd_bf16(const float* x, const float* wp, const float* bias, co
                           ptmi_stream_t s);
 int ptmi_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws,
                             int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
-/* Fused Winograd F(2x2,3x3) variant of ptmi_conv3x3_fwd for the 64..512-channel layers (conv1_2 .. conv5_3 at
+/* Fused Winograd F(2x2,3x3) variant of ptmi_conv3x3_fwd for the layers with >= 32 input channels (conv1_2 .. conv5_3 at
  * pt/modeling/backbone/vgg.py:45-53,66-69 and the RPN 3x3 conv at pt/modeling/proposal_generator/rpn.py:96; cuDNN, which
  * the reference runs there, uses Winograd for these fp32 3x3 s1 layers too).  Same arguments, epilogues and dgrad
  * convention (mode 1 pack) as ptmi_conv3x3_fwd; fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32, 16 instead of 36
@@ -87,8 +87,13 @@ int ptmi_conv3x3_wino_pack_weights(const float* w, float* wp, int w_cout, int w_
 int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
                           float* y, int n, int cin, int cout, int h, int w, int epilogue,
                           ptmi_stream_t s);
+/* 1 if the shape fits the 32-bit buffer offsets of ptmi_conv3x3_wino_fwd / ptmi_conv3x3_wino_wgrad (per-lane byte offsets
+ * relative to a workgroup's first image; roughly h*w < 8 M pixels at 64 channels), else 0: the caller then routes the layer
+ * to ptmi_conv3x3_fwd / ptmi_conv3x3_wgrad (the Winograd entry points themselves reject such shapes with an error). */
+int ptmi_conv3x3_wino_fwd_fits(int cin, int cout, int h, int w);
+int ptmi_conv3x3_wino_wgrad_fits(int h, int w);
 /* Winograd-domain weight gradient (same contract as ptmi_conv3x3_wgrad; replaces cuDNN's Winograd-nonfused BWD_FILTER
- * for the trainable 3x3 layers): dU_p[co][ci] = sum over tiles of (A dY A^T)_p V_p on v_mfma_f32_32x32x2_f32 (16 instead
+ * for the trainable 3x3 layers with >= 64 input and output channels): dU_p[co][ci] = sum over tiles of (A dY A^T)_p V_p on v_mfma_f32_32x32x2_f32 (16 instead
  * of 36 multiplies per tile and channel pair), split over contiguous tile ranges whose partials (workspace
  * [split][16][Cout][Cin] fp32, ptmi_conv3x3_wino_wgrad_ws_floats) are summed in a fixed order and mapped back by
  * dW = G^T dU G; db = sum of dy per channel (position (1,1) of A dY A^T is the tile's sum), accumulated by the same

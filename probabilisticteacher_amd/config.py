@@ -155,7 +155,7 @@ def get_cfg() -> CfgNode:
     C.INPUT = CfgNode(dict(FORMAT="BGR", MIN_SIZE_TRAIN=(800,), MAX_SIZE_TRAIN=1333, MIN_SIZE_TEST=800,
                            MAX_SIZE_TEST=1333, RANDOM_FLIP="horizontal"))
     C.DATASETS = CfgNode(dict(TRAIN=(), TEST=()))
-    C.DATALOADER = CfgNode(dict(NUM_WORKERS=4))
+    C.DATALOADER = CfgNode(dict(NUM_WORKERS=4, FILTER_EMPTY_ANNOTATIONS=True))      # D2 default: True
     C.TEST = CfgNode(dict(DETECTIONS_PER_IMAGE=100, EVAL_PERIOD=0))
     C.SOLVER = CfgNode(dict(
         LR_SCHEDULER_NAME="WarmupMultiStepLR", MAX_ITER=40000, BASE_LR=0.001, MOMENTUM=0.9, NESTEROV=False,

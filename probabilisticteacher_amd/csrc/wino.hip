@@ -37,9 +37,9 @@
 #include "common.h"
 #include <type_traits>
 
-#ifndef WINO_COLOCATE_MAX_COTILES
+// channel tiles of a pixel tile run back to back on ONE XCD when there are at most this many of them (their U slabs then fit
+// that XCD's 4 MB L2)
 #define WINO_COLOCATE_MAX_COTILES 4
-#endif
 
 namespace {
 
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_kernel(
         for (int g = 0; g < 4; ++g) {
             bv[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (epi <= 1 || epi == 4)
-                bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, half4 * 4, (co_w + g * 8) * 4, 0));
+                bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (half4 + co_w + g * 8) * 4, 0, 0));
         }
     }
 
@@ -626,9 +626,6 @@ __global__ void wino_pack_weights_kernel(const float* __restrict__ w, float* __r
 //     64 x 4 x 40 of x) four per k-step during the last two k-steps of chunk c - 2 and the first two of chunk c - 1; LDS reads
 //     run two k-steps ahead of the MFMAs and the transforms one, so the chunk hand-over (vmcnt(0), edge fix-ups, barrier) sits at
 //     k-step 6 of 8 with every own read four k-steps old.
-#ifndef WGX
-#define WGX 0          // timing experiments only (tools/exp): 1 no DMA, 2 no transforms, 4 no LDS reads, 8 no hand-over, 16 no MFMA
-#endif
 constexpr int GWC = 64;                  // channels per operand tile
 // geometry of a chunk of KSN k-steps (= 2 KSN tiles = 4 KSN columns of one tile row).  KSN = 8: 32 columns; KSN = 7: 28 columns,
 // which tiles W = 83 / 166 / 333 (21 / 42 / 84 tile pairs per row) without the 12.5 / 12.5 / 4.5 % of padded k-steps of KSN = 8
@@ -857,35 +854,31 @@ __global__ __launch_bounds__(WNT, 1) void conv3x3_wino_wgrad_kernel(
             const float* wb = window_base(src, KR);
             auto step = [&](auto p_c) {
                 constexpr int P = decltype(p_c)::value;
-                if (!(WGX & 16)) acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(M, P), opb(M, P), acc[P], 0, 0, 0);
+                acc[P] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa(M, P), opb(M, P), acc[P], 0, 0, 0);
                 if constexpr (P == 15) bsum += WZ[M][1][0];
                 if constexpr (P == 0 && KS == KSN - 2) {
                     // hand-over: the next chunk's pieces (all issued by k-step 1) have landed; edge fix-ups; barrier; then the
                     // stage this chunk occupied is free (its last raw reads were k-step KSN - 3's) and the fetch of chunk + 2 starts
-                    if (!(WGX & 8)) {
-                        wino_vmwait0();
-                        fixup(cur ^ 1, fix_h);
-                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    }
+                    wino_vmwait0();
+                    fixup(cur ^ 1, fix_h);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     fetch_setup();
                     fix_h = fix;
                 }
-                if constexpr (P < 10) { if (!(WGX & 4)) raw_read(src, wb, KR, RA[M], RB[M], P); }
+                if constexpr (P < 10) raw_read(src, wb, KR, RA[M], RB[M], P);
                 // fetch of chunk + 2 (last two k-steps) / of chunk + 1 (k-steps 0, 1): four DMA instructions per k-step
                 if constexpr ((late || KS == 0 || KS == 1) && (P == 1 || P == 8 || P == 9 || P == 14)) {
                     constexpr int part = KS == KSN - 2 ? 0 : (KS == KSN - 1 ? 1 : (KS == 0 ? 2 : 3));
                     constexpr int sub = P == 1 ? 0 : (P == 8 ? 1 : (P == 9 ? 2 : 3));
                     if constexpr (part * 4 + sub < G::NP) {
-                        if (!(WGX & 1)) fetch_piece(part * 4 + sub, late ? cur : cur ^ 1);
+                        fetch_piece(part * 4 + sub, late ? cur : cur ^ 1);
                     }
                 }
                 // transforms of k-step KS + 1
-                if (!(WGX & 2)) {
-                    if constexpr (P == 2) xform_a_rows(RA[O], WR[O]);
-                    if constexpr (P == 3) { xform_a_col(WR[O], WZ[O], 0); xform_a_col(WR[O], WZ[O], 1); xform_a_col(WR[O], WZ[O], 2); xform_a_col(WR[O], WZ[O], 3); }
-                    if constexpr (P == 4 || P == 5) xform_b_rows(RB[O], 0 + (P - 4));
-                    if constexpr (P >= 10 && P <= 13) xform_b_col(VX[O], VY[O], P - 10);
-                }
+                if constexpr (P == 2) xform_a_rows(RA[O], WR[O]);
+                if constexpr (P == 3) { xform_a_col(WR[O], WZ[O], 0); xform_a_col(WR[O], WZ[O], 1); xform_a_col(WR[O], WZ[O], 2); xform_a_col(WR[O], WZ[O], 3); }
+                if constexpr (P == 4 || P == 5) xform_b_rows(RB[O], 0 + (P - 4));
+                if constexpr (P >= 10 && P <= 13) xform_b_col(VX[O], VY[O], P - 10);
                 __builtin_amdgcn_sched_barrier(0);
             };
             step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});
@@ -1012,14 +1005,25 @@ int ptmi_conv3x3_wino_pack_weights(const float* w, float* wp, int w_cout, int w_
     return 0;
 }
 
+int ptmi_conv3x3_wino_fwd_fits(int cin, int cout, int h, int w)
+{
+    if (cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    // a workgroup's 32 flat columns may reach into the strips of later images: per-lane offsets are relative to the first one
+    const int64_t img_span = 32 / ((w + 4) & ~3) + 2;
+    return (img_span * cin + WKC) * h * w * 4 < (1ll << 32) && (img_span * cout + WBM) * h * w * 4 < (1ll << 32);
+}
+
+int ptmi_conv3x3_wino_wgrad_fits(int h, int w)
+{
+    return h > 0 && w > 0 && (int64_t)(GWC + 1) * h * w * 4 < (1ll << 31);
+}
+
 int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
                           int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino_fwd: bad args");
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_wino_fwd: bad epilogue %d", epilogue);
-    // a workgroup's 32 flat columns may reach into the strips of later images: per-lane offsets are relative to the first one
-    const int64_t img_span = 32 / ((w + 4) & ~3) + 2;
-    PTMI_CHECK_ARG((img_span * cin + WKC) * h * w * 4 < (1ll << 32) && (img_span * cout + WBM) * h * w * 4 < (1ll << 32),
+    PTMI_CHECK_ARG(ptmi_conv3x3_wino_fwd_fits(cin, cout, h, w),
                    "conv3x3_wino_fwd: image too large for 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d)", n, cin,
                    cout, h, w);
     PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_wino_fwd: bias required for epilogue %d", epilogue);
@@ -1052,7 +1056,7 @@ int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* d
                             int w, int accumulate, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino_wgrad: bad args");
-    PTMI_CHECK_ARG((int64_t)(GWC + 1) * h * w * 4 < (1ll << 31), "conv3x3_wino_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
+    PTMI_CHECK_ARG(ptmi_conv3x3_wino_wgrad_fits(h, w), "conv3x3_wino_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
     const int S = wino_wgrad_splits(n, cin, cout, h, w);
     const int coTiles = cdiv(cout, GWC), ciTiles = cdiv(cin, GWC);
     hipStream_t st = (hipStream_t)s;

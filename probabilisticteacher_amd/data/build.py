@@ -47,7 +47,7 @@ def build_detection_semisup_train_loader_two_crops(cfg, mapper: Optional[DeviceT
     bl, bu = cfg.SOLVER.IMG_PER_BATCH_LABEL, cfg.SOLVER.IMG_PER_BATCH_UNLABEL
     assert bl > 0 and bl % world == 0, f"Total label batch size ({bl}) must be divisible by the number of gpus ({world})."
     assert bu > 0 and bu % world == 0, f"Total unlabel batch size ({bu}) must be divisible by the number of gpus ({world})."
-    label_dicts = datasets.get_dataset_dicts(cfg.DATASETS.TRAIN_LABEL, filter_empty=True)
+    label_dicts = datasets.get_dataset_dicts(cfg.DATASETS.TRAIN_LABEL, filter_empty=cfg.DATALOADER.FILTER_EMPTY_ANNOTATIONS)   # build.py:111
     unlabel_dicts = datasets.get_dataset_dicts(cfg.DATASETS.TRAIN_UNLABEL, filter_empty=False)
     mapper = mapper or DeviceTwoCropMapper.from_config(cfg, seed=seed + 17 * rank)
     fmt = cfg.INPUT.FORMAT

@@ -88,8 +88,9 @@ def metadata(name: str) -> dict:
 
 def read_image(file_name: str, fmt: str = "BGR") -> torch.Tensor:
     """detection_utils.read_image + the mapper's HWC -> CHW transpose (dataset_mapper.py:162-169): uint8 (3, H, W)"""
-    from PIL import Image
+    from PIL import Image, ImageOps
     with Image.open(file_name) as im:
+        im = ImageOps.exif_transpose(im)          # D2 _apply_exif_orientation: rotated JPEGs are turned upright
         arr = np.asarray(im.convert("RGB"))
     if fmt == "BGR":
         arr = arr[:, :, ::-1]

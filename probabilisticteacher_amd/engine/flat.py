@@ -96,8 +96,8 @@ class BucketedGradReducer:
                  force: bool = False, mode: str = "all_reduce"):
         """force: install the hooks and run the collectives even for world_size 1 (the sum over one rank is the identity;
         used to exercise the RCCL / stream-ordering path on a single GPU).
-        mode: "all_reduce" -- one all-reduce per bucket; "reduce_scatter" -- the same exchange spelled as reduce-scatter +
-        all-gather per bucket (on the fully connected xGMI mesh each rank then owns 1/W of a bucket and the
+        mode: "all_reduce" -- one all-reduce per bucket; "reduce_scatter" -- the same exchange spelled as a reduce-scatter
+        per bucket during backward + the buckets' all-gathers in finish() (on the fully connected xGMI mesh each rank then owns 1/W of a bucket and the
         two halves use all seven links; which of the two RCCL runs faster is a measurement for the first 8-GPU node)."""
         if mode not in ("all_reduce", "reduce_scatter"):
             raise ValueError(f"unknown gradient exchange {mode!r}")
@@ -170,11 +170,12 @@ class BucketedGradReducer:
         s, e = self.buckets[b]
         if self.mode == "all_reduce":
             self.handles.append(dist.all_reduce(self._grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:       # collectives of one process group run in issue order: the all-gather follows its reduce-scatter
+        else:       # first half now (hidden behind the rest of backward); the all-gathers follow in finish(), after the
+            # reduce-scatters have completed -- no reliance on a backend running one group's collectives in issue order
+            # (RCCL's stream does, gloo's worker threads do not: a world-size-2 gloo test caught the all-gather overtaking)
             buf = self.fp.grad_storage[s:e]
             self.handles.append(dist.reduce_scatter_tensor(self.shards[b], buf, op=dist.ReduceOp.SUM, group=self.group,
                                                            async_op=True))
-            self.handles.append(dist.all_gather_into_tensor(buf, self.shards[b], group=self.group, async_op=True))
 
     def _launch_ready(self):
         while self.next < len(self.buckets) and self.pending[self.next] <= 0:
@@ -191,6 +192,11 @@ class BucketedGradReducer:
             for h in self.handles:
                 h.wait()
             self.handles = []
+            if self.mode == "reduce_scatter":       # second half: every rank's reduced shard back into the flat buffer
+                hs = [dist.all_gather_into_tensor(self.fp.grad_storage[s:e], self.shards[b], group=self.group, async_op=True)
+                      for b, (s, e) in enumerate(self.buckets)]
+                for h in hs:
+                    h.wait()
             if self.world > 1:
                 self._grad.div_(self.world)
         n_early = self.launched_in_backward

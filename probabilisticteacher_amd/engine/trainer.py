@@ -228,6 +228,11 @@ class PTrainer:
             m = {k: v for k, v, p in zip(keys, vals[:-1], present) if p}
             gsq = vals[-1]
         m["total_loss"] = sum(v for k, v in m.items() if k[:4] == "loss")
+        # the fused ReLU (v_max_f32) turns a NaN pre-activation into 0 where torch.relu propagates it, so a diverged backbone
+        # can hide from the loss values; the gradient norm (read back here anyway) is the cheap place where it still shows.
+        # The reference runs under torch.autograd.set_detect_anomaly (trainer.py:266) and raises out of backward().
+        if gsq != gsq or gsq in (float("inf"), float("-inf")):
+            raise FloatingPointError(f"non-finite gradient norm at iteration {self.iter} (losses {m})")
         m["grad_norm"] = gsq ** 0.5
         m["data_time"] = data_time
         self.last_metrics = m

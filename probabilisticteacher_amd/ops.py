@@ -161,12 +161,14 @@ def _conv_fwd_sym() -> str:
 
 def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
     """(dW, db) of a 3x3 s1 p1 convolution from its input and output gradient (N1 wgrad): the Winograd-domain kernel on
-    the fp32 64+-channel layers, the direct split-K kernel otherwise (and under bf16 operand rounding)."""
+    the fp32 layers with >= 64 input and output channels whose map fits its 32-bit offsets, the direct split-K kernel otherwise
+    (and under bf16 operand rounding)."""
     n, cin, h, w = x.shape
     dw = torch.empty(cout, cin, 3, 3, dtype=F32, device=x.device)
     db = torch.empty(cout, dtype=F32, device=x.device)
     lib = _lib.load()
-    if _use_wino(cin) and cin >= _WINO_WGRAD_MIN_C and cout >= _WINO_WGRAD_MIN_C:
+    if (_use_wino(cin) and cin >= _WINO_WGRAD_MIN_C and cout >= _WINO_WGRAD_MIN_C
+            and lib.ptmi_conv3x3_wino_wgrad_fits(h, w)):
         ws = _ws("wgrad", lib.ptmi_conv3x3_wino_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
         with _prof("conv3x3_wino_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino_wgrad_issued_flops(n, cin, cout, h, w)):
             _lib.call("ptmi_conv3x3_wino_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
@@ -231,8 +233,14 @@ def wino_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> floa
     return float(pairs) * chunks * ksn * 16 * 4 * 4096
 
 
-def _use_wino(conv_cin: int) -> bool:
-    return _CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and conv_cin >= _WINO_MIN_CIN
+def _use_wino(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tuple[int, int]] = None) -> bool:
+    """Winograd routing of a 3x3 layer: fp32, enough input channels, and -- when the caller knows the map size -- a shape
+    that fits the kernel's 32-bit buffer offsets (ptmi_conv3x3_wino_fwd_fits; larger maps run the direct kernel)."""
+    if not (_CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and conv_cin >= _WINO_MIN_CIN):
+        return False
+    if hw is None or conv_cout is None:
+        return True
+    return bool(_lib.load().ptmi_conv3x3_wino_fwd_fits(conv_cin, conv_cout, int(hw[0]), int(hw[1])))
 
 
 def _bf16_stem_on_valu(conv_cin: int, conv_cout: int, epilogue: int) -> bool:
@@ -242,12 +250,14 @@ def _bf16_stem_on_valu(conv_cin: int, conv_cout: int, epilogue: int) -> bool:
     return _native_bf16() and epilogue in (0, 1) and conv_cin <= 4 and conv_cout <= 64
 
 
-def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int) -> torch.Tensor:
-    """Packed weights for conv3x3_raw(..., epilogue) (mode 0) or for the dgrad launch (mode 1: epilogue 2 / 3)."""
+def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int, hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """Packed weights for conv3x3_raw(..., epilogue) (mode 0) or for the dgrad launch (mode 1: epilogue 2 / 3).  hw = (H, W)
+    of the map the weights will be applied to: decides between the Winograd and the direct pack for maps beyond the Winograd
+    kernel's 32-bit offsets (None = the map fits; conv3x3_raw checks the pack it is handed against its own routing)."""
     _chk(w, name="conv weight")
     co, ci = w.shape[0], w.shape[1]
     conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
-    if _use_wino(conv_cin):
+    if _use_wino(conv_cin, conv_cout, hw):
         n = _lib.load().ptmi_conv3x3_wino_packed_floats(conv_cin, conv_cout)
         wp = torch.empty(n, dtype=F32, device=w.device)
         _lib.call("ptmi_conv3x3_wino_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
@@ -269,7 +279,12 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     n, cin, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
     nbytes = 4.0 * (n * h * w * (cin + cout * (2 if epilogue == 3 else 1)) + 9 * cin * cout)
-    if _use_wino(cin):
+    wino = _use_wino(cin, cout, (h, w))
+    want = (_lib.load().ptmi_conv3x3_wino_packed_floats if wino else _lib.load().ptmi_conv3x3_packed_floats)(cin, cout)
+    if wp.numel() != want:
+        raise _lib.PtmiError(f"conv3x3_raw: packed weights have {wp.numel()} floats, the {'Winograd' if wino else 'direct'} "
+                             f"kernel this {h}x{w} map is routed to takes {want} (pass hw=(H, W) to conv3x3_pack)")
+    if wino:
         with _prof("conv3x3_wino", 2.0 * 9 * cin * cout * h * w * n, nbytes, wino_issued_flops(n, cin, cout, h, w)):
             _lib.call("ptmi_conv3x3_wino_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
                       epilogue, _stream())
@@ -288,9 +303,9 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     x = _chk(_rnd(x).contiguous(), name="conv input")
     n, cin, h, w = x.shape
     cout = weight.shape[0]
-    wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0, 4)
+    wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0, 4, (h, w))
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
-    wino = _use_wino(cin)
+    wino = _use_wino(cin, cout, (h, w))
     with _prof("conv3x3_wino" if wino else "conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n,
                4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout),
                wino_issued_flops(n, cin, cout, h, w) if wino else None):
@@ -316,7 +331,7 @@ class _Conv3x3(torch.autograd.Function):
         x = _chk(_rnd(x).contiguous(), name="conv input")
         weight = _chk(_rnd(weight).contiguous(), name="conv weight")
         bias = _chk(bias.contiguous(), name="conv bias")
-        wp = conv3x3_pack(weight, 0, 1 if relu else 0)
+        wp = conv3x3_pack(weight, 0, 1 if relu else 0, x.shape[-2:])
         y = conv3x3_raw(x, wp, bias, None, weight.shape[0], 1 if relu else 0)
         ctx.relu = relu
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -333,7 +348,7 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = conv3x3_wgrad(x, dz, cout)
         if ctx.needs_input_grad[0]:
-            wpd = conv3x3_pack(weight, 1, 2)
+            wpd = conv3x3_pack(weight, 1, 2, (h, w))
             dx = conv3x3_raw(dz, wpd, None, None, cin, 2)
         return dx, dw, db, None
 
@@ -382,7 +397,7 @@ class _VGGBlock(torch.autograd.Function):
         for j in range(k):
             w, b = _chk(wb[2 * j].contiguous()), _chk(wb[2 * j + 1].contiguous())
             ws.append(w)
-            acts.append(conv3x3_raw(acts[-1], conv3x3_pack(w, 0, 1), b, None, w.shape[0], 1))
+            acts.append(conv3x3_raw(acts[-1], conv3x3_pack(w, 0, 1, acts[-1].shape[-2:]), b, None, w.shape[0], 1))
         out = acts[-1]
         if pool:
             n, c, h, wd = out.shape
@@ -417,9 +432,9 @@ class _VGGBlock(torch.autograd.Function):
                 dw, db = conv3x3_wgrad(xin, dz, cout)
                 grads[2 * (j - 1)], grads[2 * (j - 1) + 1] = dw, db
             if j > 1:
-                dz = conv3x3_raw(dz, conv3x3_pack(w, 1, 3), None, xin, cin, 3)      # dgrad + ReLU mask of layer j-1
+                dz = conv3x3_raw(dz, conv3x3_pack(w, 1, 3, (h, wd)), None, xin, cin, 3)      # dgrad + ReLU mask of layer j-1
             elif ctx.needs_input_grad[0]:
-                dx = conv3x3_raw(dz, conv3x3_pack(w, 1, 2), None, None, cin, 2)
+                dx = conv3x3_raw(dz, conv3x3_pack(w, 1, 2, (h, wd)), None, None, cin, 2)
         return (dx, None, *grads)
 
 

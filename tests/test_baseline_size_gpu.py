@@ -225,8 +225,9 @@ def test_frozen_blocks_and_rpn_conv_full_size_vs_torch():
 
 def test_conv3_2_at_n48_bench_launch_shape_vs_torch():
     """ONE launch of each conv3_2 kernel at the joint student pass's batch (n = 48 = 32 labelled views + 16 unlabelled):
-    forward (8-wave variant, epilogue 1), dgrad with the producer's ReLU mask (epilogue 3), wgrad with the n = 48 split-K
-    count and the merged main + right-edge launch, bias gradient."""
+    forward (epilogue 1), dgrad with the producer's ReLU mask (epilogue 3) on the Winograd kernel; weight + bias gradient on the
+    Winograd-domain kernel (the one the fp32 step runs) AND on the direct split-K kernel (n = 48 split count, merged main +
+    right-edge launch)."""
     from probabilisticteacher_amd import ops
     from probabilisticteacher_amd import _lib
     _threads()
@@ -241,19 +242,58 @@ def test_conv3_2_at_n48_bench_launch_shape_vs_torch():
     yrelu = F.relu(yr)
     yr.backward(gy)
     xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
-    yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0, 1), bd, None, c, 1)
+    yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0, 1, (h, w)), bd, None, c, 1)
     _rel(yd, yrelu.detach(), 1e-4, "conv3_2 forward n=48")
     del yd
-    dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1, 3), None, xd, c, 3)
+    dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1, 3, (h, w)), None, xd, c, 3)
     _rel(dx, xr.grad * (x > 0), 1e-4, "conv3_2 dgrad + mask n=48")
     del dx
+    # the kernel the fp32 step runs (ops.conv3x3_wgrad routes 64+-channel fp32 layers to ptmi_conv3x3_wino_wgrad): 3.3 GB per
+    # operand -- the shape where its 32-bit buffer offsets, split count and chunk clamp matter
+    assert ops._use_wino(c, c, (h, w)) and _lib.load().ptmi_conv3x3_wino_wgrad_fits(h, w)
+    dw, db = ops.conv3x3_wgrad(xd, gd, c)
+    _rel(dw, wr.grad, 1e-4, "conv3_2 Winograd wgrad n=48")
+    _rel(db, br.grad, 1e-4, "conv3_2 Winograd bias grad n=48")
+    dw2, db2 = ops.conv3x3_wgrad(xd, gd, c)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "the split reduction runs in a fixed order"
+    # ... and the direct split-K kernel (bf16 path, small channel counts) at the same shape
     dw, db = torch.empty_like(wd), torch.empty(c, device=DEV)
     nws = _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, c, c, h, w)
     ws = torch.empty(nws, device=DEV)
     _lib.call("ptmi_conv3x3_wgrad", ops._ptr(xd), ops._ptr(gd), ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, c, c, h, w, 0,
               ops._stream())
-    _rel(dw, wr.grad, 1e-4, "conv3_2 wgrad n=48")
-    _rel(db, br.grad, 1e-4, "conv3_2 bias grad n=48")
+    _rel(dw, wr.grad, 1e-4, "conv3_2 direct wgrad n=48")
+    _rel(db, br.grad, 1e-4, "conv3_2 direct bias grad n=48")
+
+
+def test_conv4_2_at_n48_bench_launch_shape_vs_torch():
+    """The 512-channel launch shape of the joint student pass (n = 48, 512 -> 512 at 100 x 166): Winograd forward (8 channel
+    tiles: one U slab per XCD), dgrad with the producer's ReLU mask, Winograd weight + bias gradient (chunks of 7 k-steps: 42 tile
+    pairs per row), each as ONE launch against torch CPU fp32."""
+    from probabilisticteacher_amd import ops
+    from probabilisticteacher_amd import _lib
+    _threads()
+    gen = torch.Generator().manual_seed(4802)
+    n, c, h, w = 48, 512, 100, 166
+    x = torch.relu(torch.randn(n, c, h, w, generator=gen))
+    wt = torch.randn(c, c, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * c))
+    b = torch.randn(c, generator=gen) * 0.1
+    gy = torch.randn(n, c, h, w, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yrelu = F.relu(yr)
+    yr.backward(gy)
+    xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
+    assert ops._use_wino(c, c, (h, w)) and _lib.load().ptmi_conv3x3_wino_wgrad_fits(h, w)
+    yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0, 1, (h, w)), bd, None, c, 1)
+    _rel(yd, yrelu.detach(), 1e-4, "conv4_2 forward n=48")
+    del yd
+    dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1, 3, (h, w)), None, xd, c, 3)
+    _rel(dx, xr.grad * (x > 0), 1e-4, "conv4_2 dgrad + mask n=48")
+    del dx
+    dw, db = ops.conv3x3_wgrad(xd, gd, c)
+    _rel(dw, wr.grad, 1e-4, "conv4_2 Winograd wgrad n=48")
+    _rel(db, br.grad, 1e-4, "conv4_2 Winograd bias grad n=48")
 
 
 def _records(gen, n_img, h, w, K, m0=3):
@@ -547,3 +587,18 @@ def test_baseline_config2_full_mutual_learning_step_1333x800_vs_oracle(monkeypat
         print(f"\n[configs[2] 1333x800] proposals: {res['log'].check_sets()}; pseudo labels {[len(p) for p in res['tr'].mine]}; "
               f"losses HIP {m} oracle {om}")
     _compare_step(m, om, res["tr"], res["state"], res["params"], SUP + UNSUP, "configs[2]")
+
+
+def test_baseline_config2_step_b4_plus_4_1333x800_vs_oracle(monkeypatch, capsys):
+    """configs[2] with 4 labelled + 4 unlabelled 1333 x 800 images: the joint 12-image student pass (8 labelled views + 4
+    unlabelled strong views), a 4-image teacher pass, matcher / sampler / NMS batched over several images with different gt
+    counts, per-image pseudo labels -- the batched code paths of the bench (16 + 16) against the oracle's per-image loops.
+    Same bar as the 1 + 1 test: 8 losses 1e-4, gradient norm 1e-3, updated-parameter probes 1e-4."""
+    res = mutual_learning_step_vs_oracle(monkeypatch, "configs/pt/final_c2f.yaml", 800, 1333, n_img=4, seed=47)
+    m, om = res["m"], res["om"]
+    check_teacher_and_pseudo_labels(res)
+    assert set(SUP + UNSUP) <= set(m) and set(SUP + UNSUP) <= set(om)
+    with capsys.disabled():
+        print(f"\n[configs[2] 1333x800 B=4+4] proposals: {res['log'].check_sets()}; pseudo labels {[len(p) for p in res['tr'].mine]}; "
+              f"losses HIP {m} oracle {om}")
+    _compare_step(m, om, res["tr"], res["state"], res["params"], SUP + UNSUP, "configs[2] B=4+4")

@@ -81,19 +81,22 @@ def test_config4_s2c_amp_step_native_vs_emulated_vs_fp32_oracle(monkeypatch, cap
     assert any(abs(mn[k] - om[k]) > 1e-6 for k in SUP), "AMP must change the numbers"
 
 
-def _hip_trajectory(st, key_seed0, pool_raw, sched):
-    """one HIP training run of the curve workload with the sampler keys of `key_seed0`; returns {loss key: per-iteration array}"""
+def _hip_trajectory(st, key_seed0, pool_raw, sched, amp=False):
+    """one HIP training run of the curve workload with the sampler keys of `key_seed0`; returns {loss key: per-iteration array}.
+    amp: SOLVER.AMP.ENABLED (the reference's mixed-precision flag, pt/engine/trainer.py:98)"""
     from probabilisticteacher_amd.config import setup_cfg
     from probabilisticteacher_amd.engine import PTrainer
     from probabilisticteacher_amd.modeling import sampling
     from probabilisticteacher_amd.structures import Boxes, FreeInstances
     cfg = setup_cfg(S2C, ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", st["burn"],
                           "SOLVER.IMG_PER_BATCH_LABEL", st["batch"], "SOLVER.IMG_PER_BATCH_UNLABEL", st["batch"],
-                          "SOLVER.WARMUP_ITERS", st["warmup_iters"], "SOLVER.BASE_LR", st["base_lr"]])
+                          "SOLVER.WARMUP_ITERS", st["warmup_iters"], "SOLVER.BASE_LR", st["base_lr"],
+                          "SOLVER.AMP.ENABLED", bool(amp)])
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     params = opt.golden_params(opt.Cfg(num_classes=K, anchor_generator=cfg.MODEL.ANCHOR_GENERATOR.NAME), st["param_seed"])
     ratios = []
     tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
+    assert tr.operand_rounding == ("bf16" if amp else None)
     for model in (tr.model, tr.model_teacher):
         sd = model.state_dict()
         with torch.no_grad():
@@ -155,22 +158,30 @@ def test_config4_loss_curves_vs_committed_oracle_trajectories(capsys):
     [0.124, 0.117, 0.125] -- three oracle means that happen to lie within 3 % of each other.  Nine HIP trajectories
     (tools/exp/curve_hip.py, seeds 1000 .. 9000) give 0.132 +- 0.023 for that term (six of them 0.113 .. 0.127): no bias, one
     outlying seed; hence version 3, the two-sample form above."""
+    _loss_curves_vs_oracle(capsys, amp=False)
+
+
+def _loss_curves_vs_oracle(capsys, amp):
+    """the three-trajectory comparison of test_config4_loss_curves_vs_committed_oracle_trajectories (criterion v3, see there);
+    amp: the HIP side runs with SOLVER.AMP.ENABLED -- the first-iteration bar is then the bf16 rounding of every conv / FC operand
+    (5e-2 relative + 2e-3 absolute: the bar of test_config4_s2c_amp_step_native_vs_emulated_vs_fp32_oracle) instead of fp32
+    parity, and iterations 1 and 2 are not compared term by term; the statistical criterion is UNCHANGED."""
     z = load("loss_curve_s2c")
     st = dict(cc.SETTINGS)
     saved = dict(zip([str(k) for k in z["settings_keys"]], [float(v) for v in z["settings_vals"]]))
     assert {k: float(v) for k, v in st.items()} == saved, "tests/curve_common.py changed: regenerate the golden curves"
     assert [int(s) for s in z["seeds"]] == list(cc.KEY_SEEDS)
     pool_raw, sched = cc.make_pool(st, 1), cc.ratio_schedule(st)
-    hip = {seed: _hip_trajectory(st, seed, pool_raw, sched) for seed in cc.KEY_SEEDS}
+    hip = {seed: _hip_trajectory(st, seed, pool_raw, sched, amp=amp) for seed in cc.KEY_SEEDS}
     burn, n = st["burn"], st["iters"]
     report = []
     for seed in cc.KEY_SEEDS:
         # iteration 0 runs on identical parameters (pure forward parity, 1e-3); iterations 1, 2 follow one / two SGD updates at the
         # warm-up learning rate: fp32 differences in the update can already flip a proposal's rank and with it one of the 256
         # sampled ROIs (measured: 3.6e-3 on loss_cls at iteration 2), hence 2e-2 there
-        for it, rtol in ((0, 1e-3), (1, 2e-2), (2, 2e-2)):
+        for it, rtol, atol in (((0, 5e-2, 2e-3),) if amp else ((0, 1e-3, 1e-6), (1, 2e-2, 1e-6), (2, 2e-2, 1e-6))):
             for k in cc.LOSS_KEYS:
-                close(torch.tensor(hip[seed][k][it]), torch.tensor(float(z[f"{k}@{seed}"][it])), rtol, 1e-6, f"seed {seed} iteration {it} {k}")
+                close(torch.tensor(hip[seed][k][it]), torch.tensor(float(z[f"{k}@{seed}"][it])), rtol, atol, f"seed {seed} iteration {it} {k}")
     ml = slice(burn, n)
     for k in [k + "_unsup" for k in cc.LOSS_KEYS]:
         for side, curves in (("hip", [hip[s][k] for s in cc.KEY_SEEDS]), ("oracle", [z[f"{k}@{s}"] for s in cc.KEY_SEEDS])):
@@ -188,4 +199,16 @@ def test_config4_loss_curves_vs_committed_oracle_trajectories(capsys):
                           f"{np.round(mo, 4).tolist()} (tol {tol:.4f})")
             assert abs(mh.mean() - mo.mean()) <= tol, report[-1]
     with capsys.disabled():
-        print("\n[configs[4] loss curves] " + "\n  ".join(report))
+        print(f"\n[configs[4] loss curves{' SOLVER.AMP.ENABLED' if amp else ''}] " + "\n  ".join(report))
+
+
+def test_config4_amp_loss_curves_vs_committed_fp32_oracle_trajectories(capsys):
+    """BASELINE configs[4] in its own precision ("mixed bf16 convs + fp32 loss, loss-curve parity vs CPU ref"): the SAME
+    three-trajectory harness as the fp32 test above with SOLVER.AMP.ENABLED on the HIP side (reference flag
+    pt/engine/trainer.py:98; step pt/engine/trainer.py:263-392; config configs/pt/final_s2c.yaml) against the COMMITTED fp32 oracle
+    trajectories (tests/golden/loss_curve_s2c.npz).  Tolerances were fixed before the first run of this test and are criterion v3
+    of the fp32 test, unchanged: per loss term and phase |mean_hip - mean_oracle| <= max(20 % of the oracle's mean,
+    3 sqrt((sigma_o^2 + sigma_h^2) / 3), 0.01); every unsupervised term live in >= 50 % of the mutual-learning iterations; finite
+    gradients throughout (asserted per iteration in _hip_trajectory).  Iteration 0 (identical parameters): every term within
+    5e-2 relative + 2e-3 absolute of the fp32 oracle -- the bf16-rounding bar of the single-step AMP test above."""
+    _loss_curves_vs_oracle(capsys, amp=True)

@@ -138,3 +138,160 @@ def test_checkpoint_resume_is_bitwise_on_gpu(tmp_path):
                 assert x[k] == y[k] or (x[k] != x[k] and y[k] != y[k]), f"metric {k}: {x[k]} vs {y[k]}"
     assert torch.equal(a.student.flat, c.student.flat) and torch.equal(a.teacher.flat, c.teacher.flat)
     assert torch.equal(a.momentum_buf, c.momentum_buf)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The REAL step on TWO ranks.  A test box has one GPU and RCCL refuses two ranks on one device, so the two processes share
+# cuda:0 and talk over gloo.  gloo moves CUDA tensors for broadcast and all_reduce (the gradient exchange of the default
+# mode, the start-up parameter broadcast); its all_gather / reduce_scatter take host tensors only, so those calls -- the
+# metrics all-gather of `_write_metrics`, the checksum all-gather of `replicas_identical`, the reduce-scatter mode's two halves
+# -- are bounced through host copies by the shims below (test-side only: the product code calls torch.distributed as it does
+# on RCCL).
+class _Done:
+    def wait(self, *a, **k):
+        return True
+
+
+def _install_gloo_cuda_shims():
+    o_agt, o_rst, o_ag = dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_gather
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        if not inp.is_cuda:
+            return o_agt(out, inp, group=group, async_op=async_op)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        o_agt(host, inp.cpu(), group=group)
+        out.copy_(host)
+        return _Done() if async_op else None
+
+    def reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        if not inp.is_cuda:
+            return o_rst(out, inp, op=op, group=group, async_op=async_op)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        o_rst(host, inp.cpu(), op=op, group=group)
+        out.copy_(host)
+        return _Done() if async_op else None
+
+    def all_gather(outs, inp, group=None, async_op=False):
+        if not inp.is_cuda:
+            return o_ag(outs, inp, group=group, async_op=async_op)
+        hosts = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        o_ag(hosts, inp.cpu(), group=group)
+        for o, h in zip(outs, hosts):
+            o.copy_(h)
+        return _Done() if async_op else None
+
+    dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_gather = all_gather_into_tensor, reduce_scatter_tensor, all_gather
+
+
+def _two_rank_worker(rank, world, port, mode, q):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _install_gloo_cuda_shims()
+    from bench import synth_records
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.engine.flat import replicas_identical
+    from probabilisticteacher_amd.modeling import sampling
+    # global batch 2 + 2 (configs[3] in miniature: data/build.py:174-187 gives every rank total / world records per stream)
+    cfg = setup_cfg("configs/pt/final_c2f.yaml", ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", 1,
+                                                  "SOLVER.IMG_PER_BATCH_LABEL", 2, "SOLVER.IMG_PER_BATCH_UNLABEL", 2])
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    gen = torch.Generator().manual_seed(770)
+    glob = [tuple(synth_records(gen, 2, 320, 480, K, DEV) for _ in range(4)) for _ in range(3)]
+    mine = [tuple(stream[rank:rank + 1] for stream in b) for b in glob]          # this rank's 1 + 1 share of every step
+
+    class Recording(PTrainer):
+        local = None
+
+        def _write_metrics(self, record_dict, data_time, sumsq):          # this rank's own loss values, before the averaging
+            self.local = {k: float(v.detach()) for k, v in record_dict.items() if k[:4] == "loss"}
+            super()._write_metrics(record_dict, data_time, sumsq)
+
+    def run(exchange):
+        """3 steps (burn-in, EMA copy + mutual learning, mutual learning) with or without the cross-rank exchange"""
+        torch.manual_seed(100 + rank)                # ranks start from DIFFERENT weights: the start-up broadcast must fix that
+        ratios = iter([0.8, 0.6, 0.9, 0.7, 0.75, 0.65, 0.85, 0.55] * 3)
+        tr = Recording(cfg, ratio_fn=lambda: next(ratios), grad_reduce=mode)
+        assert tr.world_size == 2 and tr.reducer.active and len(tr.reducer.buckets) >= 4
+        if not exchange:                             # a purely local trainer on the same start weights: hooks off, no averaging
+            for h in tr.reducer._hooks:
+                h.remove()
+            tr.reducer.active = False
+        keyg = torch.Generator().manual_seed(5 + rank)
+        sampling.set_key_source(lambda labels, sizes, bg: torch.rand(labels.shape, generator=keyg))
+        out = []
+        try:
+            for it in range(3):
+                before = tr.student.flat.clone()
+                m = tr.run_step(mine[it])
+                out.append(dict(m=m, local=tr.local, grad=tr.student.grad.clone(), early=tr.reducer.launched_in_backward, before=before,
+                                same=replicas_identical(tr.student.flat)[0] and replicas_identical(tr.teacher.flat)[0]))
+                if not exchange:
+                    break                            # without the exchange the replicas diverge after one step: compare step 0 only
+        finally:
+            sampling.set_key_source(None)
+        return tr, out
+
+    tr, ex = run(True)
+    _, loc = run(False)
+    # (ii) the exchanged gradient of step 0 == the mean of the two ranks' local gradients (same start weights, same data, same keys)
+    local = loc[0]["grad"]
+    both = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    mean = (both[0] + both[1]) / world
+    err = float((ex[0]["grad"] - mean).abs().max() / mean.abs().max())
+    # (iii) metrics: every rank reports rank 0's keys averaged over the ranks; each rank's own loss values (recorded before the averaging) give the expectation
+    keys = sorted(ex[0]["local"])
+    lm = torch.tensor([ex[0]["local"][k] for k in keys], dtype=torch.float64, device=DEV)
+    lms = [torch.empty_like(lm) for _ in range(world)]
+    dist.all_gather(lms, lm)
+    q.put(dict(rank=rank, n_buckets=len(tr.reducer.buckets), early=[o["early"] for o in ex], same=[o["same"] for o in ex],
+               start_equal=replicas_identical(ex[0]["before"])[0], grad_err=err,
+               metrics=[{k: float(v) for k, v in o["m"].items()} for o in ex],
+               local_loss_mean=((lms[0] + lms[1]) / world).cpu().numpy(), loss_keys=keys,
+               local_differs=bool((lms[0] != lms[1]).any()),
+               grad_head=np.asarray(ex[2]["grad"][-64:].cpu())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
+def test_real_run_step_on_two_ranks_sharing_the_gpu(mode):
+    """Two PTrainer processes (gloo, world size 2) on cuda:0, each with half of a 2 + 2 batch, three real `run_step`s (burn-in,
+    EMA copy + mutual learning, mutual learning) -- reference pt/engine/trainer.py:92-95 (DDP), :403-417 (metrics), :495-496
+    (start-up sync), pt/data/build.py:174-187 (per-rank batch):
+      (0) the start-up broadcast makes differently initialised ranks identical;
+      (i)  student AND teacher replicas are bit-identical after every step (checksums, all-gathered);
+      (ii) the gradient a rank holds after the exchange == the mean of the two ranks' local gradients (1e-6 of its scale);
+      (iii) `_write_metrics`: both ranks report the same loss values = the mean of the ranks' local losses;
+      (iv) all buckets but the last one leave DURING backward."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=900) for _ in procs], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = out
+    for d in out:
+        assert d["start_equal"], "start-up broadcast"
+        assert all(d["same"]), f"replicas diverged: {d['same']}"
+        assert d["grad_err"] <= 1e-6, f"exchanged gradient vs mean of local gradients: {d['grad_err']:.3e}"
+        assert all(e >= d["n_buckets"] - 1 for e in d["early"]), (d["early"], d["n_buckets"])
+    assert (a["grad_head"] == b["grad_head"]).all()
+    for ma, mb in zip(a["metrics"], b["metrics"]):
+        assert {k for k in ma if k[:4] == "loss"} == {k for k in mb if k[:4] == "loss"}
+        for k in ma:
+            if k[:4] == "loss" or k == "total_loss":
+                assert ma[k] == mb[k] or (ma[k] != ma[k] and mb[k] != mb[k]), f"{k}: {ma[k]} vs {mb[k]}"
+    assert a["local_differs"], "the two ranks see different data: their local losses must differ"
+    for k, want in zip(a["loss_keys"], a["local_loss_mean"]):
+        got = a["metrics"][0][k]
+        assert abs(got - want) <= 1e-6 * abs(want) + 1e-7, f"step 0 {k}: reported {got} vs mean of the local losses {want}"

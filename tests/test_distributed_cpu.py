@@ -33,7 +33,9 @@ def _worker(rank, world, port, q):
     flat.zero_grad()
     ((model(xs) - ys) ** 2).mean().backward()
     allreduce_mean_(flat.grad, world, chunk_elems=7)      # tiny chunks to exercise the chunking
-    q.put((rank, flat.flat.clone(), flat.grad.clone(), flat.n_trainable, list(flat.index.keys())))
+    # numpy payloads: a torch tensor on an mp.Queue travels as a shared-memory fd that the parent may open only after this
+    # worker has exited (FileNotFoundError in rebuild_storage_fd, seen 1 in 2 runs)
+    q.put((rank, flat.flat.detach().clone().numpy(), flat.grad.detach().clone().numpy(), flat.n_trainable, list(flat.index.keys())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +51,7 @@ def test_flat_allreduce_matches_single_rank_big_batch():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, p0, g0, nt0, names0), (_, p1, g1, nt1, names1) = res
+    (_, p0, g0, nt0, names0), (_, p1, g1, nt1, names1) = [(r, torch.from_numpy(p), torch.from_numpy(g), nt, nm) for r, p, g, nt, nm in res]
     assert torch.equal(p0, p1), "broadcast must make the parameters identical"
     assert torch.equal(g0, g1), "all ranks hold the same averaged gradient"
     assert names0 == names1 and names0[-1] == "0.bias", "frozen parameters are laid out after the trainable ones"
@@ -83,7 +85,7 @@ def _mlp():
     return _Net()
 
 
-def _worker_bucketed(rank, world, port, q):
+def _worker_bucketed(rank, world, port, q, mode="all_reduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -93,7 +95,7 @@ def _worker_bucketed(rank, world, port, q):
     flat, rflat = FlatParams(model), FlatParams(ref)
     broadcast_(flat.flat)
     rflat.flat.copy_(flat.flat)
-    red = BucketedGradReducer(flat, world, bucket_elems=100)      # several buckets, tail of the buffer first
+    red = BucketedGradReducer(flat, world, bucket_elems=100, mode=mode)      # several buckets, tail of the buffer first
     g = torch.Generator().manual_seed(20 + rank)                  # rank-local data
     res = []
     for step in range(2):                                         # two steps: the reducer re-arms itself
@@ -105,17 +107,22 @@ def _worker_bucketed(rank, world, port, q):
         rflat.zero_grad()
         ((ref(x) - y) ** 2).mean().backward()
         want = allreduce_mean_(rflat.grad, world).clone()
-        res.append((got, want, launched))
+        res.append((got.numpy(), want.numpy(), launched))
     q.put((rank, res, list(red.buckets), red.bucket_of["unused"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_bucketed_reducer_overlaps_and_matches_plain_allreduce():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
+def test_bucketed_reducer_overlaps_and_matches_plain_allreduce(mode):
+    """mode: one all-reduce per bucket, or reduce-scatter + all-gather on shard-aligned buckets (engine/flat.py)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_bucketed, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_bucketed, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -126,10 +133,10 @@ def test_bucketed_reducer_overlaps_and_matches_plain_allreduce():
         assert len(buckets) >= 3 and buckets[0][1] == max(b[1] for b in buckets), "bucket 0 is the tail of the buffer"
         assert sorted(buckets)[0][0] == 0 and all(a[0] == b[1] for a, b in zip(buckets[:-1], buckets[1:])), "contiguous cover"
         for got, want, launched in res:
-            assert torch.allclose(got, want, rtol=1e-6, atol=1e-8), "bucketed exchange == plain mean all-reduce"
+            assert torch.allclose(torch.from_numpy(got), torch.from_numpy(want), rtol=1e-6, atol=1e-8), "bucketed exchange == plain mean all-reduce"
             # every bucket before the one holding the gradient-less parameter went out DURING backward
             assert launched == unused_bucket == len(buckets) - 1 and launched >= 2, (launched, unused_bucket)
-    assert torch.equal(out[0][1][1][0], out[1][1][1][0]), "both ranks hold the same averaged gradient"
+    assert (out[0][1][1][0] == out[1][1][1][0]).all(), "both ranks hold the same averaged gradient"
 
 
 def _worker_metrics(rank, world, port, q):
