@@ -238,7 +238,7 @@ def test_training_step_runs_on_the_winograd_kernels():
 def test_map_beyond_the_winograd_32bit_offsets_runs_the_direct_kernel():
     """ptmi_conv3x3_wino_fwd / _wgrad reject maps whose per-workgroup byte offsets exceed 32 bits (about 8 M pixels at
     64 channels); ops routes such a layer to the direct kernels instead of surfacing the exception (ptmi_conv3x3_wino_fwd_fits /
-    _wgrad_fits).  64 -> 64 channels at 2048 x 4100: forward + ReLU, dgrad and weight gradient against torch CPU fp32."""
+    _wgrad_fits).  64 -> 64 channels at 2048 x 4100: forward, dgrad and weight gradient against torch CPU fp32."""
     from probabilisticteacher_amd import _lib, ops
     torch.set_num_threads(max(2, min(__import__("os").cpu_count() or 2, 64)))
     n, c, h, w = 1, 64, 2048, 4100
@@ -251,17 +251,14 @@ def test_map_beyond_the_winograd_32bit_offsets_runs_the_direct_kernel():
     b = torch.randn(c, generator=g(7)) * 0.1
     gy = torch.randn(n, c, h, w, generator=g(8))
     xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
-    yr = F.relu(F.conv2d(xr, wr, br, padding=1))
+    yr = F.conv2d(xr, wr, br, padding=1)          # (no ReLU: no mask decisions that could differ between the two sides)
     yr.backward(gy)
     xd, wd, bd = x.to(DEV).requires_grad_(), wt.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
-    yd = ops.conv3x3(xd, wd, bd, True)
+    yd = ops.conv3x3(xd, wd, bd, False)
     close(yd, yr, 1e-4, 1e-4 * float(yr.abs().max()), "oversized map forward")
     yd.backward(gy.to(DEV))
-    # the ReLU masks of the two sides may differ where a pre-activation is within rounding of zero (~1e-6 of the elements): compare
-    # the gradients in norm
     for name, a, r in (("dgrad", xd.grad, xr.grad), ("dW", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
-        rel = float((a.cpu().double() - r.double()).norm() / r.double().norm())
-        assert rel <= 1e-4, f"oversized map {name}: relative error {rel:.3e}"
+        close(a, r, 1e-4, 1e-4 * float(r.abs().max()), f"oversized map {name}")
     with pytest.raises(_lib.PtmiError):          # a Winograd pack handed to a map that is routed to the direct kernel is refused
         with torch.no_grad():
             wp = ops.conv3x3_pack(wd.detach(), 0, 1)
