@@ -1,0 +1,587 @@
+// p8.hip -- bf16 STORAGE path of the 3x3 convolution stack (SOLVER.AMP.ENABLED, BASELINE configs[4]; reference AMP flag
+// pt/engine/trainer.py:98: under autocast cuDNN reads and writes bf16 activations at pt/modeling/backbone/vgg.py:45-53,66-69 and
+// pt/modeling/proposal_generator/rpn.py:96).  gfx950 only.
+//
+// Round 4.  The bf16-INPUT kernels of conv.hip keep fp32 activations in HBM and LDS and round between LDS and the matrix core:
+// twice the bytes at every level, and 0.23 of the bf16 MFMA peak.  Here activations and activation gradients LIVE in bf16:
+//
+//   "P8" layout (padded, 8-channel blocks)      t[C/8][ROWS][WS][8]  bf16,   ROWS = N (H + 1) + 1,  WS = W + 1
+//     * pixel (n, r, c) sits at row n (H + 1) + 1 + r, column 1 + c; row n (H + 1) (one zero row between images, one before the
+//       first, one after the last) and column 0 of every row hold ZEROS: the zero padding of a 3x3 convolution is IN the tensor
+//       (the right neighbour of a row's last pixel is the next row's column 0), so a tap is the flat pixel offset
+//       (ky - 1) WS + (kx - 1) and no kernel tests an image edge;
+//     * the 8 channels of a pixel are one 16-byte vector: ONE ds_read_b128 is a lane's whole B operand (8 k values) of
+//       v_mfma_f32_32x32x16_bf16 in the forward / dgrad kernel, and the weight gradient -- which contracts over PIXELS -- gets its
+//       operands out of the same image with ds_read_b64_tr_b16 (the gfx950 transposing LDS read);
+//     * every producer writes the pad positions as zeros (conv epilogue, pooling, conversion): the invariant the consumers rely on.
+//
+//   p8_conv3x3_kernel<MT>     forward and dgrad (flipped / transposed pack), implicit GEMM M = Cout, N = pixels, K = 9 Cin:
+//                             workgroup = 4 waves = (32 MT) output channels x (64 / MT) rows x 32 columns, wave = MT x (16 / MT)
+//                             accumulator tiles (256 AGPRs); K in chunks of 16 channels x 9 taps, two LDS stages filled by
+//                             buffer_load ... lds (weights: one lane-linear slab per (channel tile, chunk); patch: 16-byte pixel
+//                             vectors with per-lane source offsets), one barrier per chunk.
+//   p8_wgrad_kernel           dW[co][ci][tap] = sum over flat pixels of dY[co][f] X[ci][f + tap offset]: (see there)
+//   conversions, max-pool, weight packs.
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) ptmi_bf16x8 plds_bf16x8_t;
+typedef __attribute__((address_space(3))) void plds_void_t;
+typedef unsigned short u16;
+typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef u16 u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int P8T = 256;                     // threads per workgroup (4 waves, one per SIMD)
+
+struct P8Dims {
+    int N, H, W, HS, WS, ROWS;
+    int64_t PT;                              // pixels per 8-channel plane
+};
+inline P8Dims p8_dims(int n, int h, int w)
+{
+    P8Dims d;
+    d.N = n; d.H = h; d.W = w; d.HS = h + 1; d.WS = w + 1; d.ROWS = n * d.HS + 1;
+    d.PT = (int64_t)d.ROWS * d.WS;
+    return d;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(u16 b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+// round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    bf2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// ------------------------------------------------------------------------------------------------ conversions
+// fp32 NCHW -> P8 (channels beyond C are zero: the 3-channel image becomes a 16-channel P8 tensor for the stem layer)
+__global__ __launch_bounds__(256) void p8_from_nchw_kernel(const float* __restrict__ x, u32x4* __restrict__ y, int C, int H, int W,
+                                                           int HS, int WS, int64_t PT, int CB)
+{
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cb = blockIdx.y;
+    if (f >= PT) return;
+    const int row = (int)(f / WS), col = (int)(f - (int64_t)row * WS);
+    const int n = row / HS, r = row - n * HS - 1, c = col - 1;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r >= 0 && c >= 0) {
+        const int64_t hw = (int64_t)H * W;
+        const float* p = x + ((int64_t)n * C + cb * 8) * hw + (int64_t)r * W + c;
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (cb * 8 + j < C) ? p[j * hw] : 0.f;
+        v = (u32x4){pack_bf16x2(e[0], e[1]), pack_bf16x2(e[2], e[3]), pack_bf16x2(e[4], e[5]), pack_bf16x2(e[6], e[7])};
+    }
+    y[(int64_t)cb * PT + f] = v;
+}
+
+// P8 -> fp32 NCHW (exact: bf16 -> fp32)
+__global__ __launch_bounds__(256) void p8_to_nchw_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int C, int H, int W,
+                                                         int HS, int WS, int64_t PT)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over N * H * W
+    const int cb = blockIdx.y;
+    const int64_t hw = (int64_t)H * W;
+    const int n = (int)(i / hw);
+    const int64_t rem = i - n * hw;
+    const int r = (int)(rem / W), c = (int)(rem - (int64_t)r * W);
+    if (n >= (int)gridDim.z) return;
+    const u32x4 v = x[(int64_t)cb * PT + ((int64_t)n * HS + 1 + r) * WS + 1 + c];
+    float* p = y + ((int64_t)n * C + cb * 8) * hw + rem;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (cb * 8 + j < C) p[j * hw] = __builtin_bit_cast(float, (j & 1) ? (v[j >> 1] & 0xFFFF0000u) : (v[j >> 1] << 16));
+}
+
+// ------------------------------------------------------------------------------------------------ max pool 2x2 (floor)
+__device__ __forceinline__ float bfe(const u32x4& v, int j) { return __builtin_bit_cast(float, (j & 1) ? (v[j >> 1] & 0xFFFF0000u) : (v[j >> 1] << 16)); }
+
+__global__ __launch_bounds__(256) void p8_maxpool_fwd_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int HSi, int WSi,
+                                                             int64_t PTi, int HSo, int WSo, int64_t PTo)
+{
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;          // output flat pixel
+    const int cb = blockIdx.y;
+    if (f >= PTo) return;
+    const int row = (int)(f / WSo), col = (int)(f - (int64_t)row * WSo);
+    const int n = row / HSo, r = row - n * HSo - 1, c = col - 1;
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (r >= 0 && c >= 0) {
+        const u32x4* p = x + (int64_t)cb * PTi + ((int64_t)n * HSi + 1 + 2 * r) * WSi + 1 + 2 * c;
+        const u32x4 a = p[0], b = p[1], d = p[WSi], e = p[WSi + 1];
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaxf(bfe(a, j), bfe(b, j)), fmaxf(bfe(d, j), bfe(e, j)));
+        o = (u32x4){pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
+    }
+    y[(int64_t)cb * PTo + f] = o;
+}
+
+// dx (input geometry) from dy (output geometry): the gradient goes to the FIRST maximum of a window in (0,0),(0,1),(1,0),(1,1)
+// order (ATen); relu_mask: additionally times (x > 0) (x is a post-ReLU activation: pool backward + ReLU backward in one pass)
+__global__ __launch_bounds__(256) void p8_maxpool_bwd_kernel(const u32x4* __restrict__ x, const u32x4* __restrict__ dy,
+                                                             u32x4* __restrict__ dx, int H, int W, int HSi, int WSi, int64_t PTi,
+                                                             int HSo, int WSo, int64_t PTo, int relu_mask)
+{
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;          // input flat pixel
+    const int cb = blockIdx.y;
+    if (f >= PTi) return;
+    const int row = (int)(f / WSi), col = (int)(f - (int64_t)row * WSi);
+    const int n = row / HSi, r = row - n * HSi - 1, c = col - 1;
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (r >= 0 && c >= 0 && (r >> 1) < (H >> 1) && (c >> 1) < (W >> 1)) {
+        const int wr = r >> 1, wc = c >> 1, pos = (r & 1) * 2 + (c & 1);
+        const u32x4* p = x + (int64_t)cb * PTi + ((int64_t)n * HSi + 1 + 2 * wr) * WSi + 1 + 2 * wc;
+        const u32x4 q[4] = {p[0], p[1], p[WSi], p[WSi + 1]};
+        const u32x4 g = dy[(int64_t)cb * PTo + ((int64_t)n * HSo + 1 + wr) * WSo + 1 + wc];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float e0 = bfe(q[0], j), e1 = bfe(q[1], j), e2 = bfe(q[2], j), e3 = bfe(q[3], j);
+            const float m = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+            const int first = e0 == m ? 0 : (e1 == m ? 1 : (e2 == m ? 2 : 3));
+            const float mine = pos == 0 ? e0 : (pos == 1 ? e1 : (pos == 2 ? e2 : e3));
+            v[j] = (first == pos && (!relu_mask || mine > 0.f)) ? bfe(g, j) : 0.f;
+        }
+        o = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    }
+    dx[(int64_t)cb * PTi + f] = o;
+}
+
+// dz = dy * (y > 0) on P8 tensors (pads stay zero: dy's pads are zero)
+__global__ __launch_bounds__(256) void p8_relu_bwd_kernel(const u32x4* __restrict__ dy, const u32x4* __restrict__ y,
+                                                          u32x4* __restrict__ dz, int64_t n16)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const u32x4 g = dy[i], a = y[i];
+    u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned lo = ((a[k] & 0x8000u) || !(a[k] & 0x7FFFu)) ? 0u : (g[k] & 0xFFFFu);            // y <= 0 (or -0)
+        const unsigned hi = ((a[k] & 0x80000000u) || !(a[k] & 0x7FFF0000u)) ? 0u : (g[k] & 0xFFFF0000u);
+        o[k] = lo | hi;
+    }
+    dz[i] = o;
+}
+
+// a + b on P8 tensors, fp32 sum rounded once (two gradient branches meeting at a feature map)
+__global__ __launch_bounds__(256) void p8_add_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ o,
+                                                     int64_t n16)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const u32x4 u = a[i], v = b[i];
+    u32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = pack_bf16x2(bfe(u, 2 * k) + bfe(v, 2 * k), bfe(u, 2 * k + 1) + bfe(v, 2 * k + 1));
+    o[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ weight pack (forward / dgrad)
+// wp[coTile][chunk][tap][mt][lane = 32 h + r][e]:  A operand of v_mfma_f32_32x32x16_bf16 -- row r = output channel
+// coTile (32 MT) + 32 mt + r, k = 8 h + e = input channel within the 16-channel chunk; 16 B per lane, lane-linear: the kernel
+// copies a (coTile, chunk) slab of 9 MT KB to LDS verbatim and every A fragment is one conflict-free ds_read_b128.
+// mode 0: forward (rows = w's dim 0);  mode 1: dgrad (rows = w's dim 1, taps flipped: dX = conv(dY, W^T rotated by 180 degrees))
+__global__ __launch_bounds__(256) void p8_pack_weights_kernel(const float* __restrict__ w, u16* __restrict__ wp, int w_cout, int w_cin,
+                                                              int mode, int MT, int coTiles, int nChunks)
+{
+    const int convCout = mode ? w_cin : w_cout, convCin = mode ? w_cout : w_cin;
+    const int64_t total = (int64_t)coTiles * nChunks * 9 * MT * 64 * 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t t = i;
+        const int e = (int)(t & 7); t >>= 3;
+        const int lane = (int)(t & 63); t >>= 6;
+        const int mt = (int)(t % MT); t /= MT;
+        const int tap = (int)(t % 9); t /= 9;
+        const int chunk = (int)(t % nChunks);
+        const int cot = (int)(t / nChunks);
+        const int co = (cot * MT + mt) * 32 + (lane & 31), ci = chunk * 16 + 8 * (lane >> 5) + e;
+        float v = 0.f;
+        if (co < convCout && ci < convCin) {
+            const int ky = tap / 3, kx = tap % 3;
+            v = mode == 0 ? w[(((int64_t)co * w_cin + ci) * 3 + ky) * 3 + kx]
+                          : w[(((int64_t)ci * w_cin + co) * 3 + (2 - ky)) * 3 + (2 - kx)];
+        }
+        wp[i] = (u16)(pack_bf16x2(v, 0.f) & 0xFFFFu);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+template <int MT>
+struct P8G {
+    static constexpr int NTB = 16 / MT;                  // pixel blocks (1 row x 32 columns) per wave
+    static constexpr int TR = 4 * NTB;                   // tile rows per workgroup
+    static constexpr int TC = 32;                        // tile columns
+    static constexpr int PR = TR + 2, PC = TC + 2;       // patch rows / columns (halo of one)
+    static constexpr int PPL = PR * PC;                  // patch pixels per 8-channel plane
+    static constexpr int PIN = (2 * PPL + P8T - 1) / P8T;   // patch DMA instructions per lane and chunk (2 planes)
+    static constexpr int PBYTES = PIN * P8T * 16;        // patch bytes per stage (padded to whole DMA instructions)
+    static constexpr int WBYTES = 9 * MT * 1024;         // weight slab bytes per (channel tile, chunk)
+    static constexpr int WPIECES = 9 * MT;               // ... in 1-KB wave pieces
+    static constexpr int WIN = (WPIECES + 3) / 4;        // weight DMA instructions per lane and chunk
+    static constexpr int STAGE = WBYTES + PBYTES;
+    static constexpr int NDMA = PIN + WIN;
+};
+
+template <int MT>
+__global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
+    const u16* __restrict__ x, const u16* __restrict__ wp, const float* __restrict__ bias, const u16* __restrict__ mref,
+    u16* __restrict__ y, int Cout, int HS, int WS, int ROWS, long long PT, int nChunks, int epi, int coTiles, int tilesC,
+    int nPix)
+{
+    using G = P8G<MT>;
+    constexpr int NTB = G::NTB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * G::STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (channel tile, pixel tile): the channel tiles of a pixel tile run back to back on ONE XCD (workgroup id mod 8),
+    // so its patch leaves HBM once
+    const int slot = blockIdx.x >> 3;
+    const int cot = slot % coTiles;
+    const int pix = (slot / coTiles) * 8 + (blockIdx.x & 7);
+    if (pix >= nPix) return;
+    const int R0 = (pix / tilesC) * G::TR, C0 = (pix % tilesC) * G::TC;
+
+    // ---- DMA set-up: per-lane source offsets of the patch pieces (loop invariant; the chunk advance moves the descriptor)
+    unsigned pvoff[G::PIN];
+#pragma unroll
+    for (int i = 0; i < G::PIN; ++i) {
+        const int piece = (i * 4 + wave) * 64 + lane;
+        const int plane = piece >= G::PPL ? 1 : 0;
+        const int q = piece - plane * G::PPL;
+        const int prow = q / G::PC, pcol = q - prow * G::PC;
+        const long long flat = (long long)(R0 - 1 + prow) * WS + (C0 - 1 + pcol);
+        const bool ok = piece < 2 * G::PPL && flat >= 0 && flat < PT;
+        pvoff[i] = ok ? (unsigned)((plane * PT + flat) * 16) : 0xFFFFFFFFu;
+    }
+    const unsigned chunk_bytes_lo = (unsigned)((2 * PT * 16) & 0xFFFFFFFFll);      // < 4 GB (checked by the launcher)
+    const unsigned wvoff = (unsigned)lane * 16u;
+
+    auto issue = [&](int chunk, int st) {
+        char* base = lds + st * G::STAGE;
+        const __amdgpu_buffer_rsrc_t rw = ptmi_rsrc(wp + ((size_t)(cot * nChunks + chunk) * G::WBYTES) / 2, (unsigned)G::WBYTES);
+#pragma unroll
+        for (int i = 0; i < G::WIN; ++i) {
+            const int piece = i * 4 + wave;
+            if (piece < G::WPIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (plds_void_t*)(base + piece * 1024), 16, (int)wvoff, piece * 1024, 0, 0);
+        }
+        const __amdgpu_buffer_rsrc_t rx = ptmi_rsrc(x + (size_t)chunk * 2 * PT * 8, chunk_bytes_lo);
+#pragma unroll
+        for (int i = 0; i < G::PIN; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G::WBYTES + (i * 4 + wave) * 1024), 16, (int)pvoff[i], 0, 0, 0);
+    };
+
+    // ---- operand addresses
+    const int h = lane >> 5, px = lane & 31;
+    const int a_off = lane * 16;                                                     // + stage + (tap MT + mt) 1024
+    const int b_off = G::WBYTES + (h * G::PPL + wave * NTB * G::PC + px) * 16;       // + stage + ((nt + ky) PC + kx) 16
+
+    f32x16 acc[MT][NTB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+    // biases of the lane's channels: co = (cot MT + m) 32 + 8 q + 4 h + e, fetched before the first DMA (in-order vmcnt)
+    f32x4 bv[MT][4];
+    {
+        const __amdgpu_buffer_rsrc_t rb = ptmi_rsrc(bias ? (const void*)bias : (const void*)y, bias ? (unsigned)Cout * 4u : 0u);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bv[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (epi <= 1)
+                    bv[m][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ((cot * MT + m) * 32 + 8 * q + 4 * h) * 4, 0, 0));
+            }
+    }
+
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    ptmi_bf16x8 A0[MT], B0[NTB], A1[MT], B1[NTB];
+    auto read_a = [&](const char* st, int tap, int m) { return *(const volatile plds_bf16x8_t*)(st + a_off + (tap * MT + m) * 1024); };
+    auto read_b = [&](const char* st, int tap, int n) {
+        return *(const volatile plds_bf16x8_t*)(st + b_off + ((n + tap / 3) * G::PC + tap % 3) * 16);
+    };
+#pragma unroll
+    for (int m = 0; m < MT; ++m) A0[m] = read_a(lds, 0, m);
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) B0[n] = read_b(lds, 0, n);
+
+    // One k-step = one tap of one 16-channel chunk = 16 MFMAs; the rest of the wave's work sits between them, one item per MFMA
+    // (one wave per SIMD: whatever is not issued in the shadow of an MFMA leaves the matrix pipe idle):
+    //   slots 0 .. MT + NTB - 1   one operand read each for the NEXT k-step (tap + 1, or tap 0 of the next chunk)
+    //   slots 10, 12, 14 (taps 0 .. 4) one DMA instruction each for the chunk after this one (its <= 15 instructions)
+    //   tap 8, before slot 0      hand-over: own DMA pieces of the next chunk landed (vmcnt(0): they were issued >= 3 taps ago),
+    //                             this k-step's operands in registers (lgkmcnt(0)), workgroup barrier
+    auto kstep = [&](auto tap_c, auto more_c, const ptmi_bf16x8 (&A)[MT], const ptmi_bf16x8 (&B)[NTB], ptmi_bf16x8 (&An)[MT],
+                     ptmi_bf16x8 (&Bn)[NTB], int cur, int chunk) {
+        constexpr int TAP = decltype(tap_c)::value;
+        constexpr bool more = decltype(more_c)::value;            // a chunk follows this one
+        constexpr bool next = TAP < 8 || more;
+        const char* src = lds + (TAP < 8 ? cur : cur ^ 1) * G::STAGE;
+        constexpr int NT_ = (TAP + 1) % 9;
+        if constexpr (TAP == 8 && more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        auto slot_fn = [&](auto j_c) {
+            constexpr int J = decltype(j_c)::value;
+            constexpr int m = J / NTB, n = J % NTB;
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], acc[m][n], 0, 0, 0);
+            if constexpr (next) {
+                if constexpr (J < MT) An[J] = read_a(src, NT_, J);
+                else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);
+            }
+            if constexpr (more && TAP < 5 && (J == 10 || J == 12 || J == 14)) {
+                // chunk + 1 into the other stage: everybody left it at the last hand-over
+                constexpr int d = TAP * 3 + (J - 10) / 2;
+                char* base = lds + (cur ^ 1) * G::STAGE;
+                if constexpr (d < G::WIN) {
+                    const int piece = d * 4 + wave;
+                    if (piece < G::WPIECES) {
+                        const __amdgpu_buffer_rsrc_t rw = ptmi_rsrc(wp + ((size_t)(cot * nChunks + chunk + 1) * G::WBYTES) / 2, (unsigned)G::WBYTES);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (plds_void_t*)(base + piece * 1024), 16, (int)wvoff, piece * 1024, 0, 0);
+                    }
+                } else if constexpr (d - G::WIN < G::PIN) {
+                    constexpr int i = d - G::WIN;
+                    const __amdgpu_buffer_rsrc_t rx = ptmi_rsrc(x + (size_t)(chunk + 1) * 2 * PT * 8, chunk_bytes_lo);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G::WBYTES + (i * 4 + wave) * 1024), 16, (int)pvoff[i], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        slot_fn(std::integral_constant<int, 0>{});  slot_fn(std::integral_constant<int, 1>{});
+        slot_fn(std::integral_constant<int, 2>{});  slot_fn(std::integral_constant<int, 3>{});
+        slot_fn(std::integral_constant<int, 4>{});  slot_fn(std::integral_constant<int, 5>{});
+        slot_fn(std::integral_constant<int, 6>{});  slot_fn(std::integral_constant<int, 7>{});
+        slot_fn(std::integral_constant<int, 8>{});  slot_fn(std::integral_constant<int, 9>{});
+        slot_fn(std::integral_constant<int, 10>{}); slot_fn(std::integral_constant<int, 11>{});
+        slot_fn(std::integral_constant<int, 12>{}); slot_fn(std::integral_constant<int, 13>{});
+        slot_fn(std::integral_constant<int, 14>{}); slot_fn(std::integral_constant<int, 15>{});
+    };
+    static_assert(G::NDMA <= 15, "the chunk's DMA instructions are issued three per tap over taps 0..4");
+    static_assert(MT + NTB <= 10, "operand reads occupy the slots before the first DMA slot");
+
+    auto chunk_body = [&](auto more_c, int cur, int chunk) {
+        kstep(std::integral_constant<int, 0>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 1>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        kstep(std::integral_constant<int, 2>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 3>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        kstep(std::integral_constant<int, 4>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 5>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        kstep(std::integral_constant<int, 6>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 7>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        // nine k-steps per chunk: the register sets swap roles from chunk to chunk, so the loop body below is TWO chunks
+        kstep(std::integral_constant<int, 8>{}, more_c, A0, B0, A1, B1, cur, chunk);
+    };
+    auto chunk_body_odd = [&](auto more_c, int cur, int chunk) {
+        kstep(std::integral_constant<int, 0>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        kstep(std::integral_constant<int, 1>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 2>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        kstep(std::integral_constant<int, 3>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 4>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        kstep(std::integral_constant<int, 5>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 6>{}, more_c, A1, B1, A0, B0, cur, chunk);
+        kstep(std::integral_constant<int, 7>{}, more_c, A0, B0, A1, B1, cur, chunk);
+        kstep(std::integral_constant<int, 8>{}, more_c, A1, B1, A0, B0, cur, chunk);
+    };
+    {
+        const std::true_type T{};
+        const std::false_type F{};
+        int chunk = 0;
+        for (; chunk + 2 < nChunks; chunk += 2) {
+            chunk_body(T, 0, chunk);
+            chunk_body_odd(T, 1, chunk + 1);
+        }
+        if (chunk + 2 == nChunks) {
+            chunk_body(T, 0, chunk);
+            chunk_body_odd(F, 1, chunk + 1);
+        } else {
+            chunk_body(F, 0, chunk);
+        }
+    }
+
+    // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 h = channel: a lane holds
+    // channels 8 q + 4 h + (0..3) of its pixel for q = 0..3 -- half of a pixel's 16-byte vector: 8-byte stores, a wave writes 512
+    // contiguous bytes per (mt, q, block)
+    // (an accumulator element extracted in C++ makes the compiler copy whole 16-register tiles to VGPRs, all of them at the head of
+    // the epilogue -- hundreds of spills; explicit v_accvgpr_read keeps the tiles where they are)
+    auto rd = [](float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; };
+    unsigned svoff[NTB];                     // byte offset of the lane's pixel inside an 8-channel plane (0xFFFFFFFF: no store)
+    bool zero[NTB];                          // pad position: store zeros
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) {
+        const int Rg = R0 + wave * NTB + n, Cg = C0 + px;
+        const bool inside = Rg < ROWS && Cg < WS;
+        zero[n] = (Rg % HS) == 0 || Cg == 0;
+        svoff[n] = inside ? (unsigned)(((long long)Rg * WS + Cg) * 16 + h * 8) : 0xFFFFFFFFu;
+    }
+    const unsigned plane_bytes = (unsigned)(PT * 16);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cb = (cot * MT + m) * 4 + q;                     // 8-channel plane of the output
+            if (cb * 8 >= Cout) continue;                              // (wave-uniform)
+            const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)cb * PT * 8, plane_bytes);
+            u32x2 mk[NTB];
+            if (epi == 3) {
+                const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(mref + (size_t)cb * PT * 8, plane_bytes);
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) mk[n] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)svoff[n], 0, 0));
+            }
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = rd(acc[m][n][4 * q + e]) + bv[m][q][e];
+                    if (epi == 1) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (epi == 3) {
+                    // mask of the producing layer's ReLU: its stored activation > 0 (bf16 bit patterns: sign clear, magnitude set)
+                    if ((mk[n][0] & 0x8000u) || !(mk[n][0] & 0x7FFFu)) v[0] = 0.f;
+                    if ((mk[n][0] & 0x80000000u) || !(mk[n][0] & 0x7FFF0000u)) v[1] = 0.f;
+                    if ((mk[n][1] & 0x8000u) || !(mk[n][1] & 0x7FFFu)) v[2] = 0.f;
+                    if ((mk[n][1] & 0x80000000u) || !(mk[n][1] & 0x7FFF0000u)) v[3] = 0.f;
+                }
+                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (zero[n]) o = (u32x2){0u, 0u};
+                __builtin_amdgcn_raw_buffer_store_b64(o, ry, (int)svoff[n], 0, 0);
+            }
+        }
+    }
+}
+
+inline int p8_mt(int cout) { return cout <= 64 ? 2 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t ptmi_p8_plane_pixels(int n, int h, int w)
+{
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    return p8_dims(n, h, w).PT;
+}
+
+int ptmi_p8_from_nchw(const float* x, void* y, int n, int c, int cb_out, int h, int w, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && h > 0 && w > 0 && cb_out * 8 >= c, "p8_from_nchw: bad args");
+    const P8Dims d = p8_dims(n, h, w);
+    hipLaunchKernelGGL(p8_from_nchw_kernel, dim3((unsigned)cdiv64(d.PT, 256), cb_out), dim3(256), 0, (hipStream_t)s, x, (u32x4*)y, c, h,
+                       w, d.HS, d.WS, d.PT, cb_out);
+    PTMI_LAUNCH_CHECK("p8_from_nchw");
+    return 0;
+}
+
+int ptmi_p8_to_nchw(const void* x, float* y, int n, int c, int h, int w, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && h > 0 && w > 0, "p8_to_nchw: bad args");
+    const P8Dims d = p8_dims(n, h, w);
+    hipLaunchKernelGGL(p8_to_nchw_kernel, dim3((unsigned)cdiv64((int64_t)n * h * w, 256), cdiv(c, 8), n), dim3(256), 0, (hipStream_t)s,
+                       (const u32x4*)x, y, c, h, w, d.HS, d.WS, d.PT);
+    PTMI_LAUNCH_CHECK("p8_to_nchw");
+    return 0;
+}
+
+int ptmi_p8_maxpool2x2_fwd(const void* x, void* y, int n, int c, int h, int w, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && c % 8 == 0 && h > 1 && w > 1, "p8_maxpool2x2_fwd: bad args");
+    const P8Dims di = p8_dims(n, h, w), dq = p8_dims(n, h / 2, w / 2);
+    hipLaunchKernelGGL(p8_maxpool_fwd_kernel, dim3((unsigned)cdiv64(dq.PT, 256), c / 8), dim3(256), 0, (hipStream_t)s, (const u32x4*)x,
+                       (u32x4*)y, di.HS, di.WS, di.PT, dq.HS, dq.WS, dq.PT);
+    PTMI_LAUNCH_CHECK("p8_maxpool2x2_fwd");
+    return 0;
+}
+
+int ptmi_p8_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int n, int c, int h, int w, int relu_mask, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && dy && dx && n > 0 && c > 0 && c % 8 == 0 && h > 1 && w > 1, "p8_maxpool2x2_bwd: bad args");
+    const P8Dims di = p8_dims(n, h, w), dq = p8_dims(n, h / 2, w / 2);
+    hipLaunchKernelGGL(p8_maxpool_bwd_kernel, dim3((unsigned)cdiv64(di.PT, 256), c / 8), dim3(256), 0, (hipStream_t)s, (const u32x4*)x,
+                       (const u32x4*)dy, (u32x4*)dx, h, w, di.HS, di.WS, di.PT, dq.HS, dq.WS, dq.PT, relu_mask);
+    PTMI_LAUNCH_CHECK("p8_maxpool2x2_bwd");
+    return 0;
+}
+
+int ptmi_p8_relu_bwd(const void* dy, const void* y, void* dz, int64_t pixels16, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(dy && y && dz && pixels16 >= 0, "p8_relu_bwd: bad args");
+    if (pixels16 == 0) return 0;
+    hipLaunchKernelGGL(p8_relu_bwd_kernel, dim3((unsigned)cdiv64(pixels16, 256)), dim3(256), 0, (hipStream_t)s, (const u32x4*)dy,
+                       (const u32x4*)y, (u32x4*)dz, pixels16);
+    PTMI_LAUNCH_CHECK("p8_relu_bwd");
+    return 0;
+}
+
+int ptmi_p8_add(const void* a, const void* b, void* out, int64_t pixels16, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(a && b && out && pixels16 >= 0, "p8_add: bad args");
+    if (pixels16 == 0) return 0;
+    hipLaunchKernelGGL(p8_add_kernel, dim3((unsigned)cdiv64(pixels16, 256)), dim3(256), 0, (hipStream_t)s, (const u32x4*)a, (const u32x4*)b,
+                       (u32x4*)out, pixels16);
+    PTMI_LAUNCH_CHECK("p8_add");
+    return 0;
+}
+
+int64_t ptmi_p8_packed_elems(int cin, int cout)
+{
+    const int MT = p8_mt(cout);
+    return (int64_t)cdiv(cout, 32 * MT) * cdiv(cin, 16) * 9 * MT * 512;
+}
+
+int ptmi_p8_pack_weights(const float* w, void* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(w && wp && w_cout > 0 && w_cin > 0, "p8_pack_weights: bad args");
+    const int convCout = mode ? w_cin : w_cout, convCin = mode ? w_cout : w_cin;
+    const int MT = p8_mt(convCout), coTiles = cdiv(convCout, 32 * MT), nChunks = cdiv(convCin, 16);
+    const int64_t total = (int64_t)coTiles * nChunks * 9 * MT * 512;
+    const int blocks = (int)(cdiv64(total, 256) > 8192 ? 8192 : cdiv64(total, 256));
+    hipLaunchKernelGGL(p8_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (u16*)wp, w_cout, w_cin, mode, MT, coTiles,
+                       nChunks);
+    PTMI_LAUNCH_CHECK("p8_pack_weights");
+    return 0;
+}
+
+int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void* mask_ref, void* y, int n, int cin, int cout,
+                    int h, int w, int epilogue, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_conv3x3: bad args");
+    PTMI_CHECK_ARG(cin % 16 == 0 && cout % 8 == 0, "p8_conv3x3: cin %d must be a multiple of 16 and cout %d of 8", cin, cout);
+    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "p8_conv3x3: bad epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue > 1 || bias, "p8_conv3x3: bias required for epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "p8_conv3x3: mask_ref required for epilogue 3");
+    const P8Dims d = p8_dims(n, h, w);
+    PTMI_CHECK_ARG(d.PT * 32 < (1ll << 32), "p8_conv3x3: %lld pixels per plane exceed the 32-bit buffer offsets", (long long)d.PT);
+    const int MT = p8_mt(cout), coTiles = cdiv(cout, 32 * MT), nChunks = cin / 16;
+    const int TR = MT == 4 ? P8G<4>::TR : P8G<2>::TR;
+    const int tilesC = cdiv(d.WS, 32);
+    const int64_t nPix = (int64_t)cdiv(d.ROWS, TR) * tilesC;
+    const int64_t nWg = cdiv64(nPix, 8) * 8 * coTiles;
+    PTMI_CHECK_ARG(nWg < (1ll << 31), "p8_conv3x3: too many tiles");
+    if (MT == 4)
+        hipLaunchKernelGGL(p8_conv3x3_kernel<4>, dim3((unsigned)nWg), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
+                           (const u16*)mask_ref, (u16*)y, cout, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
+    else
+        hipLaunchKernelGGL(p8_conv3x3_kernel<2>, dim3((unsigned)nWg), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
+                           (const u16*)mask_ref, (u16*)y, cout, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
+    PTMI_LAUNCH_CHECK("p8_conv3x3");
+    return 0;
+}
+
+}  // extern "C"

@@ -238,13 +238,15 @@ def test_training_step_runs_on_the_winograd_kernels():
 def test_map_beyond_the_winograd_32bit_offsets_runs_the_direct_kernel():
     """ptmi_conv3x3_wino_fwd / _wgrad reject maps whose per-workgroup byte offsets exceed 32 bits (about 8 M pixels at
     64 channels); ops routes such a layer to the direct kernels instead of surfacing the exception (ptmi_conv3x3_wino_fwd_fits /
-    _wgrad_fits).  64 -> 64 channels at 2048 x 4100: forward, dgrad and weight gradient against torch CPU fp32."""
+    _wgrad_fits).  The window is narrow -- the direct kernel addresses one image through 32-bit offsets as well -- and widest for
+    many channels: 128 -> 128 channels at 2000 x 2050 (4.1 M pixels: (2 x 128 + 8) channel planes exceed 4 GB, 128 + 128 do not):
+    forward, dgrad (direct kernel) and weight gradient (the Winograd-domain kernel, which reaches 8 M pixels) vs torch CPU fp32."""
     from probabilisticteacher_amd import _lib, ops
     torch.set_num_threads(max(2, min(__import__("os").cpu_count() or 2, 64)))
-    n, c, h, w = 1, 64, 2048, 4100
+    n, c, h, w = 1, 128, 2000, 2050
     lib = _lib.load()
     assert lib.ptmi_conv3x3_wino_fwd_fits(c, c, 1024, 2048) == 1 and lib.ptmi_conv3x3_wino_fwd_fits(c, c, h, w) == 0
-    assert lib.ptmi_conv3x3_wino_wgrad_fits(h, w) == 0 and lib.ptmi_conv3x3_wino_wgrad_fits(800, 1333) == 1
+    assert lib.ptmi_conv3x3_wino_wgrad_fits(h, w) == 1 and lib.ptmi_conv3x3_wino_wgrad_fits(4096, 4096) == 0
     assert ops._use_wino(c, c, (1024, 2048)) and not ops._use_wino(c, c, (h, w))
     x = torch.randn(n, c, h, w, generator=g(5))
     wt = torch.randn(c, c, 3, 3, generator=g(6)) * math.sqrt(2.0 / (9 * c))
