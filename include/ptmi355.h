@@ -101,6 +101,37 @@ int ptmi_conv3x3_wino_wgrad_fits(int h, int w);
 int64_t ptmi_conv3x3_wino_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n,
                             int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
+/* ------------------------------------------------------------------ bf16 STORAGE path of the conv stack ("P8", round 4)
+ * SOLVER.AMP.ENABLED (reference pt/engine/trainer.py:98; BASELINE configs[4]): under autocast the reference's cuDNN convolutions
+ * (pt/modeling/backbone/vgg.py:45-53,66-69, pt/modeling/proposal_generator/rpn.py:96) read and write bf16 activations.  The
+ * entry points below keep activations and activation gradients in bf16 in HBM and LDS, in the P8 layout
+ *     t[ceil(C/8)][ROWS = N (H + 1) + 1][WS = W + 1][8]  bf16
+ * pixel (n, r, c) at row n (H + 1) + 1 + r, column 1 + c; rows n (H + 1) and column 0 hold zeros (the convolution's zero padding
+ * is part of the tensor: a tap is a flat pixel offset, no kernel tests an image edge); every entry point writes them as zeros.
+ * Accumulation, bias, losses and weight gradients are fp32; a value is rounded to bf16 (nearest even) when it is stored.
+ * ptmi_p8_plane_pixels = ROWS * WS (a tensor holds ceil(C/8) * that many 16-byte pixel vectors). */
+int64_t ptmi_p8_plane_pixels(int n, int h, int w);
+/* fp32 NCHW <-> P8.  cb_out >= ceil(c/8) planes are written, channels >= c as zeros (the 3-channel image becomes the
+ * 16-channel input of the first layer). */
+int ptmi_p8_from_nchw(const float* x, void* y, int n, int c, int cb_out, int h, int w, ptmi_stream_t s);
+int ptmi_p8_to_nchw(const void* x, float* y, int n, int c, int h, int w, ptmi_stream_t s);
+/* MaxPool2d(2,2) forward / backward (vgg.py:59,71) on P8 tensors; backward as ptmi_maxpool2x2_bwd (first maximum, optional
+ * ReLU mask of the pooled activation). */
+int ptmi_p8_maxpool2x2_fwd(const void* x, void* y, int n, int c, int h, int w, ptmi_stream_t s);
+int ptmi_p8_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int n, int c, int h, int w, int relu_mask,
+                           ptmi_stream_t s);
+/* dz = dy * (y > 0) and out = a + b (fp32 sum, rounded once) over `pixels16` 16-byte pixel vectors of P8 tensors */
+int ptmi_p8_relu_bwd(const void* dy, const void* y, void* dz, int64_t pixels16, ptmi_stream_t s);
+int ptmi_p8_add(const void* a, const void* b, void* out, int64_t pixels16, ptmi_stream_t s);
+/* conv3x3 s1 p1 on P8 tensors: v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 out.  cin a multiple of 16, cout of 8.
+ * Weights packed by ptmi_p8_pack_weights (bf16, MFMA A-operand order [coTile][cin/16][tap][mt][64 lanes][8]; mode 0 forward,
+ * mode 1 dgrad = flipped taps, transposed channels; ptmi_p8_packed_elems bf16 elements).
+ * epilogue 0: + bias; 1: + bias, ReLU; 2: none (dgrad); 3: dgrad times (mask_ref > 0), mask_ref = the producing layer's stored
+ * activation (P8, cout channels). */
+int64_t ptmi_p8_packed_elems(int cin, int cout);
+int ptmi_p8_pack_weights(const float* w, void* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s);
+int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void* mask_ref, void* y, int n,
+                    int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s);
 /* dz = dy * (y > 0), elementwise (ReLU backward; F.relu_ at vgg.py:67). In-place allowed. */
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s);
 

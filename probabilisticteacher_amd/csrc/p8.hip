@@ -265,33 +265,28 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     const unsigned chunk_bytes_lo = (unsigned)((2 * PT * 16) & 0xFFFFFFFFll);      // < 4 GB (checked by the launcher)
     const unsigned wvoff = (unsigned)lane * 16u;
 
-    auto issue = [&](int chunk, int st) {
-        char* base = lds + st * G::STAGE;
-        const __amdgpu_buffer_rsrc_t rw = ptmi_rsrc(wp + ((size_t)(cot * nChunks + chunk) * G::WBYTES) / 2, (unsigned)G::WBYTES);
-#pragma unroll
-        for (int i = 0; i < G::WIN; ++i) {
-            const int piece = i * 4 + wave;
-            if (piece < G::WPIECES)
+    // descriptors of a chunk's weight slab and of its two input planes; a chunk beyond the last one gets EMPTY descriptors: its DMA
+    // instructions are still issued (every lane out of range: zero fill, no memory traffic) so that the loop has no tail copies
+    auto desc_w = [&](int chunk) {
+        return ptmi_rsrc(wp + ((size_t)(cot * nChunks + chunk) * G::WBYTES) / 2, chunk < nChunks ? (unsigned)G::WBYTES : 0u);
+    };
+    auto desc_x = [&](int chunk) { return ptmi_rsrc(x + (size_t)chunk * 2 * PT * 8, chunk < nChunks ? chunk_bytes_lo : 0u); };
+    auto dma = [&](auto d_c, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rx, char* base) {
+        constexpr int d = decltype(d_c)::value;
+        if constexpr (d < G::WIN) {
+            const int piece = d * 4 + wave;
+            if (4 * G::WIN == G::WPIECES || piece < G::WPIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (plds_void_t*)(base + piece * 1024), 16, (int)wvoff, piece * 1024, 0, 0);
-        }
-        const __amdgpu_buffer_rsrc_t rx = ptmi_rsrc(x + (size_t)chunk * 2 * PT * 8, chunk_bytes_lo);
-#pragma unroll
-        for (int i = 0; i < G::PIN; ++i)
+        } else if constexpr (d - G::WIN < G::PIN) {
+            constexpr int i = d - G::WIN;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G::WBYTES + (i * 4 + wave) * 1024), 16, (int)pvoff[i], 0, 0, 0);
+        }
     };
 
     // ---- operand addresses
     const int h = lane >> 5, px = lane & 31;
     const int a_off = lane * 16;                                                     // + stage + (tap MT + mt) 1024
     const int b_off = G::WBYTES + (h * G::PPL + wave * NTB * G::PC + px) * 16;       // + stage + ((nt + ky) PC + kx) 16
-
-    f32x16 acc[MT][NTB];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NTB; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
     // biases of the lane's channels: co = (cot MT + m) 32 + 8 q + 4 h + e, fetched before the first DMA (in-order vmcnt)
     f32x4 bv[MT][4];
@@ -307,10 +302,21 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
             }
     }
 
-    issue(0, 0);
+    {
+        const __amdgpu_buffer_rsrc_t rw = desc_w(0), rx = desc_x(0);
+        dma(std::integral_constant<int, 0>{}, rw, rx, lds);   dma(std::integral_constant<int, 1>{}, rw, rx, lds);
+        dma(std::integral_constant<int, 2>{}, rw, rx, lds);   dma(std::integral_constant<int, 3>{}, rw, rx, lds);
+        dma(std::integral_constant<int, 4>{}, rw, rx, lds);   dma(std::integral_constant<int, 5>{}, rw, rx, lds);
+        dma(std::integral_constant<int, 6>{}, rw, rx, lds);   dma(std::integral_constant<int, 7>{}, rw, rx, lds);
+        dma(std::integral_constant<int, 8>{}, rw, rx, lds);   dma(std::integral_constant<int, 9>{}, rw, rx, lds);
+        dma(std::integral_constant<int, 10>{}, rw, rx, lds);  dma(std::integral_constant<int, 11>{}, rw, rx, lds);
+        dma(std::integral_constant<int, 12>{}, rw, rx, lds);  dma(std::integral_constant<int, 13>{}, rw, rx, lds);
+        dma(std::integral_constant<int, 14>{}, rw, rx, lds);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+    f32x16 acc[MT][NTB];
     ptmi_bf16x8 A0[MT], B0[NTB], A1[MT], B1[NTB];
     auto read_a = [&](const char* st, int tap, int m) { return *(const volatile plds_bf16x8_t*)(st + a_off + (tap * MT + m) * 1024); };
     auto read_b = [&](const char* st, int tap, int n) {
@@ -327,41 +333,27 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     //   slots 10, 12, 14 (taps 0 .. 4) one DMA instruction each for the chunk after this one (its <= 15 instructions)
     //   tap 8, before slot 0      hand-over: own DMA pieces of the next chunk landed (vmcnt(0): they were issued >= 3 taps ago),
     //                             this k-step's operands in registers (lgkmcnt(0)), workgroup barrier
-    auto kstep = [&](auto tap_c, auto more_c, const ptmi_bf16x8 (&A)[MT], const ptmi_bf16x8 (&B)[NTB], ptmi_bf16x8 (&An)[MT],
-                     ptmi_bf16x8 (&Bn)[NTB], int cur, int chunk) {
+    // The very first k-step of a tile has a zero C operand (no 256 accumulator writes).
+    auto kstep = [&](auto tap_c, auto zc_c, const ptmi_bf16x8 (&A)[MT], const ptmi_bf16x8 (&B)[NTB], ptmi_bf16x8 (&An)[MT],
+                     ptmi_bf16x8 (&Bn)[NTB], int cur, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rx) {
         constexpr int TAP = decltype(tap_c)::value;
-        constexpr bool more = decltype(more_c)::value;            // a chunk follows this one
-        constexpr bool next = TAP < 8 || more;
+        constexpr bool ZC = decltype(zc_c)::value;
         const char* src = lds + (TAP < 8 ? cur : cur ^ 1) * G::STAGE;
+        char* dst = lds + (cur ^ 1) * G::STAGE;
         constexpr int NT_ = (TAP + 1) % 9;
-        if constexpr (TAP == 8 && more) {
+        if constexpr (TAP == 8) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         auto slot_fn = [&](auto j_c) {
             constexpr int J = decltype(j_c)::value;
             constexpr int m = J / NTB, n = J % NTB;
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], acc[m][n], 0, 0, 0);
-            if constexpr (next) {
-                if constexpr (J < MT) An[J] = read_a(src, NT_, J);
-                else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);
-            }
-            if constexpr (more && TAP < 5 && (J == 10 || J == 12 || J == 14)) {
-                // chunk + 1 into the other stage: everybody left it at the last hand-over
-                constexpr int d = TAP * 3 + (J - 10) / 2;
-                char* base = lds + (cur ^ 1) * G::STAGE;
-                if constexpr (d < G::WIN) {
-                    const int piece = d * 4 + wave;
-                    if (piece < G::WPIECES) {
-                        const __amdgpu_buffer_rsrc_t rw = ptmi_rsrc(wp + ((size_t)(cot * nChunks + chunk + 1) * G::WBYTES) / 2, (unsigned)G::WBYTES);
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (plds_void_t*)(base + piece * 1024), 16, (int)wvoff, piece * 1024, 0, 0);
-                    }
-                } else if constexpr (d - G::WIN < G::PIN) {
-                    constexpr int i = d - G::WIN;
-                    const __amdgpu_buffer_rsrc_t rx = ptmi_rsrc(x + (size_t)(chunk + 1) * 2 * PT * 8, chunk_bytes_lo);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G::WBYTES + (i * 4 + wave) * 1024), 16, (int)pvoff[i], 0, 0, 0);
-                }
-            }
+            if constexpr (ZC) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], (f32x16){0}, 0, 0, 0);
+            else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], acc[m][n], 0, 0, 0);
+            if constexpr (J < MT) An[J] = read_a(src, NT_, J);
+            else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);
+            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // chunk + 1 into the other stage: everybody left it at the
+                dma(std::integral_constant<int, TAP * 3 + (J - 10) / 2>{}, rw, rx, dst);           // last hand-over
             __builtin_amdgcn_sched_barrier(0);
         };
         slot_fn(std::integral_constant<int, 0>{});  slot_fn(std::integral_constant<int, 1>{});
@@ -376,43 +368,38 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     static_assert(G::NDMA <= 15, "the chunk's DMA instructions are issued three per tap over taps 0..4");
     static_assert(MT + NTB <= 10, "operand reads occupy the slots before the first DMA slot");
 
-    auto chunk_body = [&](auto more_c, int cur, int chunk) {
-        kstep(std::integral_constant<int, 0>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 1>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        kstep(std::integral_constant<int, 2>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 3>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        kstep(std::integral_constant<int, 4>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 5>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        kstep(std::integral_constant<int, 6>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 7>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        // nine k-steps per chunk: the register sets swap roles from chunk to chunk, so the loop body below is TWO chunks
-        kstep(std::integral_constant<int, 8>{}, more_c, A0, B0, A1, B1, cur, chunk);
+    const std::true_type T{};
+    const std::false_type F{};
+    // nine k-steps per chunk: the two operand register sets swap roles from chunk to chunk, so the loop body is TWO chunks
+    auto chunk_even = [&](auto zc_c, int chunk) {
+        const __amdgpu_buffer_rsrc_t rw = desc_w(chunk + 1), rx = desc_x(chunk + 1);
+        kstep(std::integral_constant<int, 0>{}, zc_c, A0, B0, A1, B1, 0, rw, rx);
+        kstep(std::integral_constant<int, 1>{}, F, A1, B1, A0, B0, 0, rw, rx);
+        kstep(std::integral_constant<int, 2>{}, F, A0, B0, A1, B1, 0, rw, rx);
+        kstep(std::integral_constant<int, 3>{}, F, A1, B1, A0, B0, 0, rw, rx);
+        kstep(std::integral_constant<int, 4>{}, F, A0, B0, A1, B1, 0, rw, rx);
+        kstep(std::integral_constant<int, 5>{}, F, A1, B1, A0, B0, 0, rw, rx);
+        kstep(std::integral_constant<int, 6>{}, F, A0, B0, A1, B1, 0, rw, rx);
+        kstep(std::integral_constant<int, 7>{}, F, A1, B1, A0, B0, 0, rw, rx);
+        kstep(std::integral_constant<int, 8>{}, F, A0, B0, A1, B1, 0, rw, rx);
     };
-    auto chunk_body_odd = [&](auto more_c, int cur, int chunk) {
-        kstep(std::integral_constant<int, 0>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        kstep(std::integral_constant<int, 1>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 2>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        kstep(std::integral_constant<int, 3>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 4>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        kstep(std::integral_constant<int, 5>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 6>{}, more_c, A1, B1, A0, B0, cur, chunk);
-        kstep(std::integral_constant<int, 7>{}, more_c, A0, B0, A1, B1, cur, chunk);
-        kstep(std::integral_constant<int, 8>{}, more_c, A1, B1, A0, B0, cur, chunk);
+    auto chunk_odd = [&](int chunk) {
+        const __amdgpu_buffer_rsrc_t rw = desc_w(chunk + 1), rx = desc_x(chunk + 1);
+        kstep(std::integral_constant<int, 0>{}, F, A1, B1, A0, B0, 1, rw, rx);
+        kstep(std::integral_constant<int, 1>{}, F, A0, B0, A1, B1, 1, rw, rx);
+        kstep(std::integral_constant<int, 2>{}, F, A1, B1, A0, B0, 1, rw, rx);
+        kstep(std::integral_constant<int, 3>{}, F, A0, B0, A1, B1, 1, rw, rx);
+        kstep(std::integral_constant<int, 4>{}, F, A1, B1, A0, B0, 1, rw, rx);
+        kstep(std::integral_constant<int, 5>{}, F, A0, B0, A1, B1, 1, rw, rx);
+        kstep(std::integral_constant<int, 6>{}, F, A1, B1, A0, B0, 1, rw, rx);
+        kstep(std::integral_constant<int, 7>{}, F, A0, B0, A1, B1, 1, rw, rx);
+        kstep(std::integral_constant<int, 8>{}, F, A1, B1, A0, B0, 1, rw, rx);
     };
-    {
-        const std::true_type T{};
-        const std::false_type F{};
-        int chunk = 0;
-        for (; chunk + 2 < nChunks; chunk += 2) {
-            chunk_body(T, 0, chunk);
-            chunk_body_odd(T, 1, chunk + 1);
-        }
-        if (chunk + 2 == nChunks) {
-            chunk_body(T, 0, chunk);
-            chunk_body_odd(F, 1, chunk + 1);
-        } else {
-            chunk_body(F, 0, chunk);
-        }
+    chunk_even(T, 0);
+    if (nChunks > 1) chunk_odd(1);
+    for (int chunk = 2; chunk < nChunks; chunk += 2) {
+        chunk_even(F, chunk);
+        if (chunk + 1 < nChunks) chunk_odd(chunk + 1);
     }
 
     // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 h = channel: a lane holds

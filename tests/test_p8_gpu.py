@@ -1,0 +1,152 @@
+"""GPU parity tests (pytest -m gpu) of the bf16-STORAGE convolution path (csrc/p8.hip, C ABI ptmi_p8_*; SOLVER.AMP.ENABLED,
+reference pt/engine/trainer.py:98, pt/modeling/backbone/vgg.py:45-72) through the C ABI.
+
+The statement: P8 tensors hold bf16-rounded values; a convolution multiplies them exactly (bf16 x bf16 fits fp32) and accumulates
+in fp32, so the fp32 accumulator equals torch CPU fp32 conv2d on the bf16-rounded operands up to summation order, and the stored
+result is that value rounded to bf16: |a - b| <= 2^-7 |b| + 1e-4 max|b| (one bf16 ulp is 2^-8 relative; a rounding boundary may
+be crossed).  Index-like outputs (pool argmax routing, ReLU masks, pad zeros) are exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rb(t):
+    """round to bf16 and back (nearest even)"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def bf16_close(a, b, what, extra=0.0):
+    a, b = a.detach().cpu().double().numpy(), b.detach().cpu().double().numpy()
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    err = np.abs(a - b)
+    tol = 2.0 ** -7 * np.abs(b) + (1e-4 + extra) * np.abs(b).max()
+    assert (err <= tol).all(), (f"{what}: max abs err {err.max():.3e}, max |ref| {np.abs(b).max():.3e}, {int((err > tol).sum())} of "
+                                f"{err.size} off, first at {np.argwhere(err > tol)[0]}")
+
+
+def pads_are_zero(t, n, h, w):
+    t = t.cpu()
+    rows = torch.arange(t.shape[1])
+    assert bool((t[:, rows % (h + 1) == 0] == 0).all()), "zero rows between images"
+    assert bool((t[:, :, 0] == 0).all()), "zero column"
+
+
+SHAPES = [  # n, cin, cout, h, w
+    (2, 16, 64, 5, 7),          # one chunk, MT = 2 (64-channel tile, 32-row workgroup tile)
+    (1, 32, 128, 19, 35),       # two chunks (register sets swap roles), MT = 4, two column tiles
+    (2, 64, 64, 24, 40),        # images stacked in the row dimension: a tile spans two images
+    (1, 128, 256, 13, 33),      # two channel tiles, eight chunks
+    (3, 16, 8, 4, 3),           # fewer channels than a tile, narrower than a piece
+    (1, 48, 72, 9, 83),         # odd chunk count (3), ragged channel tile
+    (2, 64, 128, 50, 83),       # the block-5 map
+    (1, 16, 24, 1, 1),          # a single pixel
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
+def test_p8_roundtrip_and_conv_forward_dgrad(n, cin, cout, h, w):
+    from probabilisticteacher_amd import p8
+    x = rb(torch.randn(n, cin, h, w, generator=g(1)))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g(2)) * math.sqrt(2.0 / (9 * cin)))
+    b = torch.randn(cout, generator=g(3)) * 0.1
+    xp = p8.from_nchw(x.to(DEV))
+    assert xp.shape == ((cin + 7) // 8, n * (h + 1) + 1, w + 1, 8)
+    pads_are_zero(xp, n, h, w)
+    assert torch.equal(p8.to_nchw(xp, n, cin, h, w).cpu(), x), "bf16-representable values survive the round trip exactly"
+    # forward, both epilogues
+    for epi in (0, 1):
+        yr = F.conv2d(x, wt, b, padding=1)
+        if epi == 1:
+            yr = F.relu(yr)
+        yp = p8.conv3x3_raw(xp, p8.pack_weights(wt.to(DEV), 0), b.to(DEV), None, n, cin, cout, h, w, epi)
+        pads_are_zero(yp, n, h, w)
+        bf16_close(p8.to_nchw(yp, n, cout, h, w), yr, f"forward epilogue {epi}")
+    # dgrad: dX = conv(dY, W^T rotated); the P8 kernel wants its input channel count (= cout here) padded to 16
+    if cout % 16 == 0:
+        gy = rb(torch.randn(n, cout, h, w, generator=g(4)))
+        xr = x.clone().requires_grad_()
+        F.conv2d(xr, wt, None, padding=1).backward(gy)
+        gp = p8.from_nchw(gy.to(DEV))
+        wpd = p8.pack_weights(wt.to(DEV), 1)
+        dx = p8.conv3x3_raw(gp, wpd, None, None, n, cout, cin, h, w, 2)
+        pads_are_zero(dx, n, h, w)
+        bf16_close(p8.to_nchw(dx, n, cin, h, w), xr.grad, "dgrad")
+        # epilogue 3: times the ReLU mask of the producer (a post-ReLU activation with exact zeros)
+        act = rb(torch.relu(torch.randn(n, cin, h, w, generator=g(5))))
+        dxm = p8.conv3x3_raw(gp, wpd, None, p8.from_nchw(act.to(DEV)), n, cout, cin, h, w, 3)
+        pads_are_zero(dxm, n, h, w)
+        bf16_close(p8.to_nchw(dxm, n, cin, h, w), xr.grad * (act > 0), "dgrad + mask")
+
+
+def test_p8_stem_layer_three_channels_padded_to_sixteen():
+    """conv1_1 (vgg.py:44: 3 -> 64): the image becomes a 16-channel P8 tensor (13 zero channels) and runs on the MFMA kernel"""
+    from probabilisticteacher_amd import p8
+    n, h, w = 2, 37, 53
+    x = rb(torch.randn(n, 3, h, w, generator=g(7)) * 50)
+    wt = rb(torch.randn(64, 3, 3, 3, generator=g(8)) * 0.2)
+    b = torch.randn(64, generator=g(9))
+    xp = p8.from_nchw(x.to(DEV), cb_out=2)
+    assert xp.shape[0] == 2 and bool((xp[1] == 0).all()) and bool((xp[0, :, :, 3:] == 0).all())
+    yp = p8.conv3x3_raw(xp, p8.pack_weights(wt.to(DEV), 0), b.to(DEV), None, n, 16, 64, h, w, 1)
+    bf16_close(p8.to_nchw(yp, n, 64, h, w), F.relu(F.conv2d(x, wt, b, padding=1)), "stem")
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 16, 8, 10), (1, 64, 7, 9), (3, 8, 2, 2), (2, 128, 50, 83)])
+def test_p8_maxpool_forward_backward_exact(n, c, h, w):
+    from probabilisticteacher_amd import p8
+    x = rb(torch.relu(torch.randn(n, c, h, w, generator=g(11))))
+    x[:, :, : h // 2 * 2 : 2, : w // 2 * 2 : 2] = x[:, :, 1 : h // 2 * 2 : 2, : w // 2 * 2 : 2]        # ties: first maximum wins
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = rb(torch.randn(yr.shape, generator=g(12)))
+    yr.backward(gy)
+    xp = p8.from_nchw(x.to(DEV))
+    yp = p8.maxpool_fwd(xp, n, c, h, w)
+    pads_are_zero(yp, n, h // 2, w // 2)
+    assert torch.equal(p8.to_nchw(yp, n, c, h // 2, w // 2).cpu(), yr.detach())
+    gp = p8.from_nchw(gy.to(DEV))
+    for relu_mask in (False, True):
+        dx = p8.maxpool_bwd(xp, gp, n, c, h, w, relu_mask)
+        pads_are_zero(dx, n, h, w)
+        want = xr.grad * (x > 0) if relu_mask else xr.grad
+        assert torch.equal(p8.to_nchw(dx, n, c, h, w).cpu(), want), f"pool backward (relu_mask={relu_mask})"
+    # relu_bwd and add
+    y = rb(torch.randn(n, c, h, w, generator=g(13)))
+    y[0, 0, 0, 0] = -0.0
+    d = rb(torch.randn(n, c, h, w, generator=g(14)))
+    dz = p8.relu_bwd(p8.from_nchw(d.to(DEV)), p8.from_nchw(y.to(DEV)))
+    assert torch.equal(p8.to_nchw(dz, n, c, h, w).cpu(), d * (y > 0))
+    s = p8.add(p8.from_nchw(d.to(DEV)), p8.from_nchw(y.to(DEV)))
+    assert torch.equal(p8.to_nchw(s, n, c, h, w).cpu(), rb(d + y))
+
+
+@pytest.mark.parametrize("name,cin,cout,h,w", [("conv1_2", 64, 64, 800, 1333), ("conv2_2", 128, 128, 400, 666),
+                                               ("conv3_2", 256, 256, 200, 333), ("conv4_2", 512, 512, 100, 166),
+                                               ("conv5_2", 512, 512, 50, 83)])
+def test_p8_conv_full_size_layers(name, cin, cout, h, w):
+    """the 1333 x 800 layer shapes (n = 2): forward + ReLU and masked dgrad against torch CPU fp32 on the rounded operands"""
+    import os
+    from probabilisticteacher_amd import p8
+    torch.set_num_threads(max(2, min(os.cpu_count() or 2, 64)))
+    n = 2
+    x = rb(torch.relu(torch.randn(n, cin, h, w, generator=g(21))))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g(22)) * math.sqrt(2.0 / (9 * cin)))
+    b = torch.randn(cout, generator=g(23)) * 0.1
+    xp = p8.from_nchw(x.to(DEV))
+    yp = p8.conv3x3_raw(xp, p8.pack_weights(wt.to(DEV), 0), b.to(DEV), None, n, cin, cout, h, w, 1)
+    bf16_close(p8.to_nchw(yp, n, cout, h, w), F.relu(F.conv2d(x, wt, b, padding=1)), f"{name} forward")
+    gy = rb(torch.randn(n, cout, h, w, generator=g(24)))
+    xr = x.clone().requires_grad_()
+    F.conv2d(xr, wt, None, padding=1).backward(gy)
+    dx = p8.conv3x3_raw(p8.from_nchw(gy.to(DEV)), p8.pack_weights(wt.to(DEV), 1), None, xp, n, cout, cin, h, w, 3)
+    bf16_close(p8.to_nchw(dx, n, cin, h, w), xr.grad * (x > 0), f"{name} dgrad + mask")

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""tools/kbench_p8.py -- micro-benchmark of the bf16-storage (P8) conv kernels on the BASELINE shapes, HIP-event timed.
+
+    python tools/kbench_p8.py [--n 48] [--which conv,dgrad,wgrad,pool] [--iters 5] [--layers conv3_2,conv4_2]
+
+One line per layer: direct-convolution TFLOP/s and the fraction of the 2.5 PFLOP/s dense bf16 MFMA peak."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from probabilisticteacher_amd import _lib, ops, p8  # noqa: E402
+
+PEAK = 2500.0
+LAYERS = [  # name, cin, cout, h, w
+    ("conv1_1", 16, 64, 800, 1333), ("conv1_2", 64, 64, 800, 1333), ("conv2_1", 64, 128, 400, 666),
+    ("conv2_2", 128, 128, 400, 666), ("conv3_1", 128, 256, 200, 333), ("conv3_2", 256, 256, 200, 333),
+    ("conv4_1", 256, 512, 100, 166), ("conv4_2", 512, 512, 100, 166), ("conv5_1", 512, 512, 50, 83),
+]
+
+
+def timeit(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=48)
+    ap.add_argument("--which", default="conv,dgrad,wgrad")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--layers", default="")
+    a = ap.parse_args()
+    dev = "cuda:0"
+    which = a.which.split(",")
+    sel = a.layers.split(",") if a.layers else None
+    for name, cin, cout, h, w in LAYERS:
+        if sel and name not in sel:
+            continue
+        n = a.n
+        # random bf16 data (not zeros: DVFS), written straight into the P8 storage incl. the pads -- timing only
+        x = (torch.randn((cin // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * 0.5).to(torch.bfloat16)
+        wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
+        b = torch.zeros(cout, device=dev)
+        fl = 2.0 * 9 * cin * cout * h * w * n
+        if "conv" in which:
+            wp = p8.pack_weights(wt, 0)
+            ms = timeit(lambda: p8.conv3x3_raw(x, wp, b, None, n, cin, cout, h, w, 1), a.iters)
+            print(f"{name:8s} fwd   n={n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+        if "dgrad" in which and cout % 16 == 0 and cin % 8 == 0 and cin >= 64:
+            dy = (torch.randn((cout // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * 0.5).to(torch.bfloat16)
+            wpd = p8.pack_weights(wt, 1)
+            ms = timeit(lambda: p8.conv3x3_raw(dy, wpd, None, x, n, cout, cin, h, w, 3), a.iters)
+            print(f"{name:8s} dgrad n={n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+            del dy
+        if "wgrad" in which and hasattr(p8, "wgrad") and cin >= 64:
+            dy = (torch.randn((cout // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * 0.5).to(torch.bfloat16)
+            ms = timeit(lambda: p8.wgrad(x, dy, n, cin, cout, h, w), a.iters)
+            print(f"{name:8s} wgrad n={n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+            del dy
+        if "pool" in which and name in ("conv1_2", "conv2_2", "conv3_2", "conv4_2"):
+            xo = (torch.randn((cout // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * 0.5).to(torch.bfloat16)
+            ms = timeit(lambda: p8.maxpool_fwd(xo, n, cout, h, w), a.iters)
+            gb = xo.numel() * 2 * 1.25 / 1e9
+            print(f"{name:8s} pool  n={n} {ms:9.3f} ms  {gb / ms:7.2f} TB/s", flush=True)
+            del xo
+        del x
+
+
+if __name__ == "__main__":
+    main()
