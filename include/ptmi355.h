@@ -132,6 +132,13 @@ int64_t ptmi_p8_packed_elems(int cin, int cout);
 int ptmi_p8_pack_weights(const float* w, void* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s);
 int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void* mask_ref, void* y, int n,
                     int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s);
+/* Weight + bias gradient of the conv above from its P8 input x (cin channels) and P8 output gradient dy (cout channels; pads
+ * zero): dW (Cout, Cin, 3, 3) and db (Cout) in fp32 (same contract as ptmi_conv3x3_wgrad: split partials in a caller-allocated
+ * workspace of ptmi_p8_wgrad_ws_floats floats, summed in a fixed order; accumulate != 0 adds to dW / db).  The contraction runs
+ * over pixels: operands reach the MFMA through ds_read_b64_tr_b16; db is the product of dy with an all-ones operand. */
+int64_t ptmi_p8_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
+int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout,
+                  int h, int w, int accumulate, ptmi_stream_t s);
 /* dz = dy * (y > 0), elementwise (ReLU backward; F.relu_ at vgg.py:67). In-place allowed. */
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s);
 

@@ -456,6 +456,221 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
 
 inline int p8_mt(int cout) { return cout <= 64 ? 2 : 4; }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][ci][tap] = sum over ALL flat pixels f of dY[co][f] X[ci][f + (ky - 1) WS + (kx - 1)]   (pads of dY are zero, pads of X are
+// the convolution's zero padding: a plain GEMM M = co, N = ci, K = pixels with nine shifted B operands).  The contraction runs
+// over PIXELS while the layout packs CHANNELS: operands come out of LDS through ds_read_b64_tr_b16 -- a 16-lane group hands in
+// the addresses of sixteen 8-byte pieces (4 pixels x 4 channel quads) and each lane receives 4 consecutive PIXELS of one channel;
+// two of them are a lane's 8 k values.  (Semantics measured with tools/exp/tr16_probe.hip: result lane i, element j =
+// element i % 4 of the piece addressed by lane 4 j + i / 4 of the group.)
+//   workgroup = 8 waves (two per SIMD, <= 256 registers each) = 128 co x 64 ci x 9 taps; wave (cw, iw, tg): co half, ci half, taps
+//   0..4 / 5..8 -- the second tap group's fifth accumulator pair multiplies dY by an all-ones operand: every column of it is the
+//   BIAS gradient sum_f dY[co][f], for free and with the two groups issuing 10 MFMAs per k-step each;
+//   K tile = 4 rows x 32 columns of the (ROWS x WS) grid = 8 k-steps of 16 pixels; LDS stage = dY [16 planes][128 px] (plane
+//   pitch + 64 B: the four planes a 32-lane read touches sit on disjoint bank quarters) + X [8 planes][6 x 34 px] (pitch 3264 B:
+//   the same by itself); two stages, the next tile's DMA issued one instruction per k-step;
+//   split-K over contiguous tile ranges, fp32 partials [split][tap][co][ci] (+ [split][co] for db), fixed-order reduction.
+constexpr int GT = 512;                      // threads
+constexpr int G_CO = 128, G_CI = 64;
+constexpr int G_DYP = 128 * 16 + 64;         // dY plane pitch in LDS (bytes)
+constexpr int G_XPL = 6 * 34;                // X patch pixels per plane
+constexpr int G_XP = G_XPL * 16;             // X plane pitch (3264 B = 816 dwords = 48 banks mod 64)
+constexpr int G_DYB = 16 * G_DYP;            // 33792
+constexpr int G_XB = 26 * 1024;              // 8 planes x 204 pieces = 1632 pieces, padded to 26 wave instructions
+constexpr int G_STAGE = G_DYB + G_XB;        // 60416
+
+typedef short p8_s4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) p8_s4 plds_s4_t;
+struct p8_s4x2 { p8_s4 lo, hi; };
+
+__global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ ws,
+                                                         float* __restrict__ wsb, int Cin, int Cout, int WS, int ROWS, long long PT,
+                                                         int ciTiles, int S, int tilesC, int nTiles)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * G_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, iw = (wave >> 1) & 1, tg = wave >> 2;
+    // workgroup -> (channel-tile pair, split): the splits of a pair share nothing but the weights they add up to
+    const int pair = blockIdx.x / S, split = blockIdx.x - pair * S;
+    const int cot = pair / ciTiles, cit = pair - cot * ciTiles;
+    const int t0 = (int)((long long)nTiles * split / S), t1 = (int)((long long)nTiles * (split + 1) / S);
+
+    const unsigned x_bytes = (unsigned)((long long)(Cin / 8) * PT * 16), dy_bytes = (unsigned)((long long)(Cout / 8) * PT * 16);
+    const __amdgpu_buffer_rsrc_t rx = ptmi_rsrc(x, x_bytes), rdy = ptmi_rsrc(dy, dy_bytes);
+
+    // ---- DMA pieces of this lane: dY 4 (wave w: planes 2 w, 2 w + 1; 128 pixels each), X 4 (pieces 64 (4 w + i) + lane of 1632)
+    int dy_row[4], dy_col[4];
+    unsigned dy_plane[4];
+    bool dy_chan[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int plane = 2 * wave + (i >> 1), pxl = (i & 1) * 64 + lane;
+        dy_row[i] = pxl >> 5;
+        dy_col[i] = pxl & 31;
+        const int pg = cot * 16 + plane;
+        dy_chan[i] = pg * 8 < Cout;
+        dy_plane[i] = (unsigned)((long long)pg * PT * 16);
+    }
+    int x_row[4], x_col[4];
+    unsigned x_plane[4];
+    bool x_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (4 * wave + i) * 64 + lane;
+        const int plane = q / G_XPL, slot = q - plane * G_XPL;
+        x_row[i] = slot / 34 - 1;
+        x_col[i] = slot % 34 - 1;
+        const int pg = cit * 8 + plane;
+        x_ok[i] = q < 8 * G_XPL && 4 * wave + i < 26 && pg * 8 < Cin;
+        x_plane[i] = (unsigned)((long long)pg * PT * 16);
+    }
+    auto issue = [&](auto i_c, int tile, int st) {
+        constexpr int I = decltype(i_c)::value;                 // 0..3 dY, 4..7 X
+        const int R0 = (tile / tilesC) * 4, C0 = (tile % tilesC) * 32;
+        char* base = lds + st * G_STAGE;
+        if constexpr (I < 4) {
+            const int r = R0 + dy_row[I], c = C0 + dy_col[I];
+            const bool ok = dy_chan[I] && r < ROWS && c < WS && tile < t1;
+            const unsigned off = ok ? dy_plane[I] + (unsigned)(r * WS + c) * 16u : 0xFFFFFFFFu;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (plds_void_t*)(base + (2 * wave + (I >> 1)) * G_DYP + (I & 1) * 1024), 16, (int)off, 0, 0, 0);
+        } else {
+            constexpr int i = I - 4;
+            if (4 * wave + i < 26) {                             // (wave-uniform)
+                const long long flat = (long long)(R0 + x_row[i]) * WS + (C0 + x_col[i]);
+                const bool ok = x_ok[i] && flat >= 0 && flat < PT && tile < t1;
+                const unsigned off = ok ? x_plane[i] + (unsigned)flat * 16u : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G_DYB + (4 * wave + i) * 1024), 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- operand addresses (ds_read_b64_tr_b16): lane a of a 16-lane group addresses pixel (a >> 2), channel quad (a & 3) of the
+    // group's 16 channels; group gq = (lane >> 4): rows 16 (gq & 1) .. + 15 of the 32-row operand, k half gq >> 1
+    const int a = lane & 15, gq = lane >> 4, kh = gq >> 1;
+    const int lane_px = 8 * kh + (a >> 2);                                               // + 16 s + 4 u
+    const int lane_pl = 2 * (gq & 1) + ((a & 3) >> 1);                                    // plane within the 32-channel tile
+    const int a_base = (4 * (2 * cw) + lane_pl) * G_DYP + lane_px * 16 + (a & 1) * 8;      // + t 4 G_DYP + s 256 + u 64
+    int b_base[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int tap = min(tg * 5 + t, 8);
+        b_base[t] = G_DYB + (4 * iw + lane_pl) * G_XP + ((tap / 3) * 34 + tap % 3 + lane_px) * 16 + (a & 1) * 8;   // + ((s >> 1) 34 + 16 (s & 1) + 4 u) 16
+    }
+    const bool ones_slot = tg == 1;                                                       // (wave-uniform) slot 4 = bias gradient
+
+    f32x16 acc[2][5];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
+
+    auto rd = [&](const char* p) {
+        p8_s4x2 v;
+        v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plds_s4_t*)p);
+        v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plds_s4_t*)(p + 64));
+        return __builtin_bit_cast(ptmi_bf16x8, v);
+    };
+    const ptmi_bf16x8 ones = __builtin_bit_cast(ptmi_bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+
+    if (t0 < t1) {
+        issue(std::integral_constant<int, 0>{}, t0, 0); issue(std::integral_constant<int, 1>{}, t0, 0);
+        issue(std::integral_constant<int, 2>{}, t0, 0); issue(std::integral_constant<int, 3>{}, t0, 0);
+        issue(std::integral_constant<int, 4>{}, t0, 0); issue(std::integral_constant<int, 5>{}, t0, 0);
+        issue(std::integral_constant<int, 6>{}, t0, 0); issue(std::integral_constant<int, 7>{}, t0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    for (int tile = t0; tile < t1; ++tile) {
+        const int st = (tile - t0) & 1;
+        const char* base = lds + st * G_STAGE;
+        const int R0 = (tile / tilesC) * 4, C0 = (tile % tilesC) * 32;
+        auto kstep = [&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            // the next tile's pieces, one DMA instruction per k-step (into the other stage: everybody left it at the last barrier)
+            issue(std::integral_constant<int, s>{}, tile + 1, st ^ 1);
+            // k-steps whose 16 pixels lie beyond the grid carry only zeros in dY: skip them (wave-uniform)
+            if (R0 + (s >> 1) < ROWS && C0 + 16 * (s & 1) < WS) {
+                const ptmi_bf16x8 A0 = rd(base + a_base + s * 256), A1 = rd(base + a_base + 4 * G_DYP + s * 256);
+                ptmi_bf16x8 B[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) B[t] = rd(base + b_base[t] + ((s >> 1) * 34 + 16 * (s & 1)) * 16);
+                if (ones_slot) B[4] = ones;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B[t], acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B[t], acc[1][t], 0, 0, 0);
+                }
+            }
+        };
+        kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{});
+        kstep(std::integral_constant<int, 2>{}); kstep(std::integral_constant<int, 3>{});
+        kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+        kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- partials: C layout column = lane & 31 = ci, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = co
+    const int ci = cit * G_CI + iw * 32 + (lane & 31);
+    const int co0 = cot * G_CO + cw * 64 + 4 * (lane >> 5);
+    float* wsp = ws + (size_t)split * 9 * Cout * Cin;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int tap = tg * 5 + t;
+            if (tap < 9) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (co < Cout && ci < Cin) wsp[((size_t)tap * Cout + co) * Cin + ci] = acc[m][t][r];
+                }
+            } else if (cit == 0 && iw == 0 && (lane & 31) == 0) {          // bias gradient: any one column of the ones product
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (co < Cout) wsb[(size_t)split * Cout + co] = acc[m][t][r];
+                }
+            }
+        }
+}
+
+// dW (Cout, Cin, 3, 3) = sum of the split partials in split order (+ dW if accumulate); db likewise
+__global__ __launch_bounds__(256) void p8_wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ wsb, float* __restrict__ dw,
+                                                              float* __restrict__ db, int Cout, int Cin, int S, int accumulate)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t cc = (int64_t)Cout * Cin;
+    if (i < cc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            float v = 0.f;
+            for (int s = 0; s < S; ++s) v += ws[((int64_t)s * 9 + tap) * cc + i];
+            float* o = dw + i * 9 + tap;
+            *o = accumulate ? *o + v : v;
+        }
+    }
+    if (db && i < Cout) {
+        float v = 0.f;
+        for (int s = 0; s < S; ++s) v += wsb[(int64_t)s * Cout + i];
+        db[i] = accumulate ? db[i] + v : v;
+    }
+}
+
+inline int p8_wgrad_splits(int n, int cin, int cout, int h, int w)
+{
+    const P8Dims d = p8_dims(n, h, w);
+    const int pairs = cdiv(cout, G_CO) * cdiv(cin, G_CI);
+    const int64_t tiles = (int64_t)cdiv(d.ROWS, 4) * cdiv(d.WS, 32);
+    int S = cdiv(256, pairs);
+    if (S > tiles) S = (int)tiles;
+    return S < 1 ? 1 : S;
+}
+
 }  // namespace
 
 extern "C" {
@@ -568,6 +783,35 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
         hipLaunchKernelGGL(p8_conv3x3_kernel<2>, dim3((unsigned)nWg), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
                            (const u16*)mask_ref, (u16*)y, cout, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
     PTMI_LAUNCH_CHECK("p8_conv3x3");
+    return 0;
+}
+
+int64_t ptmi_p8_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
+{
+    return (int64_t)p8_wgrad_splits(n, cin, cout, h, w) * (9 * (int64_t)cout * cin + cout);
+}
+
+int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h, int w,
+                  int accumulate, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_wgrad: bad args");
+    PTMI_CHECK_ARG(cin % 8 == 0 && cout % 8 == 0, "p8_wgrad: channel counts must be multiples of 8 (cin %d cout %d)", cin, cout);
+    const P8Dims d = p8_dims(n, h, w);
+    PTMI_CHECK_ARG((int64_t)(cin / 8) * d.PT * 16 < (1ll << 32) && (int64_t)(cout / 8) * d.PT * 16 < (1ll << 32) && d.PT < (1ll << 31) / 2,
+                   "p8_wgrad: tensors beyond the 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d)", n, cin, cout, h, w);
+    const int S = p8_wgrad_splits(n, cin, cout, h, w);
+    const int coTiles = cdiv(cout, G_CO), ciTiles = cdiv(cin, G_CI), tilesC = cdiv(d.WS, 32);
+    const int64_t nTiles = (int64_t)cdiv(d.ROWS, 4) * tilesC;
+    PTMI_CHECK_ARG(nTiles < (1ll << 31), "p8_wgrad: too many tiles");
+    float* wsb = ws + (size_t)S * 9 * cout * cin;
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(p8_wgrad_kernel, dim3((unsigned)(coTiles * ciTiles * S)), dim3(GT), 0, st, (const u16*)x, (const u16*)dy, ws, wsb, cin,
+                       cout, d.WS, d.ROWS, (long long)d.PT, ciTiles, S, tilesC, (int)nTiles);
+    PTMI_LAUNCH_CHECK("p8_wgrad");
+    const int64_t cc = (int64_t)cout * cin;
+    hipLaunchKernelGGL(p8_wgrad_reduce_kernel, dim3((unsigned)cdiv64(cc > cout ? cc : cout, 256)), dim3(256), 0, st, ws, wsb, dw, db, cout, cin, S,
+                       accumulate);
+    PTMI_LAUNCH_CHECK("p8_wgrad_reduce");
     return 0;
 }
 

@@ -101,3 +101,14 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(a)
     _lib.call("ptmi_p8_add", ops._ptr(a), ops._ptr(b), ops._ptr(out), a.numel() // 8, ops._stream())
     return out
+
+
+def wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, cin: int, cout: int, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dW (cout, cin, 3, 3), db (cout,)) fp32 from the layer's P8 input and P8 output gradient; cin = x's padded channel count"""
+    dw = torch.empty((cout, cin, 3, 3), dtype=F32, device=x.device)
+    db = torch.empty(cout, dtype=F32, device=x.device)
+    ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+    with ops._prof("p8_wgrad", 2.0 * 9 * cin * cout * h * w * n):
+        _lib.call("ptmi_p8_wgrad", ops._ptr(_chk(x, cin, n, h, w, "p8 wgrad input")), ops._ptr(_chk(dy, cout, n, h, w, "p8 wgrad grad")),
+                  ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0, ops._stream())
+    return dw, db

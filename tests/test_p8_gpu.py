@@ -150,3 +150,51 @@ def test_p8_conv_full_size_layers(name, cin, cout, h, w):
     F.conv2d(xr, wt, None, padding=1).backward(gy)
     dx = p8.conv3x3_raw(p8.from_nchw(gy.to(DEV)), p8.pack_weights(wt.to(DEV), 1), None, xp, n, cout, cin, h, w, 3)
     bf16_close(p8.to_nchw(dx, n, cin, h, w), xr.grad * (x > 0), f"{name} dgrad + mask")
+
+
+WG_SHAPES = [  # n, cin, cout, h, w
+    (2, 64, 128, 5, 7),         # one channel-tile pair, fewer K tiles than workgroup slots
+    (1, 64, 64, 19, 35),        # half a co tile; two K-tile columns, the second with 4 valid columns (k-step skipped)
+    (2, 128, 256, 24, 40),      # 2 x 2 channel tiles; images stacked in the K range
+    (3, 72, 40, 4, 3),          # ragged channel tiles both ways
+    (1, 256, 128, 50, 83),      # the block-5 map, four ci tiles
+    (1, 16, 8, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", WG_SHAPES)
+def test_p8_wgrad_and_bias_grad(n, cin, cout, h, w):
+    from probabilisticteacher_amd import p8
+    x = rb(torch.relu(torch.randn(n, cin, h, w, generator=g(31))))
+    gy = rb(torch.randn(n, cout, h, w, generator=g(32)))
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    br = torch.zeros(cout, requires_grad=True)
+    F.conv2d(x, wr, br, padding=1).backward(gy)
+    dw, db = p8.wgrad(p8.from_nchw(x.to(DEV)), p8.from_nchw(gy.to(DEV)), n, cin, cout, h, w)
+    # fp32 accumulation of exact bf16 products: the fp32 bar (summation order only)
+    s = float(wr.grad.abs().max())
+    err = float((dw.cpu() - wr.grad).abs().max())
+    assert err <= 1e-4 * s + 1e-6, f"dW: max abs err {err:.3e} vs scale {s:.3e}"
+    sb = float(br.grad.abs().max())
+    errb = float((db.cpu() - br.grad).abs().max())
+    assert errb <= 1e-4 * sb + 1e-5, f"db: max abs err {errb:.3e} vs scale {sb:.3e}"
+    dw2, db2 = p8.wgrad(p8.from_nchw(x.to(DEV)), p8.from_nchw(gy.to(DEV)), n, cin, cout, h, w)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "fixed-order split reduction: bitwise reproducible"
+
+
+@pytest.mark.parametrize("name,cin,cout,h,w", [("conv3_2", 256, 256, 200, 333), ("conv4_2", 512, 512, 100, 166),
+                                               ("conv5_2", 512, 512, 50, 83), ("conv3_1", 128, 256, 200, 333)])
+def test_p8_wgrad_full_size_layers(name, cin, cout, h, w):
+    import os
+    from probabilisticteacher_amd import p8
+    torch.set_num_threads(max(2, min(os.cpu_count() or 2, 64)))
+    n = 2
+    x = rb(torch.relu(torch.randn(n, cin, h, w, generator=g(41))))
+    gy = rb(torch.randn(n, cout, h, w, generator=g(42)))
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    br = torch.zeros(cout, requires_grad=True)
+    F.conv2d(x, wr, br, padding=1).backward(gy)
+    dw, db = p8.wgrad(p8.from_nchw(x.to(DEV)), p8.from_nchw(gy.to(DEV)), n, cin, cout, h, w)
+    s, sb = float(wr.grad.abs().max()), float(br.grad.abs().max())
+    assert float((dw.cpu() - wr.grad).abs().max()) <= 1e-4 * s, f"{name} dW"
+    assert float((db.cpu() - br.grad).abs().max()) <= 1e-4 * sb, f"{name} db"
