@@ -82,6 +82,7 @@ def cpu_baseline(h, w, K, seed=0, student_only=False):
 
 PMC_PROFILE = "profiles/r03_bench_b16_pmc_by_kernel.json"
 DOMINANT = "conv3x3_wino_kernel"          # the kernel the roofline object describes (its rocprofv3 name contains this)
+DOMINANT_AMP = "p8_conv3x3_kernel"        # ... with --amp: the bf16-storage forward / dgrad kernel
 
 
 def committed_pmc_traffic():
@@ -112,12 +113,13 @@ def measured_pmc_traffic(args):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     tot, disp = {}, 0
+    dominant = DOMINANT_AMP if args.amp else DOMINANT
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ptmi_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
                "--pmc-traffic", "off", "--per-gpu-batch", str(args.per_gpu_batch), "--height", str(args.height),
-               "--width", str(args.width)] + (["--student-only"] if args.student_only else [])
+               "--width", str(args.width)] + (["--student-only"] if args.student_only else []) + (["--amp"] if args.amp else [])
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=420)
@@ -127,16 +129,16 @@ def measured_pmc_traffic(args):
         n, val = 0, 0.0
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
-                if DOMINANT in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                if dominant in row["Kernel_Name"] and row["Counter_Name"] == counter:
                     val += float(row["Counter_Value"])
                     n += 1
         shutil.rmtree(d, ignore_errors=True)
         if r.returncode != 0 or n == 0:
-            return None, f"rocprofv3 {counter} pass: rc {r.returncode}, {n} dispatches of {DOMINANT}: {r.stdout[-300:]!r}"
+            return None, f"rocprofv3 {counter} pass: rc {r.returncode}, {n} dispatches of {dominant}: {r.stdout[-300:]!r}"
         tot[counter], disp = val, n
     return ((2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / disp,
             f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 1 warm-up + 1 step each, "
-            f"{disp} dispatches of {DOMINANT}; FETCH_SIZE x2 per the gfx950 correction)")
+            f"{disp} dispatches of {dominant}; FETCH_SIZE x2 per the gfx950 correction)")
 
 
 def main():
@@ -152,9 +154,10 @@ def main():
                     help="BASELINE configs[1]: supervised student fwd/bwd only (burn-in step) on 2 x per-gpu-batch images; "
                          "use --per-gpu-batch 4 for the quoted batch of 8")
     ap.add_argument("--amp", action="store_true",
-                    help="NOT the headline metric: SOLVER.AMP.ENABLED (BASELINE configs[4] numerics) -- conv / FC operands "
-                         "rounded to bf16 inside the ptmi_*_bf16 kernels (v_mfma_f32_32x32x16_bf16), fp32 accumulation, fp32 "
-                         "losses / optimiser; reported against the dense bf16 MFMA peak")
+                    help="NOT the headline metric: SOLVER.AMP.ENABLED (BASELINE configs[4] numerics) -- bf16 activations and "
+                         "activation gradients in HBM / LDS for the 3x3 conv stack (ptmi_p8_*, v_mfma_f32_32x32x16_bf16), bf16 "
+                         "operands for the FC GEMMs, fp32 accumulation, fp32 losses / optimiser; reported against the dense bf16 "
+                         "MFMA peak")
     ap.add_argument("--grad-reduce", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: the bucketed gradient exchange as all-reduce or as reduce-scatter + all-gather (engine/flat.py)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
@@ -250,19 +253,16 @@ def main():
         value = world * 2 * B * args.steps / dt             # burn-in step: label_q + label_k = 2B images as well
         srt = sorted(step_ms)
         median = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-        if args.amp:
-            traffic, traffic_src = None, "not collected for the bf16 kernels"
-        else:
-            traffic, traffic_src = (measured_pmc_traffic(args) if args.pmc_traffic == "auto" and world == 1
-                                    else (None, "not measured in this run (--pmc-traffic off or N > 1)"))
-            if traffic is None:
-                fb, fb_src = committed_pmc_traffic()
-                traffic, traffic_src = fb, f"{fb_src}; {traffic_src}"
+        traffic, traffic_src = (measured_pmc_traffic(args) if args.pmc_traffic == "auto" and world == 1
+                                else (None, "not measured in this run (--pmc-traffic off or N > 1)"))
+        if traffic is None and not args.amp:
+            fb, fb_src = committed_pmc_traffic()
+            traffic, traffic_src = fb, f"{fb_src}; {traffic_src}"
         peak = PEAK_BF16_MFMA_TFLOPS if args.amp else PEAK_F32_MFMA_TFLOPS
-        # the dominant kernel: the fused Winograd F(2x2,3x3) kernel (fp32 bench) / the direct bf16-input kernel (--amp).
+        # the dominant kernel: the fused Winograd F(2x2,3x3) kernel (fp32 bench) / the bf16-storage direct kernel (--amp).
         # `achieved` / `frac` price the MFMA FLOPs the kernel ISSUES (never above the peak); the direct-convolution FLOPs the
         # same launches stand for are reported next to it as `effective_direct_tflops`
-        dom = "conv3x3_mfma" if args.amp else "conv3x3_wino"
+        dom = "p8_conv3x3" if args.amp else "conv3x3_wino"
         conv = prof.get(dom, {"ms": 0.0, "flops": 0.0, "issued": 0.0, "bytes": 0.0, "calls": 0})
         ach = conv["issued"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         eff = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
@@ -274,7 +274,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "ms_per_step_median": median, "value_at_median": world * 2 * B / (median * 1e-3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 operands / f32 accumulate (conv, FC); f32 elsewhere" if args.amp else "f32", "data": "synthetic",
+            "dtype": "bf16 storage + operands / f32 accumulate (3x3 conv stack), bf16 operands (FC); f32 elsewhere" if args.amp else "f32",
+            "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[1]: final_c2f.yaml (K=8) student-only supervised fwd/bwd + clip + SGD, "
                                     f"per-GPU {2 * B} synthetic {W}x{H} images (strong + weak view of {B} labelled), random init"
                                     if args.student_only else
@@ -286,7 +287,7 @@ def main():
                          "traffic_unit": "HBM-side bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["calls"], 1),
-                         "kernel": ("conv3x3_buf_kernel<BM,NWAVE,bf16> (all 3x3 conv fwd + dgrad launches)" if args.amp else
+                         "kernel": ("p8_conv3x3_kernel<MT> (bf16 storage: all 3x3 conv fwd + dgrad launches)" if args.amp else
                                     "conv3x3_wino_kernel (fused Winograd F(2x2,3x3): every 3x3 conv fwd + dgrad launch with "
                                     ">= 32 input channels; the 3-channel stem runs conv3x3_stem_kernel, listed under kernels)"),
                          "achieved_is": "MFMA FLOPs issued by the kernel (16 multiplies per 2x2 tile and channel pair, tile "

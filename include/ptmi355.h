@@ -60,19 +60,6 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws,
                        int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
-/* bf16-input / fp32-accumulate variants of the two calls above (SOLVER.AMP.ENABLED, pt/engine/trainer.py:98; BASELINE
- * configs[4]).  Same arguments and workspace size; x / dy are fp32 in memory and every operand
- * element is rounded to bf16 (round-to-nearest-even) on its way into v_mfma_f32_32x32x16_bf16; accumulation, bias,
- * epilogues, split-K reduction and outputs are fp32.  The 3-channel stem runs on the same MFMA kernel.
- * ptmi_conv3x3_fwd_bf16 takes weights packed by ptmi_conv3x3_pack_weights_bf16 (same arguments and buffer size as
- * ptmi_conv3x3_pack_weights; the slab holds the rounded weights as bf16 in MFMA operand order). */
-int ptmi_conv3x3_pack_weights_bf16(const float* w, float* wp, int w_cout, int w_cin, int mode,
-                                   ptmi_stream_t s);
-int ptmi_conv3x3_fwd_bf16(const float* x, const float* wp, const float* bias, const float* mask_ref,
-                          float* y, int n, int cin, int cout, int h, int w, int epilogue,
-                          ptmi_stream_t s);
-int ptmi_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws,
-                            int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
 /* Fused Winograd F(2x2,3x3) variant of ptmi_conv3x3_fwd for the layers with >= 32 input channels (conv1_2 .. conv5_3 at
  * pt/modeling/backbone/vgg.py:45-53,66-69 and the RPN 3x3 conv at pt/modeling/proposal_generator/rpn.py:96; cuDNN, which
  * the reference runs there, uses Winograd for these fp32 3x3 s1 layers too).  Same arguments, epilogues and dgrad
@@ -105,15 +92,17 @@ int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* d
  * SOLVER.AMP.ENABLED (reference pt/engine/trainer.py:98; BASELINE configs[4]): under autocast the reference's cuDNN convolutions
  * (pt/modeling/backbone/vgg.py:45-53,66-69, pt/modeling/proposal_generator/rpn.py:96) read and write bf16 activations.  The
  * entry points below keep activations and activation gradients in bf16 in HBM and LDS, in the P8 layout
- *     t[ceil(C/8)][ROWS = N (H + 1) + 1][WS = W + 1][8]  bf16
+ *     t[2 ceil(C/16)][ROWS = N (H + 1) + 1][WS = W + 1][8]  bf16
  * pixel (n, r, c) at row n (H + 1) + 1 + r, column 1 + c; rows n (H + 1) and column 0 hold zeros (the convolution's zero padding
  * is part of the tensor: a tap is a flat pixel offset, no kernel tests an image edge); every entry point writes them as zeros.
  * Accumulation, bias, losses and weight gradients are fp32; a value is rounded to bf16 (nearest even) when it is stored.
- * ptmi_p8_plane_pixels = ROWS * WS (a tensor holds ceil(C/8) * that many 16-byte pixel vectors). */
+ * ptmi_p8_plane_pixels = ROWS * WS (a tensor holds ptmi_p8_planes(C) * that many 16-byte pixel vectors). */
 int64_t ptmi_p8_plane_pixels(int n, int h, int w);
-/* fp32 NCHW <-> P8.  cb_out >= ceil(c/8) planes are written, channels >= c as zeros (the 3-channel image becomes the
- * 16-channel input of the first layer). */
-int ptmi_p8_from_nchw(const float* x, void* y, int n, int c, int cb_out, int h, int w, ptmi_stream_t s);
+/* A tensor of c channels holds ptmi_p8_planes(c) = 2 ceil(c/16) planes (whole 16-channel chunks; channels >= c are zeros: the
+ * 3-channel image is the 16-channel input of the first layer). */
+int ptmi_p8_planes(int c);
+/* fp32 NCHW <-> P8 */
+int ptmi_p8_from_nchw(const float* x, void* y, int n, int c, int h, int w, ptmi_stream_t s);
 int ptmi_p8_to_nchw(const void* x, float* y, int n, int c, int h, int w, ptmi_stream_t s);
 /* MaxPool2d(2,2) forward / backward (vgg.py:59,71) on P8 tensors; backward as ptmi_maxpool2x2_bwd (first maximum, optional
  * ReLU mask of the pooled activation). */
@@ -123,7 +112,7 @@ int ptmi_p8_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int n, int c
 /* dz = dy * (y > 0) and out = a + b (fp32 sum, rounded once) over `pixels16` 16-byte pixel vectors of P8 tensors */
 int ptmi_p8_relu_bwd(const void* dy, const void* y, void* dz, int64_t pixels16, ptmi_stream_t s);
 int ptmi_p8_add(const void* a, const void* b, void* out, int64_t pixels16, ptmi_stream_t s);
-/* conv3x3 s1 p1 on P8 tensors: v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 out.  cin a multiple of 16, cout of 8.
+/* conv3x3 s1 p1 on P8 tensors: v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 out; any channel counts (planes as above).
  * Weights packed by ptmi_p8_pack_weights (bf16, MFMA A-operand order [coTile][cin/16][tap][mt][64 lanes][8]; mode 0 forward,
  * mode 1 dgrad = flipped taps, transposed channels; ptmi_p8_packed_elems bf16 elements).
  * epilogue 0: + bias; 1: + bias, ReLU; 2: none (dgrad); 3: dgrad times (mask_ref > 0), mask_ref = the producing layer's stored

@@ -23,12 +23,9 @@ SIGNATURES = {
     "ptmi_conv3x3_ck": (_i, [_i]),
     "ptmi_conv3x3_packed_floats": (_i64, [_i, _i]),
     "ptmi_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "ptmi_conv3x3_pack_weights_bf16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ptmi_conv3x3_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ptmi_conv3x3_fwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "ptmi_conv3x3_wgrad_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wino_packed_floats": (_i64, [_i, _i]),
     "ptmi_conv3x3_wino_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wino_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -37,7 +34,8 @@ SIGNATURES = {
     "ptmi_conv3x3_wino_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_conv3x3_wino_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_p8_plane_pixels": (_i64, [_i, _i, _i]),
-    "ptmi_p8_from_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_p8_planes": (_i, [_i]),
+    "ptmi_p8_from_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ptmi_p8_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ptmi_p8_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ptmi_p8_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -52,12 +52,9 @@ __device__ __forceinline__ void* uniform_ptr(const void* p)
                    (unsigned)__builtin_amdgcn_readfirstlane((unsigned)a));
 }
 
-// BF = true: bf16-input / fp32-accumulate variant (SOLVER.AMP.ENABLED).  Same DMA pipeline and LDS layout (fp32 operands);
-// a lane rounds its operand elements to bf16 (v_cvt_pk_bf16_f32, RNE) between LDS and v_mfma_f32_32x32x16_bf16.  The
-// MFMA's 16 k values are (lane half h, element e) <-> (tap = 4t + e / 2, channel 2 (e % 2) + h) for MFMA t of a chunk:
-// taps 0-3, 4-7 and 8 (+ three zero taps) -- 3 MFMAs per accumulator tile and chunk instead of 18.  The weights arrive
-// already as bf16 in that order (ptmi_conv3x3_pack_weights_bf16): a third less weight DMA, one ds_read_b128 per A operand.
-template <int BM, int NWAVE, bool BF>
+// (SOLVER.AMP.ENABLED runs the bf16-storage kernels of p8.hip; the bf16-INPUT variants that rounds 2-3 kept in this file --
+// fp32 tensors in HBM and LDS, operands rounded between LDS and the MFMA -- are gone.)
+template <int BM, int NWAVE>
 __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W,
@@ -67,9 +64,8 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
     constexpr int NT = 64 * NWAVE;
     constexpr int WN = NWAVE / (BM / 64);            // waves along the pixel dimension: 2 -> 4 rows, 4 -> 8 rows
     constexpr int TH = 2 * WN, PR = TH + 2, PLANE = PR * PWB;
-    // weight slab per chunk, in floats: 9 taps x CK channels x BM fp32 -- or, bf16 variant, 3 MFMAs x 2 lane halves x BM rows of
-    // eight bf16 (16 B: a lane's whole A operand of one MFMA, packed by ptmi_conv3x3_pack_weights_bf16)
-    constexpr int WS = BF ? 24 * BM : 9 * CK * BM;
+    // weight slab per chunk, in floats: 9 taps x CK channels x BM fp32
+    constexpr int WS = 9 * CK * BM;
     constexpr int WPC = WS / 4;                      // ... in 16-B pieces
     constexpr int NWI = (WPC + NT - 1) / NT;
     constexpr int PPC = CK * PR * 10;                // patch pieces per chunk (240 / 400)
@@ -148,7 +144,6 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
     const bool row_in = y0 + rb < H;
     const int mode = !row_in ? 0 : (cb + 8 < wv ? 2 : (cb < wv ? 1 : 0));      // pixel blocks with work: 0 / 1 / 2
     const int a_off = wm * 64 + nl + (lane >> 5) * BM;
-    const int a_offb = (lane >> 5) * BM + wm * 64 + nl;         // bf16 slab, in 16-B units: [MFMA t][lane half][row]
     const int b_off = WS + (lane >> 5) * PLANE + (rb + pr) * PWB + cb + pc + 3;
 
     f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};     // acc[co half][pixel block]
@@ -176,46 +171,20 @@ __global__ __launch_bounds__(64 * NWAVE, (NWAVE == 8 ? 4 : 3)) void conv3x3_buf_
             if (MODE == 0) continue;
             const float* wsl = lds + buf * STAGE + a_off;
             const float* psl = lds + buf * STAGE + b_off;
-            if constexpr (BF) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    float b0[8], b1[8];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int tap = 4 * t + (e >> 1), j = e & 1, ky = tap / 3, kx = tap % 3;
-                        const bool on = tap < 9;
-                        b0[e] = on ? psl[2 * j * PLANE + ky * PWB + kx] : 0.f;
-                        b1[e] = (on && MODE == 2) ? psl[2 * j * PLANE + ky * PWB + kx + 8] : 0.f;
-                    }
-                    // A: the slab already holds bf16, eight per (MFMA, lane half, row) -- one 16-B read per operand
-                    const f32x4* asl = reinterpret_cast<const f32x4*>(lds + buf * STAGE) + a_offb + t * 2 * BM;
-                    const ptmi_bf16x8 A0 = __builtin_bit_cast(ptmi_bf16x8, asl[0]);
-                    const ptmi_bf16x8 A1 = __builtin_bit_cast(ptmi_bf16x8, asl[32]);
-                    const ptmi_bf16x8 B0 = ptmi_pack_bf16x8(b0);
-                    acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B0, acc00, 0, 0, 0);
-                    acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B0, acc10, 0, 0, 0);
+                for (int j = 0; j < CK / 2; ++j) {
+                    const float a0 = wsl[(tap * CK + 2 * j) * BM];
+                    const float a1 = wsl[(tap * CK + 2 * j) * BM + 32];
+                    const float b0 = psl[2 * j * PLANE + ky * PWB + kx];
+                    acc00 = mfma32(a0, b0, acc00);
+                    acc10 = mfma32(a1, b0, acc10);
                     if (MODE == 2) {
-                        const ptmi_bf16x8 B1 = ptmi_pack_bf16x8(b1);
-                        acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0, B1, acc01, 0, 0, 0);
-                        acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc11, 0, 0, 0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) {
-                    const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-                    for (int j = 0; j < CK / 2; ++j) {
-                        const float a0 = wsl[(tap * CK + 2 * j) * BM];
-                        const float a1 = wsl[(tap * CK + 2 * j) * BM + 32];
-                        const float b0 = psl[2 * j * PLANE + ky * PWB + kx];
-                        acc00 = mfma32(a0, b0, acc00);
-                        acc10 = mfma32(a1, b0, acc10);
-                        if (MODE == 2) {
-                            const float b1 = psl[2 * j * PLANE + ky * PWB + kx + 8];
-                            acc01 = mfma32(a0, b1, acc01);
-                            acc11 = mfma32(a1, b1, acc11);
-                        }
+                        const float b1 = psl[2 * j * PLANE + ky * PWB + kx + 8];
+                        acc01 = mfma32(a0, b1, acc01);
+                        acc11 = mfma32(a1, b1, acc11);
                     }
                 }
             }
@@ -474,32 +443,6 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         wp[i] = v;
     }
 }
-// bf16 slab of the bf16-input kernel: [channel tile][chunk][MFMA t (3)][lane half h (2)][row m (BM)][element e (8)] with
-// (tap, channel in chunk) = (4t + e / 2, 2 (e % 2) + h); taps 9-11 are zeros.  Rounded to nearest even.
-__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int wCout, int wCin,
-                                         int mode, int BM, int coTiles, int nChunks)
-{
-    const int64_t total = (int64_t)coTiles * nChunks * 3 * 2 * BM * 8;
-    const int convCout = mode ? wCin : wCout, convCin = mode ? wCout : wCin;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i;
-        const int e = r % 8; r /= 8;
-        const int m = r % BM; r /= BM;
-        const int h = r % 2; r /= 2;
-        const int t = r % 3; r /= 3;
-        const int chunk = r % nChunks;
-        const int cot = r / nChunks;
-        const int tap = 4 * t + (e >> 1), co = cot * BM + m, ci = chunk * 4 + 2 * (e & 1) + h;
-        float v = 0.f;
-        if (tap < 9 && co < convCout && ci < convCin) {
-            const int ky = tap / 3, kx = tap % 3;
-            if (mode == 0) v = w[((size_t)co * wCin + ci) * 9 + tap];
-            else v = w[((size_t)ci * wCin + co) * 9 + (2 - ky) * 3 + (2 - kx)];
-        }
-        wp[i] = (__bf16)v;
-    }
-}
 // ------------------------------------------------------------------------------------ wgrad, buffer-DMA pipeline
 // Third-generation wgrad main loop (default).  Measured with clock64() probes (tools/exp_wgrad_timing.py): in the
 // kernel above a wave spends as long issuing its 16 dword DMAs per stage (address VALU work that has to win issue
@@ -529,9 +472,7 @@ __device__ __forceinline__ void bdma16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_b_t*)lds_wave_base, 16, (int)voff, 0, 0, 0);
 }
 
-// BF = true (bf16-input variant): the eight pixels 16h + 8hf + 0..7 a lane holds are exactly the eight k values of its
-// half in v_mfma_f32_32x32x16_bf16 -- one MFMA per (hf, tap) instead of eight.
-template <int G, bool BF>
+template <int G>
 __device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, const float* __restrict__ bl,
                                                 f32x16 (&acc)[G == 0 ? 5 : 4])
 {
@@ -559,24 +500,13 @@ __device__ __forceinline__ void wgrad_stage_buf(const float* __restrict__ al, co
         v[17] = *(const volatile lds_f32_t*)(br + 16);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {               // pixels 16h + 8*hf + j, j = 0..7
-            if constexpr (BF) {
-                const ptmi_bf16x8 A = ptmi_pack_bf16x8(a + 8 * hf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int tap = ky * 3 + kx;
                     if (tap >= TAP0 && tap < TAP1)
-                        acc[tap - TAP0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, ptmi_pack_bf16x8(v + 8 * hf + kx),
-                                                                                  acc[tap - TAP0], 0, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int tap = ky * 3 + kx;
-                        if (tap >= TAP0 && tap < TAP1)
-                            acc[tap - TAP0] = mfma32(a[8 * hf + j], v[8 * hf + j + kx], acc[tap - TAP0]);
-                    }
+                        acc[tap - TAP0] = mfma32(a[8 * hf + j], v[8 * hf + j + kx], acc[tap - TAP0]);
                 }
             }
         }
@@ -608,7 +538,7 @@ __device__ __forceinline__ void wgrad_stage_edge(const float* __restrict__ al0, 
 
 // one tap group's whole life: descriptors, stage loop, partial store.  Instantiated twice and selected by a
 // wave-uniform branch so that each group gets its own register allocation (5 or 4 accumulator tiles).
-template <int G, bool EDGE, bool BF>
+template <int G, bool EDGE>
 __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restrict__ x, const float* __restrict__ dy,
                                                float* __restrict__ partial, int N, int Cin, int Cout, int H, int W,
                                                int tilesX, int tilesY, int ciTiles, int S, int txb, int bid, int wave,
@@ -730,7 +660,7 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
         __syncthreads();
         if (tile + S < nTiles) issue(nn, nty, ntx, buf ^ 1);
         if (!EDGE)
-            wgrad_stage_buf<G, BF>(lds + buf * WB_STAGE + a_off, lds + buf * WB_STAGE + b_off, acc);
+            wgrad_stage_buf<G>(lds + buf * WB_STAGE + a_off, lds + buf * WB_STAGE + b_off, acc);
         else
             wgrad_stage_edge<G>(lds + buf * WB_STAGE + a_off - h16 + (lane >> 5), lds + buf * WB_STAGE + b_off - h16 + (lane >> 5),
                                 acc, (wv + 1) >> 1);
@@ -754,7 +684,6 @@ __device__ __forceinline__ void wgrad_buf_body(float* lds, const float* __restri
 // workgroups nMain .. nMain+nEdge-1 walk that column alone with the interleaved short stage (split-K factor Se, partials
 // after the main ones in the workspace).  The short-stage workgroups are latency-bound (few MFMAs per DMA round trip);
 // dispatched after the main ones they fill the tail of the launch instead of costing a launch of their own.
-template <bool BF>
 __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_buf_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int N, int Cin,
     int Cout, int H, int W, int tilesXm, int tilesY, int coTiles, int ciTiles, int S, int nMain, int Se)
@@ -764,12 +693,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_wgrad_buf_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bid = blockIdx.x;
     if (bid < nMain) {
-        if (wave < 4) wgrad_buf_body<0, false, BF>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
-        else wgrad_buf_body<1, false, BF>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
-    } else if constexpr (!BF) {          // (the bf16 variant is launched without right-edge workgroups: Se = 0)
+        if (wave < 4) wgrad_buf_body<0, false>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
+        else wgrad_buf_body<1, false>(lds, x, dy, partial, N, Cin, Cout, H, W, tilesXm, tilesY, ciTiles, S, 0, bid, wave, lane);
+    } else {
         float* pe = partial + (size_t)S * 9 * Cout * Cin;
-        if (wave < 4) wgrad_buf_body<0, true, false>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
-        else wgrad_buf_body<1, true, false>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
+        if (wave < 4) wgrad_buf_body<0, true>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
+        else wgrad_buf_body<1, true>(lds, x, dy, pe, N, Cin, Cout, H, W, 1, tilesY, ciTiles, Se, tilesXm, bid - nMain, wave, lane);
     }
 }
 
@@ -794,13 +723,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
 // stage 2 = fixed-order sum over the slots (deterministic).
 constexpr int BG_SLOTS = 16;
 
-// BF: the elements are rounded to bf16 first (the bf16 variant sums the same rounded gradient its MFMAs consume)
-template <bool BF>
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, float* __restrict__ part,
                                                                 int N, int C, int HW)
 {
     __shared__ float sm[4];
-    auto rd = [](float v) { return BF ? (float)(__bf16)v : v; };
+    auto rd = [](float v) { return v; };
     const int c = blockIdx.x, slot = blockIdx.y;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int n = slot; n < N; n += BG_SLOTS) {
@@ -874,7 +801,7 @@ int wgrad_splits(int n, int cin, int cout, int h, int w)
     return S;
 }
 
-int conv3x3_fwd_impl(bool bf, const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
+int conv3x3_fwd_impl(const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
                      int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_fwd: bad args");
@@ -894,8 +821,7 @@ int conv3x3_fwd_impl(bool bf, const float* x, const float* wp, const float* bias
     const int tilesX = cdiv(w, TW), tilesY = cdiv(h, TH), coTiles = cdiv(cout, BM), nChunks = cdiv(cin, CK);
     hipStream_t st = (hipStream_t)s;
     // 3-channel stem: K = 27 is too short to amortise the LDS pipeline's prologue and the layer is HBM-write bound
-    // (the bf16 variant has no VALU stem: its 3-channel layer runs on the MFMA kernel, one zero-padded 4-channel chunk)
-    if (!bf && BM == 64 && cin <= 4 && epilogue <= 1) {
+    if (BM == 64 && cin <= 4 && epilogue <= 1) {
         // (-ffp-contract=off: fmaf() is explicit in the kernel; K = 27 keeps the rounding difference at the 1e-7 level)
         PTMI_CHECK_ARG(n < 65536 && (int64_t)h * w < (int64_t)1 << 30, "conv3x3_fwd(stem): grid too large");
         const dim3 gs((unsigned)cdiv(h * w, 64 * STEM_PX), (unsigned)n);
@@ -907,15 +833,9 @@ int conv3x3_fwd_impl(bool bf, const float* x, const float* wp, const float* bias
         return 0;
     }
     const dim3 grid3((unsigned)coTiles, (unsigned)(n * tilesY), (unsigned)tilesX);
-#define LBUF(BM_, NW_)                                                                                                    \
-    do {                                                                                                                  \
-        if (bf)                                                                                                           \
-            hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_, true>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, y, \
-                               n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue);                           \
-        else                                                                                                              \
-            hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_, false>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, y, \
-                               n, cin, cout, h, w, tilesX, tilesY, coTiles, nChunks, epilogue);                           \
-    } while (0)
+#define LBUF(BM_, NW_)                                                                                                 \
+    hipLaunchKernelGGL((conv3x3_buf_kernel<BM_, NW_>), grid3, dim3(64 * NW_), 0, st, x, wp, bias, mask_ref, y, n, cin, cout, h, \
+                       w, tilesX, tilesY, coTiles, nChunks, epilogue)
     if (BM == 128 && use8) LBUF(128, 8);
     else if (BM == 128) LBUF(128, 4);
     else LBUF(64, 4);
@@ -924,7 +844,7 @@ int conv3x3_fwd_impl(bool bf, const float* x, const float* wp, const float* bias
     return 0;
 }
 
-int conv3x3_wgrad_impl(bool bf, const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
+int conv3x3_wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
                        int cout, int h, int w, int accumulate, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0, "conv3x3_wgrad: bad args");
@@ -932,17 +852,13 @@ int conv3x3_wgrad_impl(bool bf, const float* x, const float* dy, float* dw, floa
     const int tilesX = cdiv(w, TW), tilesY = h;
     const int coTiles = cdiv(cout, 128), ciTiles = cdiv(cin, 32);
     int S = wgrad_splits(n, cin, cout, h, w);
-    const int Se = bf ? 0 : wgrad_edge_splits(n, cin, cout, h, w);
+    const int Se = wgrad_edge_splits(n, cin, cout, h, w);
     const int64_t bg_off = (int64_t)(S + wgrad_edge_splits(n, cin, cout, h, w)) * 9 * cout * cin;   // as ptmi_conv3x3_wgrad_ws_floats lays it out
     hipStream_t st = (hipStream_t)s;
     // Se > 0: the right-edge tile column has few valid pixels and gets the short interleaved stage
     const int nMain = coTiles * ciTiles * S, nEdge = coTiles * ciTiles * Se;
-    if (bf)
-        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<true>, dim3(nMain), dim3(512), 0, st, x, dy, ws, n, cin, cout, h, w,
-                           tilesX, tilesY, coTiles, ciTiles, S, nMain, 0);
-    else
-        hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel<false>, dim3(nMain + nEdge), dim3(512), 0, st, x, dy, ws, n, cin, cout,
-                           h, w, Se > 0 ? tilesX - 1 : tilesX, tilesY, coTiles, ciTiles, S, nMain, Se);
+    hipLaunchKernelGGL(conv3x3_wgrad_buf_kernel, dim3(nMain + nEdge), dim3(512), 0, st, x, dy, ws, n, cin, cout, h, w,
+                       Se > 0 ? tilesX - 1 : tilesX, tilesY, coTiles, ciTiles, S, nMain, Se);
     S += Se;
     PTMI_LAUNCH_CHECK("conv3x3_wgrad");
     const int64_t total = (int64_t)cout * cin * 9;
@@ -951,10 +867,7 @@ int conv3x3_wgrad_impl(bool bf, const float* x, const float* dy, float* dw, floa
     PTMI_LAUNCH_CHECK("conv3x3_wgrad_reduce");
     if (db) {
         float* part = ws + bg_off + 64;
-        if (bf)
-            hipLaunchKernelGGL(bias_grad_partial_kernel<true>, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
-        else
-            hipLaunchKernelGGL(bias_grad_partial_kernel<false>, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
+        hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(cout, BG_SLOTS), dim3(256), 0, st, dy, part, n, cout, h * w);
         PTMI_LAUNCH_CHECK("conv3x3_bias_grad_partial");
         hipLaunchKernelGGL(bias_grad_final_kernel, dim3(cdiv(cout, 256)), dim3(256), 0, st, part, db, cout, accumulate);
         PTMI_LAUNCH_CHECK("conv3x3_bias_grad_final");
@@ -990,30 +903,10 @@ int ptmi_conv3x3_pack_weights(const float* w, float* wp, int w_cout, int w_cin, 
     return 0;
 }
 
-int ptmi_conv3x3_pack_weights_bf16(const float* w, float* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s)
-{
-    PTMI_CHECK_ARG(w && wp && w_cout > 0 && w_cin > 0, "conv3x3_pack_weights_bf16: bad args");
-    const int convCout = mode ? w_cin : w_cout, convCin = mode ? w_cout : w_cin;
-    const int BM = ptmi_conv3x3_bm(convCout);
-    const int coTiles = cdiv(convCout, BM), nChunks = cdiv(convCin, 4);
-    const int64_t total = (int64_t)coTiles * nChunks * 3 * 2 * BM * 8;
-    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w,
-                       reinterpret_cast<__bf16*>(wp), w_cout, w_cin, mode, BM, coTiles, nChunks);
-    PTMI_LAUNCH_CHECK("conv3x3_pack_weights_bf16");
-    return 0;
-}
-
 int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
                      float* y, int n, int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
 {
-    return conv3x3_fwd_impl(false, x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue, s);
-}
-
-int ptmi_conv3x3_fwd_bf16(const float* x, const float* wp, const float* bias, const float* mask_ref,
-                          float* y, int n, int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
-{
-    return conv3x3_fwd_impl(true, x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue, s);
+    return conv3x3_fwd_impl(x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue, s);
 }
 
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
@@ -1026,13 +919,7 @@ int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
                        int cout, int h, int w, int accumulate, ptmi_stream_t s)
 {
-    return conv3x3_wgrad_impl(false, x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, s);
-}
-
-int ptmi_conv3x3_wgrad_bf16(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin,
-                            int cout, int h, int w, int accumulate, ptmi_stream_t s)
-{
-    return conv3x3_wgrad_impl(true, x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, s);
+    return conv3x3_wgrad_impl(x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, s);
 }
 
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s)

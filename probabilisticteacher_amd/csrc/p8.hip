@@ -5,7 +5,8 @@
 // Round 4.  The bf16-INPUT kernels of conv.hip keep fp32 activations in HBM and LDS and round between LDS and the matrix core:
 // twice the bytes at every level, and 0.23 of the bf16 MFMA peak.  Here activations and activation gradients LIVE in bf16:
 //
-//   "P8" layout (padded, 8-channel blocks)      t[C/8][ROWS][WS][8]  bf16,   ROWS = N (H + 1) + 1,  WS = W + 1
+//   "P8" layout (padded, 8-channel blocks)      t[2 ceil(C/16)][ROWS][WS][8]  bf16,   ROWS = N (H + 1) + 1,  WS = W + 1
+//     (whole 16-channel chunks: channels beyond C are zeros)
 //     * pixel (n, r, c) sits at row n (H + 1) + 1 + r, column 1 + c; row n (H + 1) (one zero row between images, one before the
 //       first, one after the last) and column 0 of every row hold ZEROS: the zero padding of a 3x3 convolution is IN the tensor
 //       (the right neighbour of a row's last pixel is the next row's column 0), so a tap is the flat pixel offset
@@ -233,7 +234,7 @@ struct P8G {
 template <int MT>
 __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     const u16* __restrict__ x, const u16* __restrict__ wp, const float* __restrict__ bias, const u16* __restrict__ mref,
-    u16* __restrict__ y, int Cout, int HS, int WS, int ROWS, long long PT, int nChunks, int epi, int coTiles, int tilesC,
+    u16* __restrict__ y, int Cout, int ycb, int HS, int WS, int ROWS, long long PT, int nChunks, int epi, int coTiles, int tilesC,
     int nPix)
 {
     using G = P8G<MT>;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cb = (cot * MT + m) * 4 + q;                     // 8-channel plane of the output
-            if (cb * 8 >= Cout) continue;                              // (wave-uniform)
+            if (cb >= ycb) continue;                                   // (wave-uniform) planes beyond the tensor
             const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)cb * PT * 8, plane_bytes);
             u32x2 mk[NTB];
             if (epi == 3) {
@@ -484,8 +485,8 @@ typedef __attribute__((address_space(3))) p8_s4 plds_s4_t;
 struct p8_s4x2 { p8_s4 lo, hi; };
 
 __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ ws,
-                                                         float* __restrict__ wsb, int Cin, int Cout, int WS, int ROWS, long long PT,
-                                                         int ciTiles, int S, int tilesC, int nTiles)
+                                                         float* __restrict__ wsb, int Cin, int Cout, int xcb, int dcb, int WS, int ROWS,
+                                                         long long PT, int ciTiles, int S, int tilesC, int nTiles)
 {
     __shared__ __attribute__((aligned(16))) char lds[2 * G_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
     const int cot = pair / ciTiles, cit = pair - cot * ciTiles;
     const int t0 = (int)((long long)nTiles * split / S), t1 = (int)((long long)nTiles * (split + 1) / S);
 
-    const unsigned x_bytes = (unsigned)((long long)(Cin / 8) * PT * 16), dy_bytes = (unsigned)((long long)(Cout / 8) * PT * 16);
+    const unsigned x_bytes = (unsigned)((long long)xcb * PT * 16), dy_bytes = (unsigned)((long long)dcb * PT * 16);
     const __amdgpu_buffer_rsrc_t rx = ptmi_rsrc(x, x_bytes), rdy = ptmi_rsrc(dy, dy_bytes);
 
     // ---- DMA pieces of this lane: dY 4 (wave w: planes 2 w, 2 w + 1; 128 pixels each), X 4 (pieces 64 (4 w + i) + lane of 1632)
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
         dy_row[i] = pxl >> 5;
         dy_col[i] = pxl & 31;
         const int pg = cot * 16 + plane;
-        dy_chan[i] = pg * 8 < Cout;
+        dy_chan[i] = pg < dcb;
         dy_plane[i] = (unsigned)((long long)pg * PT * 16);
     }
     int x_row[4], x_col[4];
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
         x_row[i] = slot / 34 - 1;
         x_col[i] = slot % 34 - 1;
         const int pg = cit * 8 + plane;
-        x_ok[i] = q < 8 * G_XPL && 4 * wave + i < 26 && pg * 8 < Cin;
+        x_ok[i] = q < 8 * G_XPL && 4 * wave + i < 26 && pg < xcb;
         x_plane[i] = (unsigned)((long long)pg * PT * 16);
     }
     auto issue = [&](auto i_c, int tile, int st) {
@@ -681,10 +682,11 @@ int64_t ptmi_p8_plane_pixels(int n, int h, int w)
     return p8_dims(n, h, w).PT;
 }
 
-int ptmi_p8_from_nchw(const float* x, void* y, int n, int c, int cb_out, int h, int w, ptmi_stream_t s)
+int ptmi_p8_from_nchw(const float* x, void* y, int n, int c, int h, int w, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && h > 0 && w > 0 && cb_out * 8 >= c, "p8_from_nchw: bad args");
+    PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && h > 0 && w > 0, "p8_from_nchw: bad args");
     const P8Dims d = p8_dims(n, h, w);
+    const int cb_out = ptmi_p8_planes(c);
     hipLaunchKernelGGL(p8_from_nchw_kernel, dim3((unsigned)cdiv64(d.PT, 256), cb_out), dim3(256), 0, (hipStream_t)s, x, (u32x4*)y, c, h,
                        w, d.HS, d.WS, d.PT, cb_out);
     PTMI_LAUNCH_CHECK("p8_from_nchw");
@@ -703,9 +705,9 @@ int ptmi_p8_to_nchw(const void* x, float* y, int n, int c, int h, int w, ptmi_st
 
 int ptmi_p8_maxpool2x2_fwd(const void* x, void* y, int n, int c, int h, int w, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && c % 8 == 0 && h > 1 && w > 1, "p8_maxpool2x2_fwd: bad args");
+    PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && h > 1 && w > 1, "p8_maxpool2x2_fwd: bad args");
     const P8Dims di = p8_dims(n, h, w), dq = p8_dims(n, h / 2, w / 2);
-    hipLaunchKernelGGL(p8_maxpool_fwd_kernel, dim3((unsigned)cdiv64(dq.PT, 256), c / 8), dim3(256), 0, (hipStream_t)s, (const u32x4*)x,
+    hipLaunchKernelGGL(p8_maxpool_fwd_kernel, dim3((unsigned)cdiv64(dq.PT, 256), ptmi_p8_planes(c)), dim3(256), 0, (hipStream_t)s, (const u32x4*)x,
                        (u32x4*)y, di.HS, di.WS, di.PT, dq.HS, dq.WS, dq.PT);
     PTMI_LAUNCH_CHECK("p8_maxpool2x2_fwd");
     return 0;
@@ -713,9 +715,9 @@ int ptmi_p8_maxpool2x2_fwd(const void* x, void* y, int n, int c, int h, int w, p
 
 int ptmi_p8_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int n, int c, int h, int w, int relu_mask, ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(x && dy && dx && n > 0 && c > 0 && c % 8 == 0 && h > 1 && w > 1, "p8_maxpool2x2_bwd: bad args");
+    PTMI_CHECK_ARG(x && dy && dx && n > 0 && c > 0 && h > 1 && w > 1, "p8_maxpool2x2_bwd: bad args");
     const P8Dims di = p8_dims(n, h, w), dq = p8_dims(n, h / 2, w / 2);
-    hipLaunchKernelGGL(p8_maxpool_bwd_kernel, dim3((unsigned)cdiv64(di.PT, 256), c / 8), dim3(256), 0, (hipStream_t)s, (const u32x4*)x,
+    hipLaunchKernelGGL(p8_maxpool_bwd_kernel, dim3((unsigned)cdiv64(di.PT, 256), ptmi_p8_planes(c)), dim3(256), 0, (hipStream_t)s, (const u32x4*)x,
                        (const u32x4*)dy, (u32x4*)dx, h, w, di.HS, di.WS, di.PT, dq.HS, dq.WS, dq.PT, relu_mask);
     PTMI_LAUNCH_CHECK("p8_maxpool2x2_bwd");
     return 0;
@@ -741,6 +743,8 @@ int ptmi_p8_add(const void* a, const void* b, void* out, int64_t pixels16, ptmi_
     return 0;
 }
 
+int ptmi_p8_planes(int c) { return c > 0 ? 2 * cdiv(c, 16) : 0; }
+
 int64_t ptmi_p8_packed_elems(int cin, int cout)
 {
     const int MT = p8_mt(cout);
@@ -764,13 +768,12 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
                     int h, int w, int epilogue, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_conv3x3: bad args");
-    PTMI_CHECK_ARG(cin % 16 == 0 && cout % 8 == 0, "p8_conv3x3: cin %d must be a multiple of 16 and cout %d of 8", cin, cout);
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "p8_conv3x3: bad epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue > 1 || bias, "p8_conv3x3: bias required for epilogue %d", epilogue);
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "p8_conv3x3: mask_ref required for epilogue 3");
     const P8Dims d = p8_dims(n, h, w);
     PTMI_CHECK_ARG(d.PT * 32 < (1ll << 32), "p8_conv3x3: %lld pixels per plane exceed the 32-bit buffer offsets", (long long)d.PT);
-    const int MT = p8_mt(cout), coTiles = cdiv(cout, 32 * MT), nChunks = cin / 16;
+    const int MT = p8_mt(cout), coTiles = cdiv(cout, 32 * MT), nChunks = cdiv(cin, 16), ycb = ptmi_p8_planes(cout);
     const int TR = MT == 4 ? P8G<4>::TR : P8G<2>::TR;
     const int tilesC = cdiv(d.WS, 32);
     const int64_t nPix = (int64_t)cdiv(d.ROWS, TR) * tilesC;
@@ -778,10 +781,10 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
     PTMI_CHECK_ARG(nWg < (1ll << 31), "p8_conv3x3: too many tiles");
     if (MT == 4)
         hipLaunchKernelGGL(p8_conv3x3_kernel<4>, dim3((unsigned)nWg), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
-                           (const u16*)mask_ref, (u16*)y, cout, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
+                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
     else
         hipLaunchKernelGGL(p8_conv3x3_kernel<2>, dim3((unsigned)nWg), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
-                           (const u16*)mask_ref, (u16*)y, cout, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
+                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
     PTMI_LAUNCH_CHECK("p8_conv3x3");
     return 0;
 }
@@ -795,9 +798,9 @@ int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws
                   int accumulate, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_wgrad: bad args");
-    PTMI_CHECK_ARG(cin % 8 == 0 && cout % 8 == 0, "p8_wgrad: channel counts must be multiples of 8 (cin %d cout %d)", cin, cout);
     const P8Dims d = p8_dims(n, h, w);
-    PTMI_CHECK_ARG((int64_t)(cin / 8) * d.PT * 16 < (1ll << 32) && (int64_t)(cout / 8) * d.PT * 16 < (1ll << 32) && d.PT < (1ll << 31) / 2,
+    const int xcb = ptmi_p8_planes(cin), dcb = ptmi_p8_planes(cout);
+    PTMI_CHECK_ARG((int64_t)xcb * d.PT * 16 < (1ll << 32) && (int64_t)dcb * d.PT * 16 < (1ll << 32) && d.PT < (1ll << 31) / 2,
                    "p8_wgrad: tensors beyond the 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d)", n, cin, cout, h, w);
     const int S = p8_wgrad_splits(n, cin, cout, h, w);
     const int coTiles = cdiv(cout, G_CO), ciTiles = cdiv(cin, G_CI), tilesC = cdiv(d.WS, 32);
@@ -806,7 +809,7 @@ int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws
     float* wsb = ws + (size_t)S * 9 * cout * cin;
     hipStream_t st = (hipStream_t)s;
     hipLaunchKernelGGL(p8_wgrad_kernel, dim3((unsigned)(coTiles * ciTiles * S)), dim3(GT), 0, st, (const u16*)x, (const u16*)dy, ws, wsb, cin,
-                       cout, d.WS, d.ROWS, (long long)d.PT, ciTiles, S, tilesC, (int)nTiles);
+                       cout, xcb, dcb, d.WS, d.ROWS, (long long)d.PT, ciTiles, S, tilesC, (int)nTiles);
     PTMI_LAUNCH_CHECK("p8_wgrad");
     const int64_t cc = (int64_t)cout * cin;
     hipLaunchKernelGGL(p8_wgrad_reduce_kernel, dim3((unsigned)cdiv64(cc > cout ? cc : cout, 256)), dim3(256), 0, st, ws, wsb, dw, db, cout, cin, S,

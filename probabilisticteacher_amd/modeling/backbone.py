@@ -106,7 +106,41 @@ class VGG(nn.Module):
     def size_divisibility(self):
         return 0
 
+    def _forward_p8(self, x):
+        """SOLVER.AMP.ENABLED: the whole stack on bf16-storage (P8) tensors -- the image is converted once (3 channels padded to
+        one 16-channel chunk), every layer reads and writes bf16 (probabilisticteacher_amd/p8.py), and each requested feature map
+        is converted back to fp32 NCHW once (its gradient re-enters the stack through the same conversion)."""
+        from .. import p8
+        n, c, h, w = x.shape
+        t = p8.from_nchw(ops._chk(x.contiguous(), name="image batch"))
+        outputs = {}
+        for name in self._names:
+            blk = getattr(self, name)[0]
+            params = []
+            for i in range(blk.num_convs):
+                cv = getattr(blk, f"conv{i + 1}")
+                params += [cv.weight, cv.bias]
+            trainable = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+            if trainable or t.requires_grad:
+                t = p8.block(t, n, c, h, w, blk.pool, params)
+            else:
+                with torch.no_grad():
+                    for i in range(blk.num_convs):
+                        wt, b = params[2 * i], params[2 * i + 1]
+                        t = p8.conv3x3_raw(t, p8.pack_weights(wt, 0), ops._chk(b.contiguous()), None, n, c, wt.shape[0], h, w, 1)
+                        c = wt.shape[0]
+                    if blk.pool:
+                        t = p8.maxpool_fwd(t, n, c, h, w)
+            c = blk.out_channels
+            if blk.pool:
+                h, w = h // 2, w // 2
+            if name in self._out_features:
+                outputs[name] = p8._ToNCHW.apply(t, n, c, h, w)
+        return outputs
+
     def forward(self, x):
+        if ops._native_bf16():
+            return self._forward_p8(x)
         outputs = {}
         for name in self._names:
             block = getattr(self, name)[0]

@@ -109,14 +109,16 @@ class _prof:
 # ============================================================================ bf16 operands (SOLVER.AMP.ENABLED)
 # BASELINE.json configs[4] ("mixed bf16 convs + fp32 loss"; the reference's AMP flag, pt/engine/trainer.py:98): the
 # conv / FC GEMM operands -- activations, weights and, in backward, the incoming gradients -- are rounded to bf16
-# (round-to-nearest-even), products are accumulated in fp32 and results stay fp32; losses, box codec, NMS, optimiser
-# are untouched.  Two ways to run it:
-#   "bf16"          the native kernels (ptmi_*_bf16: v_mfma_f32_32x32x16_bf16, operands rounded on their way from LDS
-#                   into the MFMA); tensors stay fp32 in HBM.  This is what SOLVER.AMP.ENABLED selects.
+# (round-to-nearest-even), products are accumulated in fp32; losses, box codec, NMS, optimiser are untouched.  Two ways to run it:
+#   "bf16"          what SOLVER.AMP.ENABLED selects.  3x3 convolutions: the bf16-STORAGE kernels (p8.py / csrc/p8.hip, round 4):
+#                   activations and activation gradients live in bf16 in HBM and LDS (what autocast stores in the reference), in
+#                   the padded 8-channel-block layout; the backbone keeps them that way from the image to the block-5 feature
+#                   map.  FC layers / 1x1 convolutions: ptmi_gemm_bf16 (fp32 tensors, operands rounded between LDS and the MFMA).
 #   "bf16_emulate"  the same numerics on the fp32 kernels: operands are rounded by a separate pass (x.to(bf16).to(f32))
 #                   and multiplied by v_mfma_f32_32x32x2_f32 -- a bf16 x bf16 product is exact in fp32, so the two
-#                   modes differ only in summation order.  The native kernels are tested against this mode.
-# Never enabled by bench.py (the headline metric is fp32).
+#                   modes differ in summation order and in the rounding of the stored conv outputs.  The native kernels
+#                   are tested against this mode.
+# Never enabled by bench.py's headline run (the headline metric is fp32).
 _OPERAND_ROUNDING = None
 
 
@@ -155,14 +157,17 @@ def _native_bf16() -> bool:
     return _OPERAND_ROUNDING == "bf16"
 
 
-def _conv_fwd_sym() -> str:
-    return "ptmi_conv3x3_fwd_bf16" if _native_bf16() else "ptmi_conv3x3_fwd"
+def _no_native_bf16(what: str) -> None:
+    if _native_bf16():
+        raise _lib.PtmiError(f"{what} is an fp32-tensor entry point: in \"bf16\" mode the 3x3 convolutions run on the bf16-storage "
+                             "kernels (probabilisticteacher_amd.p8; ops.conv3x3 / ops.vgg_block route there)")
 
 
 def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
     """(dW, db) of a 3x3 s1 p1 convolution from its input and output gradient (N1 wgrad): the Winograd-domain kernel on
     the fp32 layers with >= 64 input and output channels whose map fits its 32-bit offsets, the direct split-K kernel otherwise
     (and under bf16 operand rounding)."""
+    _no_native_bf16("ops.conv3x3_wgrad")
     n, cin, h, w = x.shape
     dw = torch.empty(cout, cin, 3, 3, dtype=F32, device=x.device)
     db = torch.empty(cout, dtype=F32, device=x.device)
@@ -176,19 +181,16 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
     else:
         ws = _ws("wgrad", lib.ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
         with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
-            _lib.call(_conv_wgrad_sym(), _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0, _stream())
+            _lib.call("ptmi_conv3x3_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0, _stream())
     return dw, db
-
-
-def _conv_wgrad_sym() -> str:
-    return "ptmi_conv3x3_wgrad_bf16" if _native_bf16() else "ptmi_conv3x3_wgrad"
 
 
 # ============================================================================ conv 3x3
 # Forward / dgrad algorithm of the fp32 3x3 layers: "auto" = fused Winograd F(2x2,3x3) (csrc/wino.hip) wherever the
 # input has enough channels to amortise its per-workgroup prologue, the direct implicit GEMM (csrc/conv.hip) for the
-# 3-channel stem; "direct" = the direct kernel everywhere (comparison runs, tests).  The bf16 modes keep the direct
-# kernels (their parity statement -- products of rounded operands are exact in fp32 -- does not survive a transform).
+# 3-channel stem; "direct" = the direct kernel everywhere (comparison runs, tests).  "bf16_emulate" keeps the direct
+# kernels (its parity statement -- products of rounded operands are exact in fp32 -- does not survive a transform); "bf16"
+# does not come here at all (p8.py).
 _CONV_ALGO = "auto"
 _WINO_MIN_CIN = 32
 _WINO_WGRAD_MIN_C = 64         # the wgrad workgroup owns 64 co x 64 ci
@@ -243,17 +245,11 @@ def _use_wino(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tuple
     return bool(_lib.load().ptmi_conv3x3_wino_fwd_fits(conv_cin, conv_cout, int(hw[0]), int(hw[1])))
 
 
-def _bf16_stem_on_valu(conv_cin: int, conv_cout: int, epilogue: int) -> bool:
-    """In native bf16 mode the 3-channel stem layer (the shapes ptmi_conv3x3_fwd sends to its VALU stem kernel) keeps that
-    kernel: x and W are rounded by tensor passes (51 MB and 7 KB at the bench shape) and multiplied in fp32 -- the same
-    numbers as the bf16 MFMA kernel up to summation order, at half its time (K = 27 gives the matrix core nothing to do)."""
-    return _native_bf16() and epilogue in (0, 1) and conv_cin <= 4 and conv_cout <= 64
-
-
 def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int, hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
     """Packed weights for conv3x3_raw(..., epilogue) (mode 0) or for the dgrad launch (mode 1: epilogue 2 / 3).  hw = (H, W)
     of the map the weights will be applied to: decides between the Winograd and the direct pack for maps beyond the Winograd
     kernel's 32-bit offsets (None = the map fits; conv3x3_raw checks the pack it is handed against its own routing)."""
+    _no_native_bf16("ops.conv3x3_pack")
     _chk(w, name="conv weight")
     co, ci = w.shape[0], w.shape[1]
     conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
@@ -264,17 +260,13 @@ def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int, hw: Optional[Tuple[i
         return wp
     n = _lib.load().ptmi_conv3x3_packed_floats(conv_cin, conv_cout)
     wp = torch.empty(n, dtype=F32, device=w.device)
-    if _bf16_stem_on_valu(conv_cin, conv_cout, epilogue):
-        w = w.to(torch.bfloat16).to(F32)
-        sym = "ptmi_conv3x3_pack_weights"
-    else:   # (the bf16-input kernels take their weights rounded and in MFMA operand order)
-        sym = "ptmi_conv3x3_pack_weights_bf16" if _native_bf16() else "ptmi_conv3x3_pack_weights"
-    _lib.call(sym, _ptr(w), _ptr(wp), co, ci, mode, _stream())
+    _lib.call("ptmi_conv3x3_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
     return wp
 
 
 def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor:
     """wp = conv3x3_pack(w, mode, epilogue) with the SAME epilogue."""
+    _no_native_bf16("ops.conv3x3_raw")
     _chk(x, name="conv input")
     n, cin, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
@@ -289,17 +281,16 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
             _lib.call("ptmi_conv3x3_wino_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
                       epilogue, _stream())
         return y
-    stem = _bf16_stem_on_valu(cin, cout, epilogue)
-    if stem:
-        x = x.to(torch.bfloat16).to(F32)
     with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, nbytes):
-        _lib.call("ptmi_conv3x3_fwd" if stem else _conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n,
-                  cin, cout, h, w, epilogue, _stream())
+        _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w, epilogue, _stream())
     return y
 
 
 def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     """conv3x3 + bias + ReLU + MaxPool(2,2) in ONE kernel (epilogue 4); inference-only (no autograd state)."""
+    if _native_bf16():
+        from . import p8
+        return p8.conv3x3_relu_pool_nograd_nchw(_chk(x.contiguous(), name="conv input"), weight, bias)
     x = _chk(_rnd(x).contiguous(), name="conv input")
     n, cin, h, w = x.shape
     cout = weight.shape[0]
@@ -309,7 +300,7 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     with _prof("conv3x3_wino" if wino else "conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n,
                4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout),
                wino_issued_flops(n, cin, cout, h, w) if wino else None):
-        _lib.call("ptmi_conv3x3_wino_fwd" if wino else _conv_fwd_sym(), _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None,
+        _lib.call("ptmi_conv3x3_wino_fwd" if wino else "ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None,
                   _ptr(y), n, cin, cout, h, w, 4, _stream())
     return y
 
@@ -354,6 +345,9 @@ class _Conv3x3(torch.autograd.Function):
 
 
 def conv3x3(x, weight, bias, relu: bool = True):
+    if _native_bf16():
+        from . import p8
+        return p8.conv3x3_nchw(_chk(x.contiguous(), name="conv input"), weight, bias, relu)
     return _Conv3x3.apply(x, weight, bias, relu)
 
 
@@ -440,6 +434,9 @@ class _VGGBlock(torch.autograd.Function):
 
 def vgg_block(x, pool: bool, params):
     """params = [w1, b1, w2, b2, ...]."""
+    if _native_bf16():
+        from . import p8
+        return p8.vgg_block_nchw(_chk(x.contiguous(), name="block input"), pool, params)
     if _OPERAND_ROUNDING == "bf16_emulate":    # layer by layer: every conv rounds its own operands
         for j in range(len(params) // 2):
             x = conv3x3(x, params[2 * j], params[2 * j + 1], True)

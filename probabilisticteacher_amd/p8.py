@@ -1,13 +1,15 @@
 """bf16 STORAGE path of the convolution stack (SOLVER.AMP.ENABLED; csrc/p8.hip, C ABI ptmi_p8_*).
 
-A `P8` value is a bf16 activation (or activation-gradient) tensor in the padded 8-channel-block layout
-`t[ceil(C/8)][N (H + 1) + 1][W + 1][8]` (include/ptmi355.h) together with its logical shape.  torch carries the storage
-(a `torch.bfloat16` tensor), the current stream and the autograd tape; every operator body is a HIP kernel.
+A P8 tensor is a bf16 activation (or activation-gradient) tensor in the padded 8-channel-block layout
+`t[2 ceil(C/16)][N (H + 1) + 1][W + 1][8]` (include/ptmi355.h).  torch carries the storage (a `torch.bfloat16` tensor), the
+current stream and the autograd tape; every operator body is a HIP kernel.  `ops` routes its 3x3-convolution entry points here
+when the operand-rounding mode is "bf16" (what SOLVER.AMP.ENABLED selects); the backbone keeps P8 tensors between its layers
+(`VGGPipeline`) and converts to fp32 NCHW once, at the feature map the RPN / ROI heads consume.
 
 Numerics (what the parity tests state): a P8 tensor holds values ROUNDED to bf16 (nearest even) at the moment they are
-stored; convolutions multiply bf16 operands exactly and accumulate in fp32 -- the same numbers, up to fp32 summation order,
-as ops' "bf16" operand-rounding mode produces with fp32 tensors in HBM (a rounded activation is what the next layer
-consumes either way), at half the bytes."""
+stored; convolutions multiply bf16 operands exactly and accumulate in fp32; weight / bias gradients and everything outside the
+convolution stack stay fp32 -- the numerics of ops' "bf16_emulate" mode (fp32 kernels on tensors rounded by separate passes) up
+to fp32 summation order and the rounding of the stored results."""
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
@@ -21,29 +23,33 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+def planes(c: int) -> int:
+    return 2 * (-(-c // 16))
+
+
 def plane_pixels(n: int, h: int, w: int) -> int:
     return (n * (h + 1) + 1) * (w + 1)
 
 
-def _alloc(cb: int, n: int, h: int, w: int, device) -> torch.Tensor:
-    return torch.empty((cb, n * (h + 1) + 1, w + 1, 8), dtype=BF16, device=device)
+def _alloc(c: int, n: int, h: int, w: int, device) -> torch.Tensor:
+    return torch.empty((planes(c), n * (h + 1) + 1, w + 1, 8), dtype=BF16, device=device)
 
 
 def _chk(t: torch.Tensor, c: int, n: int, h: int, w: int, name: str):
-    want = (-(-c // 8), n * (h + 1) + 1, w + 1, 8)
+    want = (planes(c), n * (h + 1) + 1, w + 1, 8)
     if not t.is_cuda or t.dtype != BF16 or tuple(t.shape) != want or not t.is_contiguous():
         raise _lib.PtmiError(f"{name}: expected a contiguous ROCm bf16 P8 tensor of shape {want}, got {t.dtype} {tuple(t.shape)}")
     return t
 
 
-def from_nchw(x: torch.Tensor, cb_out: Optional[int] = None) -> torch.Tensor:
-    """fp32 (N, C, H, W) -> P8 storage with cb_out (default ceil(C/8)) channel blocks; values rounded to bf16"""
+# ============================================================================ raw launches
+def from_nchw(x: torch.Tensor) -> torch.Tensor:
+    """fp32 (N, C, H, W) -> P8 storage (values rounded to bf16, channels padded to whole 16-channel chunks with zeros)"""
     x = ops._chk(x.contiguous(), name="p8.from_nchw input")
     n, c, h, w = x.shape
-    cb = -(-c // 8) if cb_out is None else cb_out
-    y = _alloc(cb, n, h, w, x.device)
+    y = _alloc(c, n, h, w, x.device)
     with ops._prof("p8_convert"):
-        _lib.call("ptmi_p8_from_nchw", ops._ptr(x), ops._ptr(y), n, c, cb, h, w, ops._stream())
+        _lib.call("ptmi_p8_from_nchw", ops._ptr(x), ops._ptr(y), n, c, h, w, ops._stream())
     return y
 
 
@@ -66,18 +72,31 @@ def pack_weights(w: torch.Tensor, mode: int) -> torch.Tensor:
 
 def conv3x3_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], mask_ref: Optional[torch.Tensor], n: int,
                 cin: int, cout: int, h: int, w: int, epilogue: int) -> torch.Tensor:
-    """one launch of ptmi_p8_conv3x3; cin = the channel count the P8 input is padded to (a multiple of 16)"""
-    y = _alloc(cout // 8, n, h, w, x.device)
+    """one launch of ptmi_p8_conv3x3 (epilogue 0: + bias, 1: + bias + ReLU, 2: none, 3: times (mask_ref > 0))"""
+    y = _alloc(cout, n, h, w, x.device)
     flops = 2.0 * 9 * cin * cout * h * w * n
     nbytes = 2.0 * plane_pixels(n, h, w) * (cin + cout * (2 if epilogue == 3 else 1)) + 2.0 * 9 * cin * cout
+    if mask_ref is not None:
+        _chk(mask_ref, cout, n, h, w, "p8 conv mask")
     with ops._prof("p8_conv3x3", flops, nbytes):
         _lib.call("ptmi_p8_conv3x3", ops._ptr(_chk(x, cin, n, h, w, "p8 conv input")), ops._ptr(wp),
                   ops._ptr(bias), ops._ptr(mask_ref), ops._ptr(y), n, cin, cout, h, w, epilogue, ops._stream())
     return y
 
 
+def wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, cin: int, cout: int, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dW (cout, cin, 3, 3), db (cout,)) fp32 from the layer's P8 input and P8 output gradient"""
+    dw = torch.empty((cout, cin, 3, 3), dtype=F32, device=x.device)
+    db = torch.empty(cout, dtype=F32, device=x.device)
+    ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+    with ops._prof("p8_wgrad", 2.0 * 9 * cin * cout * h * w * n):
+        _lib.call("ptmi_p8_wgrad", ops._ptr(_chk(x, cin, n, h, w, "p8 wgrad input")), ops._ptr(_chk(dy, cout, n, h, w, "p8 wgrad grad")),
+                  ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0, ops._stream())
+    return dw, db
+
+
 def maxpool_fwd(x: torch.Tensor, n: int, c: int, h: int, w: int) -> torch.Tensor:
-    y = _alloc(c // 8, n, h // 2, w // 2, x.device)
+    y = _alloc(c, n, h // 2, w // 2, x.device)
     with ops._prof("p8_maxpool_fwd"):
         _lib.call("ptmi_p8_maxpool2x2_fwd", ops._ptr(_chk(x, c, n, h, w, "p8 pool input")), ops._ptr(y), n, c, h, w, ops._stream())
     return y
@@ -93,7 +112,8 @@ def maxpool_bwd(x: torch.Tensor, dy: torch.Tensor, n: int, c: int, h: int, w: in
 
 def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     dz = torch.empty_like(dy)
-    _lib.call("ptmi_p8_relu_bwd", ops._ptr(dy), ops._ptr(y), ops._ptr(dz), dy.numel() // 8, ops._stream())
+    with ops._prof("p8_relu_bwd"):
+        _lib.call("ptmi_p8_relu_bwd", ops._ptr(dy), ops._ptr(y), ops._ptr(dz), dy.numel() // 8, ops._stream())
     return dz
 
 
@@ -103,12 +123,122 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, cin: int, cout: int, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(dW (cout, cin, 3, 3), db (cout,)) fp32 from the layer's P8 input and P8 output gradient; cin = x's padded channel count"""
-    dw = torch.empty((cout, cin, 3, 3), dtype=F32, device=x.device)
-    db = torch.empty(cout, dtype=F32, device=x.device)
-    ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
-    with ops._prof("p8_wgrad", 2.0 * 9 * cin * cout * h * w * n):
-        _lib.call("ptmi_p8_wgrad", ops._ptr(_chk(x, cin, n, h, w, "p8 wgrad input")), ops._ptr(_chk(dy, cout, n, h, w, "p8 wgrad grad")),
-                  ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0, ops._stream())
-    return dw, db
+# ============================================================================ autograd nodes
+class _ToNCHW(torch.autograd.Function):
+    """P8 -> fp32 NCHW (exact); backward rounds the fp32 gradient into a P8 gradient"""
+
+    @staticmethod
+    def forward(ctx, t, n, c, h, w):
+        ctx.meta = (n, c, h, w)
+        return to_nchw(t, n, c, h, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return from_nchw(dy), None, None, None, None
+
+
+class _FromNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.meta = tuple(x.shape)
+        return from_nchw(x)
+
+    @staticmethod
+    def backward(ctx, dt):
+        return to_nchw(dt.contiguous(), *ctx.meta)
+
+
+class _Block(torch.autograd.Function):
+    """k x [conv3x3 + bias + ReLU] (+ MaxPool 2x2) on P8 tensors as ONE autograd node (vgg.py:65-72): the counterpart of
+    ops._VGGBlock -- pool backward applies the last ReLU's mask, every dgrad launch the mask of the producing layer (epilogue 3),
+    weight + bias gradients come out of one kernel per layer."""
+
+    @staticmethod
+    def forward(ctx, x, n, cin, h, w, pool, *wb):
+        k = len(wb) // 2
+        acts, ws, c = [_chk(x, cin, n, h, w, "block input")], [], cin
+        for j in range(k):
+            wt, b = ops._chk(wb[2 * j].contiguous()), ops._chk(wb[2 * j + 1].contiguous())
+            ws.append(wt)
+            acts.append(conv3x3_raw(acts[-1], pack_weights(wt, 0), b, None, n, c, wt.shape[0], h, w, 1))
+            c = wt.shape[0]
+        out = maxpool_fwd(acts[-1], n, c, h, w) if pool else acts[-1]
+        ctx.meta = (k, pool, n, cin, h, w)
+        ctx.save_for_backward(*acts, *ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        k, pool, n, cin, h, w = ctx.meta
+        saved = ctx.saved_tensors
+        acts, ws = saved[: k + 1], saved[k + 1:]
+        cout = ws[-1].shape[0]
+        dout = dout.contiguous()
+        dz = maxpool_bwd(acts[k], dout, n, cout, h, w, True) if pool else relu_bwd(dout, acts[k])
+        grads = [None] * (2 * k)
+        dx = None
+        for j in range(k, 0, -1):
+            xin, wt = acts[j - 1], ws[j - 1]
+            co, ci = wt.shape[0], wt.shape[1]
+            if ctx.needs_input_grad[6 + 2 * (j - 1)] or ctx.needs_input_grad[7 + 2 * (j - 1)]:
+                grads[2 * (j - 1)], grads[2 * (j - 1) + 1] = wgrad(xin, dz, n, ci, co, h, w)
+            if j > 1:
+                dz = conv3x3_raw(dz, pack_weights(wt, 1), None, xin, n, co, ci, h, w, 3)       # dgrad + ReLU mask of layer j - 1
+            elif ctx.needs_input_grad[0]:
+                dx = conv3x3_raw(dz, pack_weights(wt, 1), None, None, n, co, ci, h, w, 2)
+        return (dx, None, None, None, None, None, *grads)
+
+
+def block(x: torch.Tensor, n: int, cin: int, h: int, w: int, pool: bool, params) -> torch.Tensor:
+    """P8 in, P8 out.  params = [w1, b1, w2, b2, ...]"""
+    return _Block.apply(x, n, cin, h, w, pool, *params)
+
+
+# ---------------------------------------------------------------------------- fp32-NCHW-facing entry points (ops routes here)
+def conv3x3_nchw(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
+    """ops.conv3x3 in "bf16" mode: fp32 NCHW in and out, the convolution and its gradients on the P8 kernels"""
+    n, cin, h, w = x.shape
+    t = _FromNCHW.apply(x) if x.requires_grad else from_nchw(x)
+    y = _Conv.apply(t, n, cin, h, w, relu, weight, bias)
+    return _ToNCHW.apply(y, n, weight.shape[0], h, w)
+
+
+class _Conv(torch.autograd.Function):
+    """one conv3x3 + bias (+ ReLU) on P8 tensors"""
+
+    @staticmethod
+    def forward(ctx, x, n, cin, h, w, relu, weight, bias):
+        weight, bias = ops._chk(weight.contiguous(), name="conv weight"), ops._chk(bias.contiguous(), name="conv bias")
+        y = conv3x3_raw(x, pack_weights(weight, 0), bias, None, n, cin, weight.shape[0], h, w, 1 if relu else 0)
+        ctx.meta = (n, cin, h, w, relu)
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, cin, h, w, relu = ctx.meta
+        x, weight, y = ctx.saved_tensors
+        cout = weight.shape[0]
+        dz = relu_bwd(dy.contiguous(), y) if relu else dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[6] or ctx.needs_input_grad[7]:
+            dw, db = wgrad(x, dz, n, cin, cout, h, w)
+        if ctx.needs_input_grad[0]:
+            dx = conv3x3_raw(dz, pack_weights(weight, 1), None, None, n, cout, cin, h, w, 2)
+        return dx, None, None, None, None, None, dw, db
+
+
+def vgg_block_nchw(x: torch.Tensor, pool: bool, params) -> torch.Tensor:
+    """ops.vgg_block in "bf16" mode (fp32 NCHW in and out)"""
+    n, cin, h, w = x.shape
+    t = _FromNCHW.apply(x) if x.requires_grad else from_nchw(x)
+    y = block(t, n, cin, h, w, pool, params)
+    cout = params[-2].shape[0]
+    return _ToNCHW.apply(y, n, cout, h // 2 if pool else h, w // 2 if pool else w)
+
+
+def conv3x3_relu_pool_nograd_nchw(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    y = conv3x3_raw(from_nchw(x), pack_weights(weight, 0), ops._chk(bias.contiguous()), None, n, cin, cout, h, w, 1)
+    return to_nchw(maxpool_fwd(y, n, cout, h, w), n, cout, h // 2, w // 2)

@@ -39,14 +39,15 @@ def main():
     ap.add_argument("--which", default="conv,wgrad,gemm,roi")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--layers", default="")
-    ap.add_argument("--bf16", action="store_true", help="the bf16-input kernels (ptmi_*_bf16); fractions stay relative "
-                                                        "to the fp32 MFMA peak")
+    ap.add_argument("--bf16", action="store_true", help="the FC GEMMs on ptmi_gemm_bf16 (fractions stay relative to the fp32 MFMA "
+                                                        "peak); the bf16 3x3 convolutions are tools/kbench_p8.py's")
     ap.add_argument("--algo", default="auto", choices=["auto", "direct"], help="fp32 forward / dgrad algorithm "
                     "(auto = fused Winograd where it applies; TF/s are ALGORITHMIC direct-convolution FLOPs either way)")
     a = ap.parse_args()
     ops.set_conv_algo(a.algo)
     if a.bf16:
         ops.set_operand_rounding("bf16")
+        a.which = ",".join(w for w in a.which.split(",") if w in ("gemm", "roi"))
     dev = "cuda:0"
     which = a.which.split(",")
     sel = a.layers.split(",") if a.layers else None
@@ -69,7 +70,7 @@ def main():
             ws = torch.empty(nws, device=dev)
 
             def f():
-                _lib.call(ops._conv_wgrad_sym(), ops._ptr(x), ops._ptr(dy), ops._ptr(dw), None, ops._ptr(ws), a.n, cin,
+                _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x), ops._ptr(dy), ops._ptr(dw), None, ops._ptr(ws), a.n, cin,
                           cout, h, w, 0, ops._stream())
             ms = timeit(f, a.iters)
             print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}")
