@@ -81,7 +81,7 @@ def test_config4_s2c_amp_step_native_vs_emulated_vs_fp32_oracle(monkeypatch, cap
     assert any(abs(mn[k] - om[k]) > 1e-6 for k in SUP), "AMP must change the numbers"
 
 
-def _hip_trajectory(st, key_seed0, pool_raw, sched, amp=False):
+def _hip_trajectory(st, key_seed0, pool_raw, sched, amp=False, rounding=None):
     """one HIP training run of the curve workload with the sampler keys of `key_seed0`; returns {loss key: per-iteration array}.
     amp: SOLVER.AMP.ENABLED (the reference's mixed-precision flag, pt/engine/trainer.py:98)"""
     from probabilisticteacher_amd.config import setup_cfg
@@ -97,6 +97,8 @@ def _hip_trajectory(st, key_seed0, pool_raw, sched, amp=False):
     ratios = []
     tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
     assert tr.operand_rounding == ("bf16" if amp else None)
+    if rounding is not None:          # (diagnostic runs: "bf16_emulate")
+        tr.operand_rounding = rounding
     for model in (tr.model, tr.model_teacher):
         sd = model.state_dict()
         with torch.no_grad():
