@@ -12,6 +12,7 @@ SETTINGS = dict(height=192, width=256, batch=2, pool=8, data_seed=2024, ratio_se
                 obj_min=0.30, obj_max=0.65)      # object extent as a fraction of the image extent (anchors are 128-512 px)
 LOSS_KEYS = ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")
 KEY_SEEDS = (1000, 5000, 9000)     # sampler-key seeds: one trajectory each (iteration `it` of a trajectory uses seed + it)
+AMP_EXTRA_SEEDS = (2000, 3000, 4000)   # HIP-side only: the SOLVER.AMP.ENABLED test runs these three trajectories as well
 
 
 def make_pool(settings, K):
