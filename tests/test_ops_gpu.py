@@ -998,10 +998,12 @@ def test_vgg_block_bf16_native(ops, pool):
             ops.set_operand_rounding(None)
         res[mode] = (yd.detach(), xd.grad, [t.grad for t in wd], [t.grad for t in bd], fused, fused3)
     e, nat = res["bf16_emulate"], res["bf16"]
+    # both modes round what is stored (native: in the kernels' epilogues; emulate: by passes): equal up to the summation order of the
+    # fp32 accumulators, i.e. up to a bf16 rounding boundary crossed here and there
     close_stored_bf16(nat[0], e[0], "block fwd")
     close_stored_bf16(nat[4], e[4], "fused conv+relu+pool")
     close_stored_bf16(nat[5], e[5], "fused conv+relu+pool, 3 input channels")
-    close(nat[1], e[1], 1e-2, 2e-3, "block dx")        # (stored as bf16; a handful of ReLU-mask flips between the two summation orders)
+    close(nat[1], e[1], 1e-2, 5e-3, "block dx")        # (a handful of ReLU-mask / pool-tie flips between the two summation orders)
     for i in range(3):
         close(nat[2][i], e[2][i], 5e-3, 5e-3, f"block dw{i}")
         close(nat[3][i], e[3][i], 5e-3, 5e-3, f"block db{i}")
@@ -1068,12 +1070,8 @@ def test_bf16_operand_rounding_mode(ops, mode):
         lyd.backward(lg.to(DEV))
     finally:
         ops.set_operand_rounding(None)
-    if mode == "bf16":      # stored in bf16 (p8.hip)
-        close_stored_bf16(yd, yr, "bf16-mode conv fwd")
-        close_stored_bf16(xd.grad, xr.grad, "bf16-mode conv dgrad")
-    else:
-        close(yd, yr, 1e-4, 1e-4, "bf16-mode conv fwd")
-        close(xd.grad, xr.grad, 1e-4, 2e-4, "bf16-mode conv dgrad")
+    close_stored_bf16(yd, yr, "bf16-mode conv fwd")          # stored in bf16 (p8.hip; emulated by a rounding pass)
+    close_stored_bf16(xd.grad, xr.grad, "bf16-mode conv dgrad")
     close(wd.grad, wr.grad, 1e-4, 1e-3, "bf16-mode conv wgrad")
     close(lyd, lyr, 1e-4, 1e-4, "bf16-mode linear fwd")
     close(lxd.grad, lxr.grad, 1e-4, 1e-4, "bf16-mode linear dx")
