@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void p8_from_nchw_kernel(const float* __restri
 }
 
 // P8 -> fp32 NCHW (exact: bf16 -> fp32)
-__global__ __launch_bounds__(256) void p8_to_nchw_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int C, int H, int W,
+__global__ __launch_bounds__(256) void p8_to_nchw_kernel(const u32x4* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
                                                          int HS, int WS, int64_t PT)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over N * H * W
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void p8_to_nchw_kernel(const u32x4* __restrict
     const int n = (int)(i / hw);
     const int64_t rem = i - n * hw;
     const int r = (int)(rem / W), c = (int)(rem - (int64_t)r * W);
-    if (n >= (int)gridDim.z) return;
+    if (n >= N) return;
     const u32x4 v = x[(int64_t)cb * PT + ((int64_t)n * HS + 1 + r) * WS + 1 + c];
     float* p = y + ((int64_t)n * C + cb * 8) * hw + rem;
 #pragma unroll
@@ -697,8 +697,8 @@ int ptmi_p8_to_nchw(const void* x, float* y, int n, int c, int h, int w, ptmi_st
 {
     PTMI_CHECK_ARG(x && y && n > 0 && c > 0 && h > 0 && w > 0, "p8_to_nchw: bad args");
     const P8Dims d = p8_dims(n, h, w);
-    hipLaunchKernelGGL(p8_to_nchw_kernel, dim3((unsigned)cdiv64((int64_t)n * h * w, 256), cdiv(c, 8), n), dim3(256), 0, (hipStream_t)s,
-                       (const u32x4*)x, y, c, h, w, d.HS, d.WS, d.PT);
+    hipLaunchKernelGGL(p8_to_nchw_kernel, dim3((unsigned)cdiv64((int64_t)n * h * w, 256), cdiv(c, 8)), dim3(256), 0, (hipStream_t)s,
+                       (const u32x4*)x, y, n, c, h, w, d.HS, d.WS, d.PT);
     PTMI_LAUNCH_CHECK("p8_to_nchw");
     return 0;
 }
