@@ -469,7 +469,7 @@ inline int p8_mt(int cout) { return cout <= 64 ? 2 : 4; }
 //   BIAS gradient sum_f dY[co][f], for free and with the two groups issuing 10 MFMAs per k-step each;
 //   K tile = 4 rows x 32 columns of the (ROWS x WS) grid = 8 k-steps of 16 pixels; LDS stage = dY [16 planes][128 px] (plane
 //   pitch + 64 B: the four planes a 32-lane read touches sit on disjoint bank quarters) + X [8 planes][6 x 34 px] (pitch 3264 B:
-//   the same by itself); two stages, the next tile's DMA issued one instruction per k-step;
+//   the same by itself); two stages, the next tile's DMA issued in the tile's first k-steps;
 //   split-K over contiguous tile ranges, fp32 partials [split][tap][co][ci] (+ [split][co] for db), fixed-order reduction.
 constexpr int GT = 512;                      // threads
 constexpr int G_CO = 128, G_CI = 64;
@@ -500,9 +500,11 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
     const unsigned x_bytes = (unsigned)((long long)xcb * PT * 16), dy_bytes = (unsigned)((long long)dcb * PT * 16);
     const __amdgpu_buffer_rsrc_t rx = ptmi_rsrc(x, x_bytes), rdy = ptmi_rsrc(dy, dy_bytes);
 
-    // ---- DMA pieces of this lane: dY 4 (wave w: planes 2 w, 2 w + 1; 128 pixels each), X 4 (pieces 64 (4 w + i) + lane of 1632)
+    // ---- DMA pieces of this lane: dY 4 (wave w: planes 2 w, 2 w + 1; 128 pixels each), X 4 (pieces 64 (4 w + i) + lane of 1632).
+    // Per lane: byte offset relative to the tile's first pixel (loop invariant); per tile: one scalar base + the validity of the
+    // piece (rows / columns beyond the grid are ZERO for dY: a column beyond WS would alias the next row's pixels)
     int dy_row[4], dy_col[4];
-    unsigned dy_plane[4];
+    unsigned dy_lane[4];
     bool dy_chan[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -511,36 +513,34 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
         dy_col[i] = pxl & 31;
         const int pg = cot * 16 + plane;
         dy_chan[i] = pg < dcb;
-        dy_plane[i] = (unsigned)((long long)pg * PT * 16);
+        dy_lane[i] = (unsigned)((long long)pg * PT * 16) + (unsigned)(dy_row[i] * WS + dy_col[i]) * 16u;
     }
-    int x_row[4], x_col[4];
+    int x_lane[4];
     unsigned x_plane[4];
     bool x_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = (4 * wave + i) * 64 + lane;
         const int plane = q / G_XPL, slot = q - plane * G_XPL;
-        x_row[i] = slot / 34 - 1;
-        x_col[i] = slot % 34 - 1;
+        x_lane[i] = (slot / 34 - 1) * WS + (slot % 34 - 1);
         const int pg = cit * 8 + plane;
         x_ok[i] = q < 8 * G_XPL && 4 * wave + i < 26 && pg < xcb;
         x_plane[i] = (unsigned)((long long)pg * PT * 16);
     }
-    auto issue = [&](auto i_c, int tile, int st) {
+    auto issue = [&](auto i_c, int R0, int C0, int st) {
         constexpr int I = decltype(i_c)::value;                 // 0..3 dY, 4..7 X
-        const int R0 = (tile / tilesC) * 4, C0 = (tile % tilesC) * 32;
+        const int tb = R0 * WS + C0;                             // (scalar) the tile's first flat pixel; < PT < 2^30
         char* base = lds + st * G_STAGE;
         if constexpr (I < 4) {
-            const int r = R0 + dy_row[I], c = C0 + dy_col[I];
-            const bool ok = dy_chan[I] && r < ROWS && c < WS && tile < t1;
-            const unsigned off = ok ? dy_plane[I] + (unsigned)(r * WS + c) * 16u : 0xFFFFFFFFu;
+            const bool ok = dy_chan[I] && R0 + dy_row[I] < ROWS && C0 + dy_col[I] < WS;
+            const unsigned off = ok ? dy_lane[I] + (unsigned)tb * 16u : 0xFFFFFFFFu;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (plds_void_t*)(base + (2 * wave + (I >> 1)) * G_DYP + (I & 1) * 1024), 16, (int)off, 0, 0, 0);
         } else {
             constexpr int i = I - 4;
             if (4 * wave + i < 26) {                             // (wave-uniform)
-                const long long flat = (long long)(R0 + x_row[i]) * WS + (C0 + x_col[i]);
-                const bool ok = x_ok[i] && flat >= 0 && flat < PT && tile < t1;
-                const unsigned off = ok ? x_plane[i] + (unsigned)flat * 16u : 0xFFFFFFFFu;
+                const unsigned flat = (unsigned)(tb + x_lane[i]);            // negative -> huge: out of range
+                const bool ok = x_ok[i] && flat < (unsigned)PT;
+                const unsigned off = ok ? x_plane[i] + flat * 16u : 0xFFFFFFFFu;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G_DYB + (4 * wave + i) * 1024), 16, (int)off, 0, 0, 0);
             }
         }
@@ -577,10 +577,11 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
     const ptmi_bf16x8 ones = __builtin_bit_cast(ptmi_bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
 
     if (t0 < t1) {
-        issue(std::integral_constant<int, 0>{}, t0, 0); issue(std::integral_constant<int, 1>{}, t0, 0);
-        issue(std::integral_constant<int, 2>{}, t0, 0); issue(std::integral_constant<int, 3>{}, t0, 0);
-        issue(std::integral_constant<int, 4>{}, t0, 0); issue(std::integral_constant<int, 5>{}, t0, 0);
-        issue(std::integral_constant<int, 6>{}, t0, 0); issue(std::integral_constant<int, 7>{}, t0, 0);
+        const int R0 = (t0 / tilesC) * 4, C0 = (t0 % tilesC) * 32;
+        issue(std::integral_constant<int, 0>{}, R0, C0, 0); issue(std::integral_constant<int, 1>{}, R0, C0, 0);
+        issue(std::integral_constant<int, 2>{}, R0, C0, 0); issue(std::integral_constant<int, 3>{}, R0, C0, 0);
+        issue(std::integral_constant<int, 4>{}, R0, C0, 0); issue(std::integral_constant<int, 5>{}, R0, C0, 0);
+        issue(std::integral_constant<int, 6>{}, R0, C0, 0); issue(std::integral_constant<int, 7>{}, R0, C0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -589,10 +590,22 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
         const int st = (tile - t0) & 1;
         const char* base = lds + st * G_STAGE;
         const int R0 = (tile / tilesC) * 4, C0 = (tile % tilesC) * 32;
+        const int R1 = ((tile + 1) / tilesC) * 4, C1 = ((tile + 1) % tilesC) * 32;
+        const bool more = tile + 1 < t1;
         auto kstep = [&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
-            // the next tile's pieces, one DMA instruction per k-step (into the other stage: everybody left it at the last barrier)
-            issue(std::integral_constant<int, s>{}, tile + 1, st ^ 1);
+            // the next tile's pieces go out EARLY (their latency hides behind the rest of the tile; issued at the end of the tile
+            // the hand-over waited 2/3 of the kernel's time for them), four per k-step, and staggered between the two waves of a
+            // SIMD (tap group 0: k-steps 0, 1; tap group 1: k-steps 2, 3) so that one of them keeps the matrix pipe busy meanwhile;
+            // into the other stage: everybody left it at the last barrier
+            if constexpr (s < 4) {
+                if (more && (s >> 1) == tg) {
+                    issue(std::integral_constant<int, (s & 1) * 4 + 0>{}, R1, C1, st ^ 1);
+                    issue(std::integral_constant<int, (s & 1) * 4 + 1>{}, R1, C1, st ^ 1);
+                    issue(std::integral_constant<int, (s & 1) * 4 + 2>{}, R1, C1, st ^ 1);
+                    issue(std::integral_constant<int, (s & 1) * 4 + 3>{}, R1, C1, st ^ 1);
+                }
+            }
             // k-steps whose 16 pixels lie beyond the grid carry only zeros in dY: skip them (wave-uniform)
             if (R0 + (s >> 1) < ROWS && C0 + 16 * (s & 1) < WS) {
                 const ptmi_bf16x8 A0 = rd(base + a_base + s * 256), A1 = rd(base + a_base + 4 * G_DYP + s * 256);

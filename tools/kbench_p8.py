@@ -39,7 +39,11 @@ def main():
     ap.add_argument("--which", default="conv,dgrad,wgrad")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--layers", default="")
+    ap.add_argument("--lib", default="", help="another build of libptmi355.so (tools/exp/p8_variants.sh)")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands (DVFS check: the same kernel at lower power)")
     a = ap.parse_args()
+    if a.lib:
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     dev = "cuda:0"
     which = a.which.split(",")
     sel = a.layers.split(",") if a.layers else None
@@ -48,7 +52,7 @@ def main():
             continue
         n = a.n
         # random bf16 data (not zeros: DVFS), written straight into the P8 storage incl. the pads -- timing only
-        x = (torch.randn((cin // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * 0.5).to(torch.bfloat16)
+        x = (torch.randn((cin // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * (0.0 if a.zeros else 0.5)).to(torch.bfloat16)
         wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
         b = torch.zeros(cout, device=dev)
         fl = 2.0 * 9 * cin * cout * h * w * n
@@ -63,7 +67,7 @@ def main():
             print(f"{name:8s} dgrad n={n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
             del dy
         if "wgrad" in which and hasattr(p8, "wgrad") and cin >= 64:
-            dy = (torch.randn((cout // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * 0.5).to(torch.bfloat16)
+            dy = (torch.randn((cout // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * (0.0 if a.zeros else 0.5)).to(torch.bfloat16)
             ms = timeit(lambda: p8.wgrad(x, dy, n, cin, cout, h, w), a.iters)
             print(f"{name:8s} wgrad n={n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
             del dy
