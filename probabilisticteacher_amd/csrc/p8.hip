@@ -235,7 +235,7 @@ template <int MT>
 __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     const u16* __restrict__ x, const u16* __restrict__ wp, const float* __restrict__ bias, const u16* __restrict__ mref,
     u16* __restrict__ y, int Cout, int ycb, int HS, int WS, int ROWS, long long PT, int nChunks, int epi, int coTiles, int tilesC,
-    int nPix)
+    int nPix, int nWork)
 {
     using G = P8G<MT>;
     constexpr int NTB = G::NTB;
@@ -243,36 +243,56 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup -> (channel tile, pixel tile): the channel tiles of a pixel tile run back to back on ONE XCD (workgroup id mod 8),
-    // so its patch leaves HBM once
-    const int slot = blockIdx.x >> 3;
-    const int cot = slot % coTiles;
-    const int pix = (slot / coTiles) * 8 + (blockIdx.x & 7);
-    if (pix >= nPix) return;
-    const int R0 = (pix / tilesC) * G::TR, C0 = (pix % tilesC) * G::TC;
+    // PERSISTENT workgroups: one per CU (the two LDS stages leave no room for a second), each walking work items blockIdx.x,
+    // + gridDim.x, ...  The last chunk of a tile treats the first chunk of the workgroup's NEXT tile as its successor -- DMA during
+    // its taps, hand-over, first operand reads -- so that only the epilogue separates the MFMA streams of two tiles (one tile per
+    // workgroup left the prologue -- 14 DMA issues + their latency -- exposed once per tile: 15 % of a 4-chunk conv1_2 tile).
+    // work item -> (channel tile, pixel tile): the channel tiles of a pixel tile run back to back on ONE XCD (item id mod 8 = the
+    // workgroup id mod 8: gridDim.x is a multiple of 8), so its patch leaves HBM once
+    auto decode = [&](int t, int& cot_, int& R0_, int& C0_) {
+        const int slot = t >> 3;
+        cot_ = slot % coTiles;
+        const int pix = (slot / coTiles) * 8 + (t & 7);
+        R0_ = (pix / tilesC) * G::TR;
+        C0_ = (pix % tilesC) * G::TC;
+        return t < nWork && pix < nPix;
+    };
+    auto next_valid = [&](int t, int& cot_, int& R0_, int& C0_) {       // first valid item at or after t on this workgroup's walk, or -1
+        while (t < nWork) {
+            if (decode(t, cot_, R0_, C0_)) return t;
+            t += (int)gridDim.x;
+        }
+        return -1;
+    };
+    int cot, R0, C0;
+    int t = next_valid((int)blockIdx.x, cot, R0, C0);
+    if (t < 0) return;
 
-    // ---- DMA set-up: per-lane source offsets of the patch pieces (loop invariant; the chunk advance moves the descriptor)
-    unsigned pvoff[G::PIN];
+    // ---- DMA set-up: per-lane source offsets of a tile's patch pieces (the chunk advance moves the descriptor)
+    auto patch_offsets = [&](int R0_, int C0_, unsigned (&pv)[G::PIN]) {
 #pragma unroll
-    for (int i = 0; i < G::PIN; ++i) {
-        const int piece = (i * 4 + wave) * 64 + lane;
-        const int plane = piece >= G::PPL ? 1 : 0;
-        const int q = piece - plane * G::PPL;
-        const int prow = q / G::PC, pcol = q - prow * G::PC;
-        const long long flat = (long long)(R0 - 1 + prow) * WS + (C0 - 1 + pcol);
-        const bool ok = piece < 2 * G::PPL && flat >= 0 && flat < PT;
-        pvoff[i] = ok ? (unsigned)((plane * PT + flat) * 16) : 0xFFFFFFFFu;
-    }
+        for (int i = 0; i < G::PIN; ++i) {
+            const int piece = (i * 4 + wave) * 64 + lane;
+            const int plane = piece >= G::PPL ? 1 : 0;
+            const int q = piece - plane * G::PPL;
+            const int prow = q / G::PC, pcol = q - prow * G::PC;
+            const long long flat = (long long)(R0_ - 1 + prow) * WS + (C0_ - 1 + pcol);
+            const bool ok = piece < 2 * G::PPL && flat >= 0 && flat < PT;
+            pv[i] = ok ? (unsigned)((plane * PT + flat) * 16) : 0xFFFFFFFFu;
+        }
+    };
+    unsigned pv_cur[G::PIN], pv_next[G::PIN], pvd[G::PIN];     // this tile's / the next tile's / the ones the DMA slots use
+    patch_offsets(R0, C0, pv_cur);
     const unsigned chunk_bytes_lo = (unsigned)((2 * PT * 16) & 0xFFFFFFFFll);      // < 4 GB (checked by the launcher)
     const unsigned wvoff = (unsigned)lane * 16u;
 
-    // descriptors of a chunk's weight slab and of its two input planes; a chunk beyond the last one gets EMPTY descriptors: its DMA
+    // descriptors of a chunk's weight slab and of its two input planes; `live` = false gives EMPTY descriptors: the DMA
     // instructions are still issued (every lane out of range: zero fill, no memory traffic) so that the loop has no tail copies
-    auto desc_w = [&](int chunk) {
-        return ptmi_rsrc(wp + ((size_t)(cot * nChunks + chunk) * G::WBYTES) / 2, chunk < nChunks ? (unsigned)G::WBYTES : 0u);
+    auto desc_w = [&](int cot_, int chunk, bool live) {
+        return ptmi_rsrc(wp + ((size_t)(cot_ * nChunks + chunk) * G::WBYTES) / 2, live ? (unsigned)G::WBYTES : 0u);
     };
-    auto desc_x = [&](int chunk) { return ptmi_rsrc(x + (size_t)chunk * 2 * PT * 8, chunk < nChunks ? chunk_bytes_lo : 0u); };
-    auto dma = [&](auto d_c, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rx, char* base) {
+    auto desc_x = [&](int chunk, bool live) { return ptmi_rsrc(x + (size_t)chunk * 2 * PT * 8, live ? chunk_bytes_lo : 0u); };
+    auto dma = [&](auto d_c, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rx, char* base, const unsigned (&pv)[G::PIN]) {
         constexpr int d = decltype(d_c)::value;
         if constexpr (d < G::WIN) {
             const int piece = d * 4 + wave;
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (plds_void_t*)(base + piece * 1024), 16, (int)wvoff, piece * 1024, 0, 0);
         } else if constexpr (d - G::WIN < G::PIN) {
             constexpr int i = d - G::WIN;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G::WBYTES + (i * 4 + wave) * 1024), 16, (int)pvoff[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (plds_void_t*)(base + G::WBYTES + (i * 4 + wave) * 1024), 16, (int)pv[i], 0, 0, 0);
         }
     };
 
@@ -289,30 +309,16 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     const int a_off = lane * 16;                                                     // + stage + (tap MT + mt) 1024
     const int b_off = G::WBYTES + (h * G::PPL + wave * NTB * G::PC + px) * 16;       // + stage + ((nt + ky) PC + kx) 16
 
-    // biases of the lane's channels: co = (cot MT + m) 32 + 8 q + 4 h + e, fetched before the first DMA (in-order vmcnt)
-    f32x4 bv[MT][4];
-    {
-        const __amdgpu_buffer_rsrc_t rb = ptmi_rsrc(bias ? (const void*)bias : (const void*)y, bias ? (unsigned)Cout * 4u : 0u);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                bv[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (epi <= 1)
-                    bv[m][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ((cot * MT + m) * 32 + 8 * q + 4 * h) * 4, 0, 0));
-            }
-    }
-
-    {
-        const __amdgpu_buffer_rsrc_t rw = desc_w(0), rx = desc_x(0);
-        dma(std::integral_constant<int, 0>{}, rw, rx, lds);   dma(std::integral_constant<int, 1>{}, rw, rx, lds);
-        dma(std::integral_constant<int, 2>{}, rw, rx, lds);   dma(std::integral_constant<int, 3>{}, rw, rx, lds);
-        dma(std::integral_constant<int, 4>{}, rw, rx, lds);   dma(std::integral_constant<int, 5>{}, rw, rx, lds);
-        dma(std::integral_constant<int, 6>{}, rw, rx, lds);   dma(std::integral_constant<int, 7>{}, rw, rx, lds);
-        dma(std::integral_constant<int, 8>{}, rw, rx, lds);   dma(std::integral_constant<int, 9>{}, rw, rx, lds);
-        dma(std::integral_constant<int, 10>{}, rw, rx, lds);  dma(std::integral_constant<int, 11>{}, rw, rx, lds);
-        dma(std::integral_constant<int, 12>{}, rw, rx, lds);  dma(std::integral_constant<int, 13>{}, rw, rx, lds);
-        dma(std::integral_constant<int, 14>{}, rw, rx, lds);
+    {   // the very first chunk of the workgroup: nothing to hide it behind
+        const __amdgpu_buffer_rsrc_t rw = desc_w(cot, 0, true), rx = desc_x(0, true);
+        dma(std::integral_constant<int, 0>{}, rw, rx, lds, pv_cur);   dma(std::integral_constant<int, 1>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 2>{}, rw, rx, lds, pv_cur);   dma(std::integral_constant<int, 3>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 4>{}, rw, rx, lds, pv_cur);   dma(std::integral_constant<int, 5>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 6>{}, rw, rx, lds, pv_cur);   dma(std::integral_constant<int, 7>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 8>{}, rw, rx, lds, pv_cur);   dma(std::integral_constant<int, 9>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 10>{}, rw, rx, lds, pv_cur);  dma(std::integral_constant<int, 11>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 12>{}, rw, rx, lds, pv_cur);  dma(std::integral_constant<int, 13>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 14>{}, rw, rx, lds, pv_cur);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -353,8 +359,8 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
             else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], acc[m][n], 0, 0, 0);
             if constexpr (J < MT) An[J] = read_a(src, NT_, J);
             else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);
-            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // chunk + 1 into the other stage: everybody left it at the
-                dma(std::integral_constant<int, TAP * 3 + (J - 10) / 2>{}, rw, rx, dst);           // last hand-over
+            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the
+                dma(std::integral_constant<int, TAP * 3 + (J - 10) / 2>{}, rw, rx, dst, pvd);      // last hand-over
             __builtin_amdgcn_sched_barrier(0);
         };
         slot_fn(std::integral_constant<int, 0>{});  slot_fn(std::integral_constant<int, 1>{});
@@ -371,54 +377,110 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
 
     const std::true_type T{};
     const std::false_type F{};
-    // nine k-steps per chunk: the two operand register sets swap roles from chunk to chunk, so the loop body is TWO chunks
-    auto chunk_even = [&](auto zc_c, int chunk) {
-        const __amdgpu_buffer_rsrc_t rw = desc_w(chunk + 1), rx = desc_x(chunk + 1);
-        kstep(std::integral_constant<int, 0>{}, zc_c, A0, B0, A1, B1, 0, rw, rx);
-        kstep(std::integral_constant<int, 1>{}, F, A1, B1, A0, B0, 0, rw, rx);
-        kstep(std::integral_constant<int, 2>{}, F, A0, B0, A1, B1, 0, rw, rx);
-        kstep(std::integral_constant<int, 3>{}, F, A1, B1, A0, B0, 0, rw, rx);
-        kstep(std::integral_constant<int, 4>{}, F, A0, B0, A1, B1, 0, rw, rx);
-        kstep(std::integral_constant<int, 5>{}, F, A1, B1, A0, B0, 0, rw, rx);
-        kstep(std::integral_constant<int, 6>{}, F, A0, B0, A1, B1, 0, rw, rx);
-        kstep(std::integral_constant<int, 7>{}, F, A1, B1, A0, B0, 0, rw, rx);
-        kstep(std::integral_constant<int, 8>{}, F, A0, B0, A1, B1, 0, rw, rx);
+    // nine k-steps per chunk: the two operand register sets swap roles from chunk to chunk.  A tile's chunks alternate
+    // even / odd bodies starting with an even one (three instantiations: even with a zero C operand, odd, even); the LDS stage
+    // is a running parity (`st`) of its own, because a tile with an odd chunk count hands the next tile the other stage.
+    auto chunk_even = [&](auto zc_c, int st, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rx) {
+        kstep(std::integral_constant<int, 0>{}, zc_c, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 1>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 2>{}, F, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 3>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 4>{}, F, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 5>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 6>{}, F, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 7>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 8>{}, F, A0, B0, A1, B1, st, rw, rx);
     };
-    auto chunk_odd = [&](int chunk) {
-        const __amdgpu_buffer_rsrc_t rw = desc_w(chunk + 1), rx = desc_x(chunk + 1);
-        kstep(std::integral_constant<int, 0>{}, F, A1, B1, A0, B0, 1, rw, rx);
-        kstep(std::integral_constant<int, 1>{}, F, A0, B0, A1, B1, 1, rw, rx);
-        kstep(std::integral_constant<int, 2>{}, F, A1, B1, A0, B0, 1, rw, rx);
-        kstep(std::integral_constant<int, 3>{}, F, A0, B0, A1, B1, 1, rw, rx);
-        kstep(std::integral_constant<int, 4>{}, F, A1, B1, A0, B0, 1, rw, rx);
-        kstep(std::integral_constant<int, 5>{}, F, A0, B0, A1, B1, 1, rw, rx);
-        kstep(std::integral_constant<int, 6>{}, F, A1, B1, A0, B0, 1, rw, rx);
-        kstep(std::integral_constant<int, 7>{}, F, A0, B0, A1, B1, 1, rw, rx);
-        kstep(std::integral_constant<int, 8>{}, F, A1, B1, A0, B0, 1, rw, rx);
+    auto chunk_odd = [&](int st, const __amdgpu_buffer_rsrc_t& rw, const __amdgpu_buffer_rsrc_t& rx) {
+        kstep(std::integral_constant<int, 0>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 1>{}, F, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 2>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 3>{}, F, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 4>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 5>{}, F, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 6>{}, F, A1, B1, A0, B0, st, rw, rx);
+        kstep(std::integral_constant<int, 7>{}, F, A0, B0, A1, B1, st, rw, rx);
+        kstep(std::integral_constant<int, 8>{}, F, A1, B1, A0, B0, st, rw, rx);
     };
-    chunk_even(T, 0);
-    if (nChunks > 1) chunk_odd(1);
-    for (int chunk = 2; chunk < nChunks; chunk += 2) {
-        chunk_even(F, chunk);
-        if (chunk + 1 < nChunks) chunk_odd(chunk + 1);
-    }
-
-    // ---- epilogue: C layout of the 32x32 tile: column = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 h = channel: a lane holds
-    // channels 8 q + 4 h + (0..3) of its pixel for q = 0..3 -- half of a pixel's 16-byte vector: 8-byte stores, a wave writes 512
-    // contiguous bytes per (mt, q, block)
     // (an accumulator element extracted in C++ makes the compiler copy whole 16-register tiles to VGPRs, all of them at the head of
     // the epilogue -- hundreds of spills; explicit v_accvgpr_read keeps the tiles where they are)
     auto rd = [](float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; };
-    unsigned svoff[NTB];                     // byte offset of the lane's pixel inside an 8-channel plane (0xFFFFFFFF: no store)
+    const unsigned plane_bytes = (unsigned)(PT * 16);
+
+    int st = 0;                                           // LDS stage of the chunk about to be computed
+    for (;;) {
+        int cotn, R0n, C0n;
+        const int tn = next_valid(t + (int)gridDim.x, cotn, R0n, C0n);
+        const bool more_tiles = tn >= 0;
+        if (more_tiles) patch_offsets(R0n, C0n, pv_next);
+#pragma unroll
+        for (int i = 0; i < G::PIN; ++i) pvd[i] = pv_cur[i];
+        // biases of the lane's channels: co = (cot MT + m) 32 + 8 q + 4 h + e; used in the epilogue, fetched now
+        f32x4 bv[MT][4];
+        {
+            const __amdgpu_buffer_rsrc_t rb = ptmi_rsrc(bias ? (const void*)bias : (const void*)y, bias ? (unsigned)Cout * 4u : 0u);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bv[m][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (epi <= 1)
+                        bv[m][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, ((cot * MT + m) * 32 + 8 * q + 4 * h) * 4, 0, 0));
+                }
+        }
+        // the successor of chunk c: chunk c + 1 of this tile, or -- after the last one -- chunk 0 of the workgroup's next tile
+        auto succ = [&](int chunk, __amdgpu_buffer_rsrc_t& rw, __amdgpu_buffer_rsrc_t& rx) {
+            const bool last = chunk + 1 == nChunks;
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < G::PIN; ++i) pvd[i] = pv_next[i];
+            }
+            rw = desc_w(last ? cotn : cot, last ? 0 : chunk + 1, !last || more_tiles);
+            rx = desc_x(last ? 0 : chunk + 1, !last || more_tiles);
+        };
+        {
+            __amdgpu_buffer_rsrc_t rw, rx;
+            succ(0, rw, rx);
+            chunk_even(T, st, rw, rx);
+            st ^= 1;
+            if (nChunks > 1) {
+                succ(1, rw, rx);
+                chunk_odd(st, rw, rx);
+                st ^= 1;
+            }
+            for (int chunk = 2; chunk < nChunks; chunk += 2) {
+                succ(chunk, rw, rx);
+                chunk_even(F, st, rw, rx);
+                st ^= 1;
+                if (chunk + 1 < nChunks) {
+                    succ(chunk + 1, rw, rx);
+                    chunk_odd(st, rw, rx);
+                    st ^= 1;
+                }
+            }
+            if (nChunks & 1) {       // an even body ran last: the next tile's first operands sit in the odd register set
+#pragma unroll
+                for (int m = 0; m < MT; ++m) A0[m] = A1[m];
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) B0[n] = B1[n];
+            }
+        }
+
+    unsigned mvoff[NTB];                     // byte offset of the lane's 8-byte half (mask loads; 0xFFFFFFFF: outside the grid)
     bool zero[NTB];                          // pad position: store zeros
+    unsigned svoff[NTB / 2];                 // byte offset of the 16-byte vector this lane stores for the block pair (n0, n1)
 #pragma unroll
     for (int n = 0; n < NTB; ++n) {
         const int Rg = R0 + wave * NTB + n, Cg = C0 + px;
         const bool inside = Rg < ROWS && Cg < WS;
         zero[n] = (Rg % HS) == 0 || Cg == 0;
-        svoff[n] = inside ? (unsigned)(((long long)Rg * WS + Cg) * 16 + h * 8) : 0xFFFFFFFFu;
+        mvoff[n] = inside ? (unsigned)(((long long)Rg * WS + Cg) * 16 + h * 8) : 0xFFFFFFFFu;
     }
-    const unsigned plane_bytes = (unsigned)(PT * 16);
+#pragma unroll
+    for (int j = 0; j < NTB / 2; ++j) {
+        const unsigned own = h ? mvoff[2 * j + 1] : mvoff[2 * j];
+        svoff[j] = own == 0xFFFFFFFFu ? own : own - (unsigned)h * 8u;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -430,8 +492,9 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
             if (epi == 3) {
                 const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(mref + (size_t)cb * PT * 8, plane_bytes);
 #pragma unroll
-                for (int n = 0; n < NTB; ++n) mk[n] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)svoff[n], 0, 0));
+                for (int n = 0; n < NTB; ++n) mk[n] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, (int)mvoff[n], 0, 0));
             }
+            u32x2 o[NTB];
 #pragma unroll
             for (int n = 0; n < NTB; ++n) {
                 float v[4];
@@ -447,11 +510,26 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
                     if ((mk[n][1] & 0x8000u) || !(mk[n][1] & 0x7FFFu)) v[2] = 0.f;
                     if ((mk[n][1] & 0x80000000u) || !(mk[n][1] & 0x7FFF0000u)) v[3] = 0.f;
                 }
-                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                if (zero[n]) o = (u32x2){0u, 0u};
-                __builtin_amdgcn_raw_buffer_store_b64(o, ry, (int)svoff[n], 0, 0);
+                o[n] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                if (zero[n]) o[n] = (u32x2){0u, 0u};
+            }
+#pragma unroll
+            for (int j = 0; j < NTB / 2; ++j) {
+                // (vdst, vsrc) -> vdst keeps its lower lanes and takes vsrc's lower lanes into its upper ones; vsrc takes vdst's upper
+                // lanes into its lower ones and keeps its upper lanes:  lower lanes end with (own n0 half, partner's n0 half), upper
+                // lanes with (partner's n1 half, own n1 half) -- channels 0..3 first in both
+                const auto s0 = __builtin_amdgcn_permlane32_swap(o[2 * j][0], o[2 * j + 1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(o[2 * j][1], o[2 * j + 1][1], false, false);
+                const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)svoff[j], 0, 0);
             }
         }
+    }
+        // ---- next tile of this workgroup (its first chunk is already in LDS, its first operands in registers)
+        if (!more_tiles) break;
+        t = tn; cot = cotn; R0 = R0n; C0 = C0n;
+#pragma unroll
+        for (int i = 0; i < G::PIN; ++i) pv_cur[i] = pv_next[i];
     }
 }
 
@@ -790,14 +868,21 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
     const int TR = MT == 4 ? P8G<4>::TR : P8G<2>::TR;
     const int tilesC = cdiv(d.WS, 32);
     const int64_t nPix = (int64_t)cdiv(d.ROWS, TR) * tilesC;
-    const int64_t nWg = cdiv64(nPix, 8) * 8 * coTiles;
-    PTMI_CHECK_ARG(nWg < (1ll << 31), "p8_conv3x3: too many tiles");
+    const int64_t nWork = cdiv64(nPix, 8) * 8 * coTiles;                // work items (some beyond nPix: skipped by the kernel)
+    PTMI_CHECK_ARG(nWork < (1ll << 31), "p8_conv3x3: too many tiles");
+    // persistent workgroups: one per CU (a multiple of 8: a work item stays on the XCD of its id mod 8)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+        cus = 256;
+    const int64_t grid = nWork < (cus / 8) * 8 ? nWork : (cus / 8) * 8;
     if (MT == 4)
-        hipLaunchKernelGGL(p8_conv3x3_kernel<4>, dim3((unsigned)nWg), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
-                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
+        hipLaunchKernelGGL(p8_conv3x3_kernel<4>, dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
+                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix,
+                           (int)nWork);
     else
-        hipLaunchKernelGGL(p8_conv3x3_kernel<2>, dim3((unsigned)nWg), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
-                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix);
+        hipLaunchKernelGGL(p8_conv3x3_kernel<2>, dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
+                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix,
+                           (int)nWork);
     PTMI_LAUNCH_CHECK("p8_conv3x3");
     return 0;
 }

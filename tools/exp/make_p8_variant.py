@@ -15,16 +15,16 @@ SRC = os.path.join(ROOT, "probabilisticteacher_amd", "csrc", "p8.hip")
 
 EDITS = [
     ("constexpr int P8T = 256;", "#ifndef P8X\n#define P8X 0\n#endif\nconstexpr int P8T = 256;"),
-    ("            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // chunk + 1 into the other stage: everybody left it at the\n"
+    ("            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the\n"
      "                dma(",
-     "            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // chunk + 1 into the other stage: everybody left it at the\n"
+     "            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the\n"
      "                if (!(P8X & 1)) dma("),
     ("            if constexpr (J < MT) An[J] = read_a(src, NT_, J);\n            else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);",
      "            if (!(P8X & 2)) {\n            if constexpr (J < MT) An[J] = read_a(src, NT_, J);\n            else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);\n            }"),
     ("        if constexpr (TAP == 8) {\n            asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");",
      "        if constexpr (TAP == 8 && !(P8X & 4)) {\n            asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");"),
-    ("                __builtin_amdgcn_raw_buffer_store_b64(o, ry, (int)svoff[n], 0, 0);",
-     "                if (!(P8X & 8)) __builtin_amdgcn_raw_buffer_store_b64(o, ry, (int)svoff[n], 0, 0);\n                else asm volatile(\"\" :: \"v\"(o));"),
+    ("                __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)svoff[j], 0, 0);",
+     "                if (!(P8X & 8)) __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)svoff[j], 0, 0);\n                else asm volatile(\"\" :: \"v\"(w));"),
     ("                if (more && (s >> 1) == tg) {", "                if (!(P8X & 16) && more && (s >> 1) == tg) {"),
     ("        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n    }\n\n    // ---- partials",
      "        if (!(P8X & 64)) {\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n        }\n    }\n\n    // ---- partials"),
