@@ -119,7 +119,7 @@ def measured_pmc_traffic(args):
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--output-format", "csv", "--",
                sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
                "--pmc-traffic", "off", "--per-gpu-batch", str(args.per_gpu_batch), "--height", str(args.height),
-               "--width", str(args.width)] + (["--student-only"] if args.student_only else []) + (["--amp"] if args.amp else [])
+               "--width", str(args.width)] + (["--student-only"] if args.student_only else []) + (["--amp"] if args.amp else [])  # (--config3 is already folded into --per-gpu-batch)
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, text=True, timeout=420)
@@ -158,12 +158,18 @@ def main():
                          "activation gradients in HBM / LDS for the 3x3 conv stack (ptmi_p8_*, v_mfma_f32_32x32x16_bf16), bf16 "
                          "operands for the FC GEMMs, fp32 accumulation, fp32 losses / optimiser; reported against the dense bf16 "
                          "MFMA peak")
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE configs[3]: global batch 64 labelled + 64 unlabelled on 8 GPUs = 8 + 8 per GPU (SURVEY 8d C4; "
+                         "pt/data/build.py:174-187 gives every rank total / world); sets --per-gpu-batch 8, so `--gpus N --config3` "
+                         "for N = 1, 2, 4, 8 is that config's weak-scaling curve and N = 8 its own number")
     ap.add_argument("--grad-reduce", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: the bucketed gradient exchange as all-reduce or as reduce-scatter + all-gather (engine/flat.py)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic after the timed region by re-running one step under rocprofv3 "
                          "PMC passes; off: report the committed profile's number, labelled as such")
     args = ap.parse_args()
+    if args.config3:
+        args.per_gpu_batch = 8
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -279,7 +285,7 @@ def main():
             "config": {"workload": (f"BASELINE configs[1]: final_c2f.yaml (K=8) student-only supervised fwd/bwd + clip + SGD, "
                                     f"per-GPU {2 * B} synthetic {W}x{H} images (strong + weak view of {B} labelled), random init"
                                     if args.student_only else
-                                    f"BASELINE configs[2]: final_c2f.yaml (K=8) full teacher+student+EMA step, per-GPU "
+                                    f"BASELINE configs[{'3' if args.config3 else '2'}]: final_c2f.yaml (K=8) full teacher+student+EMA step, per-GPU "
                                     f"{B} labelled + {B} unlabelled synthetic {W}x{H} images, BURN_UP_STEP=0, random init"),
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",

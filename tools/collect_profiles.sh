@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round profile set, on the GPU box:  bash tools/collect_profiles.sh r03   -> gpurun_out/<tag>_* (copy what is judged into profiles/)
-TAG=${1:-r03}
+# Round profile set, on the GPU box:  bash tools/collect_profiles.sh r04   -> gpurun_out/<tag>_* (copy what is judged into profiles/)
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
+# the headline line (fp32, 16 + 16), with traffic measured in the run and the CPU baseline
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_b16.json 2> gpurun_out/${TAG}_bench_b16.err
 tail -c 300 gpurun_out/${TAG}_bench_b16.err
 cd /tmp
@@ -14,5 +15,18 @@ cd $R
 timeout 1200 python tools/pmc_collect.py ${TAG}_bench_b16 2>&1 | tail -2
 timeout 600 python tools/kbench.py --n 16 --iters 3 > gpurun_out/${TAG}_kbench_per_layer_n16.txt 2>&1
 timeout 600 python tools/kbench.py --n 48 --which conv,wgrad --iters 2 > gpurun_out/${TAG}_kbench_per_layer_n48.txt 2>&1
-timeout 900 python bench.py --amp > gpurun_out/${TAG}_bench_b16_amp.json 2> gpurun_out/${TAG}_bench_b16_amp.err
-ls gpurun_out | head -40
+# SOLVER.AMP.ENABLED (bf16 storage kernels): bench line (traffic measured in the run), kernel stats, per-layer kernels, PMC of the two MFMA kernels
+timeout 900 python bench.py --amp --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_b16_amp.json 2> gpurun_out/${TAG}_bench_b16_amp.err
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_amp -o ${TAG}amp --output-format csv -- python $R/bench.py --amp --steps 2 --warmup 1 --no-cpu-baseline --pmc-traffic off > /dev/null 2> $R/gpurun_out/${TAG}_rocprof_amp.err
+cp $R/gpurun_out/${TAG}_prof_amp/${TAG}amp_kernel_stats.csv $R/gpurun_out/${TAG}_bench_b16_amp_kernel_stats.csv
+cd $R
+timeout 600 python tools/kbench_p8.py --n 16 --which conv,dgrad,wgrad,pool --iters 5 > gpurun_out/${TAG}_kbench_p8_per_layer_n16_bf16.txt 2>&1
+timeout 600 python tools/kbench_p8.py --n 48 --which conv,dgrad,wgrad --iters 3 > gpurun_out/${TAG}_kbench_p8_per_layer_n48_bf16.txt 2>&1
+timeout 600 bash tools/exp/p8_pmc.sh conv3_2 conv 48 > gpurun_out/${TAG}_p8_conv3_2_fwd_n48_pmc.txt 2>&1
+timeout 600 bash tools/exp/p8_pmc.sh conv3_2 wgrad 48 > gpurun_out/${TAG}_p8_conv3_2_wgrad_n48_pmc.txt 2>&1
+# BASELINE configs[1] at its own batch (8 images = 4 labelled x 2 views)
+timeout 600 python bench.py --student-only --per-gpu-batch 4 --steps 20 --warmup 5 --pmc-traffic off > gpurun_out/${TAG}_bench_config1_student_only_b8.json 2> /dev/null
+# BASELINE configs[3] per-GPU share (8 + 8) on one GPU: the N = 1 point of its weak-scaling curve
+timeout 600 python bench.py --config3 --steps 20 --warmup 5 --pmc-traffic off --no-cpu-baseline > gpurun_out/${TAG}_bench_config3_per_gpu_share_n1.json 2> /dev/null
+ls gpurun_out | head -60
