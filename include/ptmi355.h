@@ -128,6 +128,18 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
 int64_t ptmi_p8_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout,
                   int h, int w, int accumulate, ptmi_stream_t s);
+/* bf16-STORAGE GEMM for the box head's large Linear layer under SOLVER.AMP.ENABLED (FastRCNNConvFCHead fc1 25088 -> 1024 behind
+ * pt/modeling/roi_heads/roi_heads.py:126-128; cuBLAS bf16 under autocast): C[m][n] (fp32, row pitch ldc) = A . B^T (+ bias[n]) (+ ReLU)
+ * with BOTH operands bf16 in the "P8 matrix" layout t[ceil(k/8)][rows][8] (k in octets, one 16-byte vector per (row, octet)).
+ * ptmi_p8m_pack builds an operand from an fp32 matrix: element (row, k) = src[row * ld + k] (k_major = 1) or src[k * ld + row]
+ * (k_major = 0), rounded to bf16 (nearest even), zero beyond k; ptmi_p8m_elems bf16 elements.  Forward, dX and dW of a Linear layer
+ * are all of this form (operands packed with their contraction index as k).  Shapes with few tiles and long k run split-K through a
+ * caller-allocated workspace (ptmi_p8_gemm_nt_ws_floats floats; 0 = none), reduced in a fixed order. */
+int64_t ptmi_p8m_elems(int rows, int k);
+int ptmi_p8m_pack(const float* src, void* dst, int rows, int k, int64_t ld, int k_major, ptmi_stream_t s);
+int64_t ptmi_p8_gemm_nt_ws_floats(int m, int n, int k);
+int ptmi_p8_gemm_nt(const void* a, const void* b, float* c, const float* bias, float* ws, int m, int n, int k,
+                    int ldc, int relu, ptmi_stream_t s);
 /* dz = dy * (y > 0), elementwise (ReLU backward; F.relu_ at vgg.py:67). In-place allowed. */
 int ptmi_relu_bwd(const float* dy, const float* y, float* dz, int64_t numel, ptmi_stream_t s);
 

@@ -46,6 +46,10 @@ SIGNATURES = {
     "ptmi_p8_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_p8_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_p8_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_p8m_elems": (_i64, [_i, _i]),
+    "ptmi_p8m_pack": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp]),
+    "ptmi_p8_gemm_nt_ws_floats": (_i64, [_i, _i, _i]),
+    "ptmi_p8_gemm_nt": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ptmi_relu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "ptmi_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ptmi_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

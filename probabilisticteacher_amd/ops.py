@@ -516,6 +516,10 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x, weight, bias, relu: bool = False):
+    if _native_bf16() and x.shape[0] > 0:
+        from . import p8
+        if weight.shape[1] >= p8.LINEAR_MIN_K:          # fc1 (25088 -> 1024): bf16-storage GEMMs
+            return p8.linear(x, weight, bias, relu)
     return _Linear.apply(x, weight, bias, relu)
 
 

@@ -242,3 +242,63 @@ def conv3x3_relu_pool_nograd_nchw(x: torch.Tensor, weight: torch.Tensor, bias: t
     cout = weight.shape[0]
     y = conv3x3_raw(from_nchw(x), pack_weights(weight, 0), ops._chk(bias.contiguous()), None, n, cin, cout, h, w, 1)
     return to_nchw(maxpool_fwd(y, n, cout, h, w), n, cout, h // 2, w // 2)
+
+
+# ============================================================================ bf16-storage GEMM (the box head's large Linear layer)
+def pack_matrix(src: torch.Tensor, rows: int, k: int, ld: int, k_major: bool) -> torch.Tensor:
+    """fp32 matrix -> bf16 "P8 matrix" operand t[ceil(k/8)][rows][8]: element (row, kk) = src[row * ld + kk] (k_major) or
+    src[kk * ld + row] (not k_major)"""
+    dst = torch.empty((-(-k // 8), rows, 8), dtype=BF16, device=src.device)
+    with ops._prof("p8m_pack"):
+        _lib.call("ptmi_p8m_pack", ops._ptr(ops._chk(src, name="p8m_pack source")), ops._ptr(dst), rows, k, ld, int(k_major), ops._stream())
+    return dst
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, m: int, n: int, k: int, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """C (m, n) fp32 = A . B^T (+ bias) (+ ReLU) from two packed operands (pack_matrix) with k octets each"""
+    c = torch.empty((m, n), dtype=F32, device=a.device)
+    nws = _lib.load().ptmi_p8_gemm_nt_ws_floats(m, n, k)
+    ws = ops._ws("p8gemm", nws * 4, a.device) if nws else None
+    with ops._prof("p8_gemm", 2.0 * m * n * k):
+        _lib.call("ptmi_p8_gemm_nt", ops._ptr(a), ops._ptr(b), ops._ptr(c), ops._ptr(bias), ops._ptr(ws), m, n, k, n, int(relu), ops._stream())
+    return c
+
+
+class _LinearP8(torch.autograd.Function):
+    """y = x W^T + b (+ ReLU) with bf16-storage operands: forward, dX and dW are three launches of ONE kernel (C = A . B^T), each on
+    operands packed with their contraction index as k; fp32 accumulation, fp32 y / dX / dW / db."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu: bool):
+        x = ops._chk(x.contiguous(), name="linear input")
+        weight, bias = ops._chk(weight.contiguous()), ops._chk(bias.contiguous())
+        r, k = x.shape
+        n = weight.shape[0]
+        y = gemm_nt(pack_matrix(x, r, k, k, True), pack_matrix(weight, n, k, k, True), r, n, k, bias, relu)
+        # for dW the input is needed with the ROW index as k: packed now (bf16: half of what saving x would hold)
+        xt = pack_matrix(x, k, r, k, False) if ctx.needs_input_grad[1] else None
+        ctx.meta = (r, k, n, relu, ctx.needs_input_grad[0])
+        ctx.save_for_backward(xt, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xt, weight, y = ctx.saved_tensors
+        r, k, n, relu, need_dx = ctx.meta
+        dy = ops._chk(dy.contiguous())
+        dz = ops.relu_bwd(dy, y) if relu else dy
+        dx = dw = db = None
+        if need_dx:                                        # dX = dZ W:  A = dZ (k = n), B = W^T (rows = input feature, k = n)
+            dx = gemm_nt(pack_matrix(dz, r, n, n, True), pack_matrix(weight, k, n, k, False), r, k, n)
+        if ctx.needs_input_grad[1]:                        # dW = dZ^T X:  A = dZ^T (rows n, k = r), B = X^T (rows = input feature, k = r)
+            dw = gemm_nt(pack_matrix(dz, n, r, n, False), xt, n, k, r)
+        if ctx.needs_input_grad[2]:                        # the bias gradient sums the values the GEMMs consumed (rounded)
+            db = ops.colsum(dz.to(BF16).to(F32))
+        return dx, dw, db, None
+
+
+LINEAR_MIN_K = 4096        # below this (fc2, the predictors) the operand packs cost what the GEMM saves: ptmi_gemm_bf16 keeps those
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
+    return _LinearP8.apply(x, weight, bias, relu)

@@ -198,3 +198,69 @@ def test_p8_wgrad_full_size_layers(name, cin, cout, h, w):
     s, sb = float(wr.grad.abs().max()), float(br.grad.abs().max())
     assert float((dw.cpu() - wr.grad).abs().max()) <= 1e-4 * s, f"{name} dW"
     assert float((db.cpu() - br.grad).abs().max()) <= 1e-4 * sb, f"{name} db"
+
+
+GEMM_SHAPES = [  # m (rows), n (outputs), k
+    (300, 70, 200),            # one ragged tile, k not a multiple of 64 (zero-filled octets), no split
+    (512, 256, 1024),          # exact tiles
+    (257, 513, 136),           # one row / column beyond a tile boundary
+    (64, 1024, 25088),         # few tiles, long k: split-K through the workspace
+    (1000, 9, 1024),           # narrow output (predictor-like)
+    (5, 3, 8),
+]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
+def test_p8_gemm_nt_and_packs(m, n, k):
+    """ptmi_p8m_pack (both source orientations) + ptmi_p8_gemm_nt against float64 products of the bf16-rounded operands"""
+    from probabilisticteacher_amd import p8
+    a = rb(torch.randn(m, k, generator=g(51)))
+    b = rb(torch.randn(n, k, generator=g(52)))
+    bias = torch.randn(n, generator=g(53))
+    ref = a.double() @ b.double().t()
+    ap, bp = p8.pack_matrix(a.to(DEV), m, k, k, True), p8.pack_matrix(b.to(DEV), n, k, k, True)
+    assert ap.shape == ((k + 7) // 8, m, 8)
+    # the pack itself: element (row, kk) of the packed operand
+    back = ap.cpu().float().permute(1, 0, 2).reshape(m, -1)[:, :k]
+    assert torch.equal(back, a), "k-major pack"
+    at = p8.pack_matrix(a.t().contiguous().to(DEV), m, k, m, False)            # the same operand from the transposed source
+    assert torch.equal(at, ap), "row-major pack of the transposed source gives the same operand"
+    for relu in (False, True):
+        c = p8.gemm_nt(ap, bp, m, n, k, bias.to(DEV), relu).cpu().double()
+        want = ref + bias.double()
+        if relu:
+            want = want.clamp(min=0)
+        err = float((c - want).abs().max())
+        assert err <= 1e-5 * float(want.abs().max()) + 4e-6 * math.sqrt(k) + 1e-5, f"gemm relu={relu}: max abs err {err:.3e}"
+    c1 = p8.gemm_nt(ap, bp, m, n, k, None, False)
+    assert torch.equal(c1, p8.gemm_nt(ap, bp, m, n, k, None, False)), "bitwise reproducible (fixed-order split reduction)"
+
+
+def test_p8_linear_autograd_matches_torch_on_rounded_operands():
+    """p8._LinearP8 (what ops.linear runs for fc1 in "bf16" mode): y, dX, dW, db against torch CPU on bf16-rounded operands"""
+    from probabilisticteacher_amd import ops, p8
+    r, k, n = 700, 4608, 320
+    x = torch.randn(r, k, generator=g(61))
+    w = torch.randn(n, k, generator=g(62)) * 0.02
+    b = torch.randn(n, generator=g(63))
+    gy = torch.randn(r, n, generator=g(64))
+    xr, wr, br = rb(x).requires_grad_(), rb(w).requires_grad_(), b.clone().requires_grad_()
+    zr = F.linear(xr, wr, br)
+    yr = F.relu(zr)
+    yr.backward(rb(gy * (zr.detach() > 0)))          # the gradient that reaches the GEMMs is rounded
+    ops.set_operand_rounding("bf16")
+    try:
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+        yd = ops.linear(xd, wd, bd, True)
+        assert isinstance(yd.grad_fn, p8._LinearP8._backward_cls) or "LinearP8" in type(yd.grad_fn).__name__
+        yd.backward(gy.to(DEV))
+    finally:
+        ops.set_operand_rounding(None)
+    sc = lambda t: float(t.abs().max())
+    assert float((yd.detach().cpu() - yr.detach()).abs().max()) <= 1e-4 * sc(yr) + 1e-4
+    stable = zr.detach().abs() > 1e-4
+    assert float(stable.float().mean()) > 0.999
+    if bool(stable.all()):
+        assert float((xd.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * sc(xr.grad) + 1e-5
+        assert float((wd.grad.cpu() - wr.grad).abs().max()) <= 2e-4 * sc(wr.grad) + 1e-5
+        assert float((bd.grad.cpu() - br.grad).abs().max()) <= 2e-4 * sc(br.grad) + 1e-4

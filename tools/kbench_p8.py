@@ -78,6 +78,28 @@ def main():
             print(f"{name:8s} pool  n={n} {ms:9.3f} ms  {gb / ms:7.2f} TB/s", flush=True)
             del xo
         del x
+    if "gemm" in which:
+        for r in (8192, 16384, 32000):
+            k, nn = 25088, 1024
+            xa = (torch.randn((k // 8, r, 8), device=dev) * 0.5).to(torch.bfloat16)
+            wb = (torch.randn((k // 8, nn, 8), device=dev) * 0.05).to(torch.bfloat16)
+            b1 = torch.zeros(nn, device=dev)
+            fl = 2.0 * r * k * nn
+            ms = timeit(lambda: p8.gemm_nt(xa, wb, r, nn, k, b1, True), a.iters)
+            print(f"fc1 fwd  R={r:6d} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+            dz = (torch.randn((nn // 8, r, 8), device=dev) * 0.5).to(torch.bfloat16)
+            wt = (torch.randn((nn // 8, k, 8), device=dev) * 0.05).to(torch.bfloat16)
+            ms = timeit(lambda: p8.gemm_nt(dz, wt, r, k, nn), a.iters)
+            print(f"fc1 dx   R={r:6d} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+            dzt = (torch.randn((r // 8, nn, 8), device=dev) * 0.5).to(torch.bfloat16)
+            xt = (torch.randn((r // 8, k, 8), device=dev) * 0.5).to(torch.bfloat16)
+            ms = timeit(lambda: p8.gemm_nt(dzt, xt, nn, k, r), a.iters)
+            print(f"fc1 dw   R={r:6d} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+            src = torch.randn(r, k, device=dev)
+            ms = timeit(lambda: p8.pack_matrix(src, r, k, k, True), a.iters)
+            ms2 = timeit(lambda: p8.pack_matrix(src, k, r, k, False), a.iters)
+            print(f"fc1 pack R={r:6d} k-major {ms:7.3f} ms  row-major {ms2:7.3f} ms  ({src.numel() * 6 / 1e9:.2f} GB each)", flush=True)
+            del xa, dz, dzt, xt, src
 
 
 if __name__ == "__main__":
