@@ -47,7 +47,11 @@ def test_config4_s2c_mutual_learning_step_fp32_vs_oracle(monkeypatch, capsys, h,
     _compare_step(m, om, res["tr"], res["state"], res["params"], SUP + UNSUP, f"configs[4] {tag}")
 
 
-def test_config4_s2c_amp_step_native_vs_emulated_vs_fp32_oracle(monkeypatch, capsys):
+@pytest.mark.parametrize("h,w,n_img,tag", [(160, 208, 2, "fixture size"), (800, 1333, 1, "1333x800")])
+def test_config4_s2c_amp_step_native_vs_emulated_vs_fp32_oracle(monkeypatch, capsys, h, w, n_img, tag):
+    """one mutual-learning step with SOLVER.AMP.ENABLED: the bf16-storage kernels (csrc/p8.hip, p8gemm.hip) vs `bf16_emulate` (the fp32
+    kernels on tensors rounded by passes) vs the fp32 oracle -- at fixture size and, round 4, at 1333 x 800 (1 + 1 images: the
+    multi-tile, persistent-workgroup and split-K paths of the storage kernels inside a real step)"""
     from probabilisticteacher_amd import ops
     out = {}
     try:
@@ -55,7 +59,7 @@ def test_config4_s2c_amp_step_native_vs_emulated_vs_fp32_oracle(monkeypatch, cap
             with monkeypatch.context() as mp:
                 # the emulated run's student gets the native run's pseudo labels (its own teacher's differ by bf16-noise-driven
                 # index decisions, which is not what this comparison is about)
-                out[mode] = mutual_learning_step_vs_oracle(mp, S2C, 160, 208, n_img=2, seed=71, spread=_spread_k1,
+                out[mode] = mutual_learning_step_vs_oracle(mp, S2C, h, w, n_img=n_img, seed=71, spread=_spread_k1,
                                                            extra_cfg=("SOLVER.AMP.ENABLED", True), rounding=mode,
                                                            oracle=(mode == "bf16"), paired_views=True, ratio_range=(0.96, 1.0),
                                                            pseudo_from=out["bf16"]["tr"].mine if mode != "bf16" else None)
@@ -64,7 +68,7 @@ def test_config4_s2c_amp_step_native_vs_emulated_vs_fp32_oracle(monkeypatch, cap
         pass
     mn, me, om = out["bf16"]["m"], out["bf16_emulate"]["m"], out["bf16"]["om"]
     with capsys.disabled():
-        print(f"\n[configs[4] AMP] native {mn}\n emulate {me}\n fp32 oracle {om}")
+        print(f"\n[configs[4] AMP {tag}] native {mn}\n emulate {me}\n fp32 oracle {om}")
     for k in SUP + UNSUP:
         assert math.isfinite(mn[k]) and math.isfinite(me[k]) and math.isfinite(om[k]), k
     for k in ("loss_rpn_cls_sup", "loss_rpn_loc_sup", "loss_rpn_cls_unsup", "loss_rpn_loc_unsup"):

@@ -264,3 +264,32 @@ def test_p8_linear_autograd_matches_torch_on_rounded_operands():
         assert float((xd.grad.cpu() - xr.grad).abs().max()) <= 1e-4 * sc(xr.grad) + 1e-5
         assert float((wd.grad.cpu() - wr.grad).abs().max()) <= 2e-4 * sc(wr.grad) + 1e-5
         assert float((bd.grad.cpu() - br.grad).abs().max()) <= 2e-4 * sc(br.grad) + 1e-4
+
+
+def test_p8_conv3_2_at_n48_bench_launch_shape_vs_torch():
+    """ONE launch of each storage kernel at the joint student pass's batch (n = 48, 256 -> 256 at 200 x 333; `bench.py --amp` runs
+    this shape): forward + ReLU, masked dgrad (persistent workgroups walking ~17 tiles each, images stacked in the row dimension),
+    weight + bias gradient (32 K splits) -- against torch CPU fp32 on the bf16-rounded operands"""
+    import os
+    from probabilisticteacher_amd import p8
+    torch.set_num_threads(max(2, min(os.cpu_count() or 2, 64)))
+    n, c, h, w = 48, 256, 200, 333
+    x = rb(torch.relu(torch.randn(n, c, h, w, generator=g(71))))
+    wt = rb(torch.randn(c, c, 3, 3, generator=g(72)) * math.sqrt(2.0 / (9 * c)))
+    b = torch.randn(c, generator=g(73)) * 0.1
+    gy = rb(torch.randn(n, c, h, w, generator=g(74)))
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yr.backward(gy)
+    xp = p8.from_nchw(x.to(DEV))
+    yp = p8.conv3x3_raw(xp, p8.pack_weights(wt.to(DEV), 0), b.to(DEV), None, n, c, c, h, w, 1)
+    bf16_close(p8.to_nchw(yp, n, c, h, w), F.relu(yr.detach()), "conv3_2 forward n=48")
+    del yp
+    gp = p8.from_nchw(gy.to(DEV))
+    dx = p8.conv3x3_raw(gp, p8.pack_weights(wt.to(DEV), 1), None, xp, n, c, c, h, w, 3)
+    bf16_close(p8.to_nchw(dx, n, c, h, w), xr.grad * (x > 0), "conv3_2 dgrad + mask n=48")
+    del dx
+    dw, db = p8.wgrad(xp, gp, n, c, c, h, w)
+    s, sb = float(wr.grad.abs().max()), float(br.grad.abs().max())
+    assert float((dw.cpu() - wr.grad).abs().max()) <= 1e-4 * s, "conv3_2 wgrad n=48"
+    assert float((db.cpu() - br.grad).abs().max()) <= 1e-4 * sb, "conv3_2 bias grad n=48"
