@@ -215,13 +215,21 @@ __global__ __launch_bounds__(256) void p8_pack_weights_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
-template <int MT>
+// FLAT = false: a workgroup's pixels are a 2-D tile of TR rows x 32 columns of the (ROWS x WS) grid, the patch its (TR + 2) x 34 halo
+// box.  Column tiles of 32 waste 13 % of the MFMAs on WS = 167 (the 100 x 166 maps) and 12.5 % on WS = 84 (50 x 83).
+// FLAT = true (narrow maps, WS <= P8_FLAT_MAX_WS): the workgroup owns TP CONSECUTIVE FLAT pixels f0 .. f0 + TP - 1 of the plane --
+// rows, images and pad positions just follow one another (the pads are in the tensor, so nothing special happens at a row or image
+// end) -- and the patch is the contiguous flat range [f0 - WS - 1, f0 + TP + WS + 1): no column padding at all, one partly filled tile
+// per launch.  Tap offsets ky * WS are then run-time values (three address registers instead of one).
+constexpr int P8_FLAT_MAX_WS = 170;
+template <int MT, bool FLAT>
 struct P8G {
-    static constexpr int NTB = 16 / MT;                  // pixel blocks (1 row x 32 columns) per wave
-    static constexpr int TR = 4 * NTB;                   // tile rows per workgroup
-    static constexpr int TC = 32;                        // tile columns
-    static constexpr int PR = TR + 2, PC = TC + 2;       // patch rows / columns (halo of one)
-    static constexpr int PPL = PR * PC;                  // patch pixels per 8-channel plane
+    static constexpr int NTB = 16 / MT;                  // pixel blocks (32 pixels of a row / 32 flat pixels) per wave
+    static constexpr int TR = 4 * NTB;                   // tile rows per workgroup (2-D)
+    static constexpr int TC = 32;                        // tile columns (2-D)
+    static constexpr int TP = 4 * NTB * 32;              // tile pixels
+    static constexpr int PR = TR + 2, PC = TC + 2;       // patch rows / columns (2-D: halo of one)
+    static constexpr int PPL = FLAT ? TP + 2 * P8_FLAT_MAX_WS + 2 : PR * PC;     // patch pixels per 8-channel plane (FLAT: the most)
     static constexpr int PIN = (2 * PPL + P8T - 1) / P8T;   // patch DMA instructions per lane and chunk (2 planes)
     static constexpr int PBYTES = PIN * P8T * 16;        // patch bytes per stage (padded to whole DMA instructions)
     static constexpr int WBYTES = 9 * MT * 1024;         // weight slab bytes per (channel tile, chunk)
@@ -231,15 +239,16 @@ struct P8G {
     static constexpr int NDMA = PIN + WIN;
 };
 
-template <int MT>
+template <int MT, bool FLAT>
 __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     const u16* __restrict__ x, const u16* __restrict__ wp, const float* __restrict__ bias, const u16* __restrict__ mref,
     u16* __restrict__ y, int Cout, int ycb, int HS, int WS, int ROWS, long long PT, int nChunks, int epi, int coTiles, int tilesC,
     int nPix, int nWork)
 {
-    using G = P8G<MT>;
+    using G = P8G<MT, FLAT>;
     constexpr int NTB = G::NTB;
     __shared__ __attribute__((aligned(16))) char lds[2 * G::STAGE];
+    const int PPLF = G::TP + 2 * WS + 2;                 // FLAT: patch pixels per plane actually used (<= G::PPL)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -253,8 +262,13 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
         const int slot = t >> 3;
         cot_ = slot % coTiles;
         const int pix = (slot / coTiles) * 8 + (t & 7);
-        R0_ = (pix / tilesC) * G::TR;
-        C0_ = (pix % tilesC) * G::TC;
+        if constexpr (FLAT) {                          // R0_ carries the tile's first FLAT pixel, C0_ is unused
+            R0_ = pix * G::TP;
+            C0_ = 0;
+        } else {
+            R0_ = (pix / tilesC) * G::TR;
+            C0_ = (pix % tilesC) * G::TC;
+        }
         return t < nWork && pix < nPix;
     };
     auto next_valid = [&](int t, int& cot_, int& R0_, int& C0_) {       // first valid item at or after t on this workgroup's walk, or -1
@@ -273,12 +287,19 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
 #pragma unroll
         for (int i = 0; i < G::PIN; ++i) {
             const int piece = (i * 4 + wave) * 64 + lane;
-            const int plane = piece >= G::PPL ? 1 : 0;
-            const int q = piece - plane * G::PPL;
-            const int prow = q / G::PC, pcol = q - prow * G::PC;
-            const long long flat = (long long)(R0_ - 1 + prow) * WS + (C0_ - 1 + pcol);
-            const bool ok = piece < 2 * G::PPL && flat >= 0 && flat < PT;
-            pv[i] = ok ? (unsigned)((plane * PT + flat) * 16) : 0xFFFFFFFFu;
+            if constexpr (FLAT) {
+                const int plane = piece >= PPLF ? 1 : 0;
+                const long long flat = (long long)R0_ - WS - 1 + (piece - plane * PPLF);
+                const bool ok = piece < 2 * PPLF && flat >= 0 && flat < PT;
+                pv[i] = ok ? (unsigned)((plane * PT + flat) * 16) : 0xFFFFFFFFu;
+            } else {
+                const int plane = piece >= G::PPL ? 1 : 0;
+                const int q = piece - plane * G::PPL;
+                const int prow = q / G::PC, pcol = q - prow * G::PC;
+                const long long flat = (long long)(R0_ - 1 + prow) * WS + (C0_ - 1 + pcol);
+                const bool ok = piece < 2 * G::PPL && flat >= 0 && flat < PT;
+                pv[i] = ok ? (unsigned)((plane * PT + flat) * 16) : 0xFFFFFFFFu;
+            }
         }
     };
     unsigned pv_cur[G::PIN], pv_next[G::PIN], pvd[G::PIN];     // this tile's / the next tile's / the ones the DMA slots use
@@ -307,7 +328,11 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     // ---- operand addresses
     const int h = lane >> 5, px = lane & 31;
     const int a_off = lane * 16;                                                     // + stage + (tap MT + mt) 1024
-    const int b_off = G::WBYTES + (h * G::PPL + wave * NTB * G::PC + px) * 16;       // + stage + ((nt + ky) PC + kx) 16
+    // B operand of pixel block n, tap (ky, kx):  2-D: patch slot (wave NTB + n + ky) PC + px + kx;  FLAT: slot wave NTB 32 + n 32 + px
+    // + ky WS + kx (slot 0 = flat pixel f0 - WS - 1)
+    const int b_off = FLAT ? G::WBYTES + (h * PPLF + wave * NTB * 32 + px) * 16
+                           : G::WBYTES + (h * G::PPL + wave * NTB * G::PC + px) * 16;
+    const int b_ky[3] = {b_off, b_off + WS * 16, b_off + 2 * WS * 16};              // (FLAT only)
 
     {   // the very first chunk of the workgroup: nothing to hide it behind
         const __amdgpu_buffer_rsrc_t rw = desc_w(cot, 0, true), rx = desc_x(0, true);
@@ -318,7 +343,8 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
         dma(std::integral_constant<int, 8>{}, rw, rx, lds, pv_cur);   dma(std::integral_constant<int, 9>{}, rw, rx, lds, pv_cur);
         dma(std::integral_constant<int, 10>{}, rw, rx, lds, pv_cur);  dma(std::integral_constant<int, 11>{}, rw, rx, lds, pv_cur);
         dma(std::integral_constant<int, 12>{}, rw, rx, lds, pv_cur);  dma(std::integral_constant<int, 13>{}, rw, rx, lds, pv_cur);
-        dma(std::integral_constant<int, 14>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 14>{}, rw, rx, lds, pv_cur);  dma(std::integral_constant<int, 15>{}, rw, rx, lds, pv_cur);
+        dma(std::integral_constant<int, 16>{}, rw, rx, lds, pv_cur);  dma(std::integral_constant<int, 17>{}, rw, rx, lds, pv_cur);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -327,7 +353,8 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     ptmi_bf16x8 A0[MT], B0[NTB], A1[MT], B1[NTB];
     auto read_a = [&](const char* st, int tap, int m) { return *(const volatile plds_bf16x8_t*)(st + a_off + (tap * MT + m) * 1024); };
     auto read_b = [&](const char* st, int tap, int n) {
-        return *(const volatile plds_bf16x8_t*)(st + b_off + ((n + tap / 3) * G::PC + tap % 3) * 16);
+        if constexpr (FLAT) return *(const volatile plds_bf16x8_t*)(st + b_ky[tap / 3] + (n * 32 + tap % 3) * 16);
+        else return *(const volatile plds_bf16x8_t*)(st + b_off + ((n + tap / 3) * G::PC + tap % 3) * 16);
     };
 #pragma unroll
     for (int m = 0; m < MT; ++m) A0[m] = read_a(lds, 0, m);
@@ -337,7 +364,7 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     // One k-step = one tap of one 16-channel chunk = 16 MFMAs; the rest of the wave's work sits between them, one item per MFMA
     // (one wave per SIMD: whatever is not issued in the shadow of an MFMA leaves the matrix pipe idle):
     //   slots 0 .. MT + NTB - 1   one operand read each for the NEXT k-step (tap + 1, or tap 0 of the next chunk)
-    //   slots 10, 12, 14 (taps 0 .. 4) one DMA instruction each for the chunk after this one (its <= 15 instructions)
+    //   slots 10, 12, 14 (taps 0 .. 5) one DMA instruction each for the chunk after this one (its <= 18 instructions)
     //   tap 8, before slot 0      hand-over: own DMA pieces of the next chunk landed (vmcnt(0): they were issued >= 3 taps ago),
     //                             this k-step's operands in registers (lgkmcnt(0)), workgroup barrier
     // The very first k-step of a tile has a zero C operand (no 256 accumulator writes).
@@ -359,7 +386,7 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
             else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], acc[m][n], 0, 0, 0);
             if constexpr (J < MT) An[J] = read_a(src, NT_, J);
             else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);
-            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the
+            if constexpr (TAP < 6 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the
                 dma(std::integral_constant<int, TAP * 3 + (J - 10) / 2>{}, rw, rx, dst, pvd);      // last hand-over
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -372,7 +399,7 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
         slot_fn(std::integral_constant<int, 12>{}); slot_fn(std::integral_constant<int, 13>{});
         slot_fn(std::integral_constant<int, 14>{}); slot_fn(std::integral_constant<int, 15>{});
     };
-    static_assert(G::NDMA <= 15, "the chunk's DMA instructions are issued three per tap over taps 0..4");
+    static_assert(G::NDMA <= 18, "the chunk's DMA instructions are issued three per tap over taps 0..5");
     static_assert(MT + NTB <= 10, "operand reads occupy the slots before the first DMA slot");
 
     const std::true_type T{};
@@ -469,12 +496,29 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     unsigned mvoff[NTB];                     // byte offset of the lane's 8-byte half (mask loads; 0xFFFFFFFF: outside the grid)
     bool zero[NTB];                          // pad position: store zeros
     unsigned svoff[NTB / 2];                 // byte offset of the 16-byte vector this lane stores for the block pair (n0, n1)
+    if constexpr (FLAT) {
+        // flat pixel f = f0 + 32 (wave NTB + n) + px -> (row, column): one division, then +32 columns per block
+        const long long f = (long long)R0 + (wave * NTB) * 32 + px;
+        int row = (int)(f / WS), col = (int)(f - (long long)row * WS), rmod = row % HS;
 #pragma unroll
-    for (int n = 0; n < NTB; ++n) {
-        const int Rg = R0 + wave * NTB + n, Cg = C0 + px;
-        const bool inside = Rg < ROWS && Cg < WS;
-        zero[n] = (Rg % HS) == 0 || Cg == 0;
-        mvoff[n] = inside ? (unsigned)(((long long)Rg * WS + Cg) * 16 + h * 8) : 0xFFFFFFFFu;
+        for (int n = 0; n < NTB; ++n) {
+            const long long fn = f + 32 * n;
+            zero[n] = rmod == 0 || col == 0;
+            mvoff[n] = fn < PT ? (unsigned)(fn * 16 + h * 8) : 0xFFFFFFFFu;
+            col += 32;
+            while (col >= WS) {                      // (WS >= 1: a 1-pixel-wide map wraps up to 16 times per block)
+                col -= WS;
+                rmod = rmod + 1 == HS ? 0 : rmod + 1;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+            const int Rg = R0 + wave * NTB + n, Cg = C0 + px;
+            const bool inside = Rg < ROWS && Cg < WS;
+            zero[n] = (Rg % HS) == 0 || Cg == 0;
+            mvoff[n] = inside ? (unsigned)(((long long)Rg * WS + Cg) * 16 + h * 8) : 0xFFFFFFFFu;
+        }
     }
 #pragma unroll
     for (int j = 0; j < NTB / 2; ++j) {
@@ -865,9 +909,11 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
     const P8Dims d = p8_dims(n, h, w);
     PTMI_CHECK_ARG(d.PT * 32 < (1ll << 32), "p8_conv3x3: %lld pixels per plane exceed the 32-bit buffer offsets", (long long)d.PT);
     const int MT = p8_mt(cout), coTiles = cdiv(cout, 32 * MT), nChunks = cdiv(cin, 16), ycb = ptmi_p8_planes(cout);
-    const int TR = MT == 4 ? P8G<4>::TR : P8G<2>::TR;
+    // narrow maps: flat tile line (no column padding); wide maps: 2-D tiles (a flat tile's halo -- two whole rows -- would not fit)
+    const bool flat = d.WS <= P8_FLAT_MAX_WS;
+    const int TR = MT == 4 ? P8G<4, false>::TR : P8G<2, false>::TR, TP = MT == 4 ? P8G<4, true>::TP : P8G<2, true>::TP;
     const int tilesC = cdiv(d.WS, 32);
-    const int64_t nPix = (int64_t)cdiv(d.ROWS, TR) * tilesC;
+    const int64_t nPix = flat ? cdiv64(d.PT, TP) : (int64_t)cdiv(d.ROWS, TR) * tilesC;
     const int64_t nWork = cdiv64(nPix, 8) * 8 * coTiles;                // work items (some beyond nPix: skipped by the kernel)
     PTMI_CHECK_ARG(nWork < (1ll << 31), "p8_conv3x3: too many tiles");
     // persistent workgroups: one per CU (a multiple of 8: a work item stays on the XCD of its id mod 8)
@@ -875,14 +921,15 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
         cus = 256;
     const int64_t grid = nWork < (cus / 8) * 8 ? nWork : (cus / 8) * 8;
-    if (MT == 4)
-        hipLaunchKernelGGL(p8_conv3x3_kernel<4>, dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
-                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix,
-                           (int)nWork);
-    else
-        hipLaunchKernelGGL(p8_conv3x3_kernel<2>, dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias,
-                           (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC, (int)nPix,
-                           (int)nWork);
+#define P8_LAUNCH(MT_, FLAT_)                                                                                                              \
+    hipLaunchKernelGGL((p8_conv3x3_kernel<MT_, FLAT_>), dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias, \
+                       (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC,   \
+                       (int)nPix, (int)nWork)
+    if (MT == 4 && flat) P8_LAUNCH(4, true);
+    else if (MT == 4) P8_LAUNCH(4, false);
+    else if (flat) P8_LAUNCH(2, true);
+    else P8_LAUNCH(2, false);
+#undef P8_LAUNCH
     PTMI_LAUNCH_CHECK("p8_conv3x3");
     return 0;
 }

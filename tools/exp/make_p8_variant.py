@@ -15,9 +15,9 @@ SRC = os.path.join(ROOT, "probabilisticteacher_amd", "csrc", "p8.hip")
 
 EDITS = [
     ("constexpr int P8T = 256;", "#ifndef P8X\n#define P8X 0\n#endif\nconstexpr int P8T = 256;"),
-    ("            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the\n"
+    ("            if constexpr (TAP < 6 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the\n"
      "                dma(",
-     "            if constexpr (TAP < 5 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the\n"
+     "            if constexpr (TAP < 6 && (J == 10 || J == 12 || J == 14))      // the next chunk into the other stage: everybody left it at the\n"
      "                if (!(P8X & 1)) dma("),
     ("            if constexpr (J < MT) An[J] = read_a(src, NT_, J);\n            else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);",
      "            if (!(P8X & 2)) {\n            if constexpr (J < MT) An[J] = read_a(src, NT_, J);\n            else if constexpr (J < MT + NTB) Bn[J - MT] = read_b(src, NT_, J - MT);\n            }"),
