@@ -134,7 +134,9 @@ int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws
  * ptmi_p8m_pack builds an operand from an fp32 matrix: element (row, k) = src[row * ld + k] (k_major = 1) or src[k * ld + row]
  * (k_major = 0), rounded to bf16 (nearest even), zero beyond k; ptmi_p8m_elems bf16 elements.  Forward, dX and dW of a Linear layer
  * are all of this form (operands packed with their contraction index as k).  Shapes with few tiles and long k run split-K through a
- * caller-allocated workspace (ptmi_p8_gemm_nt_ws_floats floats; 0 = none), reduced in a fixed order. */
+ * caller-allocated workspace (ptmi_p8_gemm_nt_ws_floats floats; 0 = none), reduced in a fixed order.
+ * relu: bit 0 = ReLU; bit 1 = store the result TRANSPOSED, C[n][m] with row pitch ldc >= m (no bias / ReLU / split-K): with the
+ * operands swapped by the caller this writes the same matrix with 16-byte stores (fc1's dX, 1.6 GB of fp32, is store-bound). */
 int64_t ptmi_p8m_elems(int rows, int k);
 int ptmi_p8m_pack(const float* src, void* dst, int rows, int k, int64_t ld, int k_major, ptmi_stream_t s);
 int64_t ptmi_p8_gemm_nt_ws_floats(int m, int n, int k);

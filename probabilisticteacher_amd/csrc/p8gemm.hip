@@ -78,6 +78,10 @@ constexpr int G_BM = 256, G_BN = 256, G_BK = 64;
 constexpr int G_ABYTES = (G_BK / 8) * G_BM * 16;          // 32 KB
 constexpr int G_STAGE_ = 2 * G_ABYTES;                    // 64 KB
 
+// TOUT: the result is stored TRANSPOSED, C[col][row] with row pitch ldc -- the caller swaps the operands (C^T = B . A^T), so that a
+// lane's four consecutive accumulator rows are four consecutive elements of one output row: 16-byte stores instead of 4-byte ones
+// (fc1's dX writes 1.6 GB of fp32 and is store-bound; no bias / ReLU / split-K in this form)
+template <bool TOUT>
 __global__ __launch_bounds__(GT_, 2) void p8_gemm_nt_kernel(const u16* __restrict__ A, const u16* __restrict__ B, float* __restrict__ C,
                                                             const float* __restrict__ bias, float* __restrict__ ws, int M, int N, int K, int ldc,
                                                             int relu, int tilesN, int S, int nChunks)
@@ -159,6 +163,25 @@ __global__ __launch_bounds__(GT_, 2) void p8_gemm_nt_kernel(const u16* __restric
 
     // C layout: column = lane & 31 = n, row = (reg & 3) + 8 (reg >> 2) + 4 h = m: a half wave writes 128 contiguous bytes per register
     const int nn0 = n0 + wn * 64 + r;
+    if constexpr (TOUT) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = nn0 + n * 32;
+                if (col >= N) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = m0 + wm * 128 + m * 32 + 8 * q + 4 * h;          // rows row .. row + 3 = registers 4 q .. 4 q + 3
+                    float* o = C + (size_t)col * ldc + row;
+                    if (row + 3 < M && (ldc & 3) == 0) *reinterpret_cast<f32x4*>(o) = (f32x4){acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+                    else
+                        for (int e = 0; e < 4; ++e)
+                            if (row + e < M) o[e] = acc[m][n][4 * q + e];
+                }
+            }
+        return;
+    }
     float* out = S > 1 ? ws + (size_t)split * M * N : C;
     const int ld = S > 1 ? N : ldc;
 #pragma unroll
@@ -231,14 +254,24 @@ int64_t ptmi_p8_gemm_nt_ws_floats(int m, int n, int k)
 int ptmi_p8_gemm_nt(const void* a, const void* b, float* c, const float* bias, float* ws, int m, int n, int k, int ldc, int relu,
                     ptmi_stream_t s)
 {
-    PTMI_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0 && ldc >= n, "p8_gemm_nt: bad args");
+    PTMI_CHECK_ARG(a && b && c && m > 0 && n > 0 && k > 0 && (ldc >= n || (relu & 2)), "p8_gemm_nt: bad args");
+    if (relu & 2) {         // flag bit 1: transposed store C[n][m] (row pitch ldc >= m); operands as given; no bias / ReLU / split-K
+        PTMI_CHECK_ARG(!bias && !(relu & 1) && ldc >= m, "p8_gemm_nt: the transposed-store form takes no bias / ReLU and needs ldc >= m");
+        PTMI_CHECK_ARG((int64_t)cdiv(k, 8) * m * 16 < (1ll << 32) && (int64_t)cdiv(k, 8) * n * 16 < (1ll << 32),
+                       "p8_gemm_nt: operands beyond the 32-bit buffer offsets (m=%d n=%d k=%d)", m, n, k);
+        const int tilesN_ = cdiv(n, G_BN), tiles_ = cdiv(m, G_BM) * tilesN_;
+        hipLaunchKernelGGL(p8_gemm_nt_kernel<true>, dim3((unsigned)tiles_), dim3(GT_), 0, (hipStream_t)s, (const u16*)a, (const u16*)b, c, bias, ws, m,
+                           n, k, ldc, 0, tilesN_, 1, cdiv(k, G_BK));
+        PTMI_LAUNCH_CHECK("p8_gemm_nt(transposed store)");
+        return 0;
+    }
     PTMI_CHECK_ARG((int64_t)cdiv(k, 8) * m * 16 < (1ll << 32) && (int64_t)cdiv(k, 8) * n * 16 < (1ll << 32),
                    "p8_gemm_nt: operands beyond the 32-bit buffer offsets (m=%d n=%d k=%d)", m, n, k);
     const int S = p8_gemm_splits(m, n, k);
     PTMI_CHECK_ARG(S == 1 || ws, "p8_gemm_nt: this shape runs split-K and needs the workspace of ptmi_p8_gemm_nt_ws_floats");
     const int tilesN = cdiv(n, G_BN), tiles = cdiv(m, G_BM) * tilesN;
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(p8_gemm_nt_kernel, dim3((unsigned)(tiles * S)), dim3(GT_), 0, st, (const u16*)a, (const u16*)b, c, bias, ws, m, n, k, ldc,
+    hipLaunchKernelGGL(p8_gemm_nt_kernel<false>, dim3((unsigned)(tiles * S)), dim3(GT_), 0, st, (const u16*)a, (const u16*)b, c, bias, ws, m, n, k, ldc,
                        relu, tilesN, S, cdiv(k, G_BK));
     PTMI_LAUNCH_CHECK("p8_gemm_nt");
     if (S > 1) {

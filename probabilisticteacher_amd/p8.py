@@ -254,9 +254,16 @@ def pack_matrix(src: torch.Tensor, rows: int, k: int, ld: int, k_major: bool) ->
     return dst
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, m: int, n: int, k: int, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """C (m, n) fp32 = A . B^T (+ bias) (+ ReLU) from two packed operands (pack_matrix) with k octets each"""
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, m: int, n: int, k: int, bias: Optional[torch.Tensor] = None, relu: bool = False,
+            swapped: bool = False) -> torch.Tensor:
+    """C (m, n) fp32 = A . B^T (+ bias) (+ ReLU) from two packed operands (pack_matrix) with k octets each.
+    swapped: compute C^T = B . A^T and store it transposed -- the same matrix through 16-byte stores (large, store-bound outputs)"""
     c = torch.empty((m, n), dtype=F32, device=a.device)
+    if swapped:
+        assert bias is None and not relu
+        with ops._prof("p8_gemm", 2.0 * m * n * k):
+            _lib.call("ptmi_p8_gemm_nt", ops._ptr(b), ops._ptr(a), ops._ptr(c), None, None, n, m, k, n, 2, ops._stream())
+        return c
     nws = _lib.load().ptmi_p8_gemm_nt_ws_floats(m, n, k)
     ws = ops._ws("p8gemm", nws * 4, a.device) if nws else None
     with ops._prof("p8_gemm", 2.0 * m * n * k):
@@ -289,7 +296,7 @@ class _LinearP8(torch.autograd.Function):
         dz = ops.relu_bwd(dy, y) if relu else dy
         dx = dw = db = None
         if need_dx:                                        # dX = dZ W:  A = dZ (k = n), B = W^T (rows = input feature, k = n)
-            dx = gemm_nt(pack_matrix(dz, r, n, n, True), pack_matrix(weight, k, n, k, False), r, k, n)
+            dx = gemm_nt(pack_matrix(dz, r, n, n, True), pack_matrix(weight, k, n, k, False), r, k, n, swapped=True)
         if ctx.needs_input_grad[1]:                        # dW = dZ^T X:  A = dZ^T (rows n, k = r), B = X^T (rows = input feature, k = r)
             dw = gemm_nt(pack_matrix(dz, n, r, n, False), xt, n, k, r)
         if ctx.needs_input_grad[2]:                        # the bias gradient sums the values the GEMMs consumed (rounded)

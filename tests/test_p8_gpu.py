@@ -232,6 +232,8 @@ def test_p8_gemm_nt_and_packs(m, n, k):
             want = want.clamp(min=0)
         err = float((c - want).abs().max())
         assert err <= 1e-5 * float(want.abs().max()) + 4e-6 * math.sqrt(k) + 1e-5, f"gemm relu={relu}: max abs err {err:.3e}"
+    cs = p8.gemm_nt(ap, bp, m, n, k, None, False, swapped=True).cpu().double()       # C^T = B . A^T stored transposed: the same matrix
+    assert float((cs - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 4e-6 * math.sqrt(k) + 1e-5, "swapped / transposed-store form"
     c1 = p8.gemm_nt(ap, bp, m, n, k, None, False)
     assert torch.equal(c1, p8.gemm_nt(ap, bp, m, n, k, None, False)), "bitwise reproducible (fixed-order split reduction)"
 

@@ -89,7 +89,7 @@ def main():
             print(f"fc1 fwd  R={r:6d} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
             dz = (torch.randn((nn // 8, r, 8), device=dev) * 0.5).to(torch.bfloat16)
             wt = (torch.randn((nn // 8, k, 8), device=dev) * 0.05).to(torch.bfloat16)
-            ms = timeit(lambda: p8.gemm_nt(dz, wt, r, k, nn), a.iters)
+            ms = timeit(lambda: p8.gemm_nt(dz, wt, r, k, nn, swapped=True), a.iters)
             print(f"fc1 dx   R={r:6d} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
             dzt = (torch.randn((r // 8, nn, 8), device=dev) * 0.5).to(torch.bfloat16)
             xt = (torch.randn((r // 8, k, 8), device=dev) * 0.5).to(torch.bfloat16)
