@@ -109,9 +109,8 @@ int ptmi_p8_to_nchw(const void* x, float* y, int n, int c, int h, int w, ptmi_st
 int ptmi_p8_maxpool2x2_fwd(const void* x, void* y, int n, int c, int h, int w, ptmi_stream_t s);
 int ptmi_p8_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int n, int c, int h, int w, int relu_mask,
                            ptmi_stream_t s);
-/* dz = dy * (y > 0) and out = a + b (fp32 sum, rounded once) over `pixels16` 16-byte pixel vectors of P8 tensors */
+/* dz = dy * (y > 0) over `pixels16` 16-byte pixel vectors of P8 tensors */
 int ptmi_p8_relu_bwd(const void* dy, const void* y, void* dz, int64_t pixels16, ptmi_stream_t s);
-int ptmi_p8_add(const void* a, const void* b, void* out, int64_t pixels16, ptmi_stream_t s);
 /* conv3x3 s1 p1 on P8 tensors: v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 out; any channel counts (planes as above).
  * Weights packed by ptmi_p8_pack_weights (bf16, MFMA A-operand order [coTile][cin/16][tap][mt][64 lanes][8]; mode 0 forward,
  * mode 1 dgrad = flipped taps, transposed channels; ptmi_p8_packed_elems bf16 elements).

@@ -40,7 +40,6 @@ SIGNATURES = {
     "ptmi_p8_maxpool2x2_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ptmi_p8_maxpool2x2_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ptmi_p8_relu_bwd": (_i, [_vp, _vp, _vp, _i64, _vp]),
-    "ptmi_p8_add": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "ptmi_p8_packed_elems": (_i64, [_i, _i]),
     "ptmi_p8_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ptmi_p8_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

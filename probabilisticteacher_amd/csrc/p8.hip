@@ -22,7 +22,7 @@
 //                             buffer_load ... lds (weights: one lane-linear slab per (channel tile, chunk); patch: 16-byte pixel
 //                             vectors with per-lane source offsets), one barrier per chunk.
 //   p8_wgrad_kernel           dW[co][ci][tap] = sum over flat pixels of dY[co][f] X[ci][f + tap offset]: (see there)
-//   conversions, max-pool, weight packs.
+//   conversions, max-pool, ReLU backward, weight packs.
 #include "common.h"
 #include <type_traits>
 
@@ -31,8 +31,6 @@ namespace {
 typedef __attribute__((address_space(3))) ptmi_bf16x8 plds_bf16x8_t;
 typedef __attribute__((address_space(3))) void plds_void_t;
 typedef unsigned short u16;
-typedef u16 u16x4 __attribute__((ext_vector_type(4)));
-typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -50,7 +48,6 @@ inline P8Dims p8_dims(int n, int h, int w)
     return d;
 }
 
-__device__ __forceinline__ float bf16_bits_to_f32(u16 b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
 // round to nearest even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
 {
@@ -170,19 +167,6 @@ __global__ __launch_bounds__(256) void p8_relu_bwd_kernel(const u32x4* __restric
         o[k] = lo | hi;
     }
     dz[i] = o;
-}
-
-// a + b on P8 tensors, fp32 sum rounded once (two gradient branches meeting at a feature map)
-__global__ __launch_bounds__(256) void p8_add_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ o,
-                                                     int64_t n16)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n16) return;
-    const u32x4 u = a[i], v = b[i];
-    u32x4 r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r[k] = pack_bf16x2(bfe(u, 2 * k) + bfe(v, 2 * k), bfe(u, 2 * k + 1) + bfe(v, 2 * k + 1));
-    o[i] = r;
 }
 
 // ------------------------------------------------------------------------------------------------ weight pack (forward / dgrad)
@@ -865,16 +849,6 @@ int ptmi_p8_relu_bwd(const void* dy, const void* y, void* dz, int64_t pixels16, 
     hipLaunchKernelGGL(p8_relu_bwd_kernel, dim3((unsigned)cdiv64(pixels16, 256)), dim3(256), 0, (hipStream_t)s, (const u32x4*)dy,
                        (const u32x4*)y, (u32x4*)dz, pixels16);
     PTMI_LAUNCH_CHECK("p8_relu_bwd");
-    return 0;
-}
-
-int ptmi_p8_add(const void* a, const void* b, void* out, int64_t pixels16, ptmi_stream_t s)
-{
-    PTMI_CHECK_ARG(a && b && out && pixels16 >= 0, "p8_add: bad args");
-    if (pixels16 == 0) return 0;
-    hipLaunchKernelGGL(p8_add_kernel, dim3((unsigned)cdiv64(pixels16, 256)), dim3(256), 0, (hipStream_t)s, (const u32x4*)a, (const u32x4*)b,
-                       (u32x4*)out, pixels16);
-    PTMI_LAUNCH_CHECK("p8_add");
     return 0;
 }
 

@@ -117,11 +117,6 @@ def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return dz
 
 
-def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    out = torch.empty_like(a)
-    _lib.call("ptmi_p8_add", ops._ptr(a), ops._ptr(b), ops._ptr(out), a.numel() // 8, ops._stream())
-    return out
-
 
 # ============================================================================ autograd nodes
 class _ToNCHW(torch.autograd.Function):
