@@ -251,6 +251,14 @@ int ptmi_sample_by_keys(const int64_t* cls_all, const float* keys_all, const int
                         int64_t max_count, int num_samples, int num_pos_max, int bg_label, int64_t* out_fg,
                         int64_t* out_bg, int32_t* counts, ptmi_stream_t s);
 
+/* RPN._subsample_labels for a whole batch (pt/modeling/proposal_generator/rpn.py:433 -> D2 subsample_labels; SURVEY A.4,
+ * N6): labels (nimg, r) int8 in {-1 ignore, bg_label, anything else = positive}, keys (nimg, r) float32 >= 0 (i.i.d.
+ * uniform in production).  Per image n_f = min(#positives, num_pos_max), n_b = min(#negatives, num_samples - n_f); out
+ * (nimg, r) int8 = 1 for the n_f positives and 0 for the n_b negatives with the smallest keys (ties: lowest index), -1
+ * everywhere else.  Radix select on the key bits, one workgroup per image, no host sync. */
+int ptmi_rpn_subsample_relabel(const int8_t* labels, const float* keys, int8_t* out, int nimg, int64_t r, int num_samples,
+                               int num_pos_max, int bg_label, ptmi_stream_t s);
+
 /* ------------------------------------------------------------------ sort + proposals (N10)
  * replaces torch.sort(descending) at pt/modeling/proposal_generator/proposal_utils.py:87 and the
  * sort inside torchvision nms.  Stable: ties keep ascending original index.

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ptmi_iou_match": (_i, [_vp, _vp, _i, _i64, ctypes.POINTER(_f), ctypes.POINTER(_i), _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ptmi_iou_match_batched": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i64, ctypes.POINTER(_f), ctypes.POINTER(_i), _i, _i,
                                     _vp, _vp, _vp, _vp, _vp]),
+    "ptmi_rpn_subsample_relabel": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp]),
     "ptmi_sample_by_keys": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ptmi_segsort_ws_bytes": (_i64, [_i64, _i]),
     "ptmi_segsort_desc": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),

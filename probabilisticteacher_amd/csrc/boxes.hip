@@ -324,6 +324,110 @@ __global__ __launch_bounds__(256) void sample_by_keys_kernel(const int64_t* __re
     }
 }
 
+// RPN._subsample_labels for a batch (rpn.py:433 -> D2 subsample_labels): one workgroup per image selects the n_f positives
+// and n_b negatives with the smallest keys out of R ~ 37 000 anchors and writes the relabelled vector (1 / 0 / -1).  The
+// threshold key of each class is found by a 4 x 8-bit radix select on the key bits (keys are >= 0, so the bit pattern orders
+// like the value): per pass one histogram of 2 x 256 bins in LDS over the candidates that still share the prefix; ties on the
+// threshold key are resolved towards the lowest index by an ordered scan of the few tied candidates.
+constexpr int RELABEL_THREADS = 1024;
+
+__global__ __launch_bounds__(RELABEL_THREADS) void rpn_subsample_relabel_kernel(const int8_t* __restrict__ labels,
+                                                                                const float* __restrict__ keys,
+                                                                                int8_t* __restrict__ out, int64_t R,
+                                                                                int num_samples, int num_pos_max, int bg_label)
+{
+    __shared__ int hist[2][256];
+    __shared__ unsigned prefix[2];      // key bits fixed so far (high bits)
+    __shared__ int want[2];             // how many candidates with the current prefix are still to be taken (1-based rank)
+    __shared__ int total[2];
+    __shared__ int tie_take[2];         // candidates equal to the threshold that are taken (lowest indices first)
+    __shared__ int tie_seen[2];
+    const int tid = threadIdx.x;
+    const int8_t* lab = labels + (int64_t)blockIdx.x * R;
+    const float* key = keys + (int64_t)blockIdx.x * R;
+    int8_t* o = out + (int64_t)blockIdx.x * R;
+    if (tid < 2) { total[tid] = 0; prefix[tid] = 0; tie_seen[tid] = 0; }
+    __syncthreads();
+    int c0 = 0, c1 = 0;
+    for (int64_t i = tid; i < R; i += RELABEL_THREADS) {
+        const int l = lab[i];
+        c0 += (l != -1 && l != bg_label);
+        c1 += (l == bg_label);
+    }
+    for (int d = 32; d; d >>= 1) { c0 += __shfl_xor(c0, d); c1 += __shfl_xor(c1, d); }
+    if ((tid & 63) == 0) { atomicAdd(&total[0], c0); atomicAdd(&total[1], c1); }
+    __syncthreads();
+    const int n_f = min(total[0], num_pos_max);
+    const int n_b = min(total[1], num_samples - n_f);
+    const int n_sel[2] = {n_f, n_b};
+    if (tid < 2) want[tid] = n_sel[tid];
+    // radix select: after the four passes prefix[t] is the n_sel[t]-th smallest key of class t and want[t] the number of
+    // candidates EQUAL to it that belong to the selection
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < 512; i += RELABEL_THREADS) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        const unsigned p0 = prefix[0], p1 = prefix[1];
+        for (int64_t i = tid; i < R; i += RELABEL_THREADS) {
+            const int l = lab[i];
+            if (l == -1) continue;
+            const int t = l == bg_label;
+            if (n_sel[t] == 0) continue;
+            const unsigned kb = __float_as_uint(key[i]);
+            if ((kb & himask) == (t ? p1 : p0)) atomicAdd(&hist[t][(kb >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (tid < 2 && n_sel[tid] > 0) {
+            int w = want[tid], b = 0;
+            for (; b < 255; ++b) {
+                const int h = hist[tid][b];
+                if (w <= h) break;
+                w -= h;
+            }
+            want[tid] = w;
+            prefix[tid] |= (unsigned)b << shift;
+        }
+        __syncthreads();
+    }
+    if (tid < 2) tie_take[tid] = want[tid];
+    __syncthreads();
+    const unsigned th[2] = {prefix[0], prefix[1]};
+    // ties: candidates whose key equals the threshold are taken in index order.  One pass in index order over blocks of
+    // RELABEL_THREADS elements; the running count of tied candidates is carried in LDS.
+    for (int64_t base = 0; base < R; base += RELABEL_THREADS) {
+        const int64_t i = base + tid;
+        int l = -1;
+        unsigned kb = 0;
+        if (i < R) { l = lab[i]; kb = __float_as_uint(key[i]); }
+        const int t = l == bg_label;
+        const bool cand = l != -1 && n_sel[t] > 0;
+        const bool less = cand && kb < th[t];
+        const bool tied = cand && kb == th[t];
+        int8_t res = -1;
+        if (less) res = t ? 0 : 1;
+        // rank of a tied candidate among the tied ones of its class with a lower index
+        const unsigned long long m0 = __ballot(tied && t == 0), m1 = __ballot(tied && t == 1);
+        __shared__ int wave_cnt[2][RELABEL_THREADS / 64];
+        const int wv = tid >> 6, ln = tid & 63;
+        if (ln == 0) { wave_cnt[0][wv] = __popcll(m0); wave_cnt[1][wv] = __popcll(m1); }
+        __syncthreads();
+        if (tied) {
+            int before = tie_seen[t] + __popcll((t ? m1 : m0) & ((1ull << ln) - 1));
+            for (int w2 = 0; w2 < wv; ++w2) before += wave_cnt[t][w2];
+            if (before < tie_take[t]) res = t ? 0 : 1;
+        }
+        if (i < R) o[i] = res;
+        __syncthreads();
+        if (tid < 2) {
+            int a = 0;
+            for (int w2 = 0; w2 < RELABEL_THREADS / 64; ++w2) a += wave_cnt[tid][w2];
+            tie_seen[tid] += a;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void fill_nomatch_kernel(int64_t* __restrict__ midx, int8_t* __restrict__ mlabel, float* __restrict__ miou,
                                     int64_t nb, int lab)
 {
@@ -591,6 +695,18 @@ int ptmi_sample_by_keys(const int64_t* cls_all, const float* keys_all, const int
     hipLaunchKernelGGL(sample_by_keys_kernel, dim3(nimg, parts), dim3(256), (size_t)max_count * 5 + 16, (hipStream_t)s, cls_all,
                        keys_all, offsets, num_samples, num_pos_max, bg_label, kf, num_samples, out_fg, out_bg, counts);
     PTMI_LAUNCH_CHECK("sample_by_keys");
+    return 0;
+}
+
+int ptmi_rpn_subsample_relabel(const int8_t* labels, const float* keys, int8_t* out, int nimg, int64_t r, int num_samples,
+                               int num_pos_max, int bg_label, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(labels && keys && out && nimg > 0 && r > 0 && num_samples > 0 && num_pos_max >= 0 &&
+                       num_pos_max <= num_samples,
+                   "rpn_subsample_relabel: bad args");
+    hipLaunchKernelGGL(rpn_subsample_relabel_kernel, dim3(nimg), dim3(RELABEL_THREADS), 0, (hipStream_t)s, labels, keys, out,
+                       r, num_samples, num_pos_max, bg_label);
+    PTMI_LAUNCH_CHECK("rpn_subsample_relabel");
     return 0;
 }
 

@@ -81,6 +81,9 @@ def keyed_relabel(labels: torch.Tensor, num_samples: int, positive_fraction: flo
     new labels with the sampled positives = 1, sampled negatives = 0, everything else -1.  No host sync."""
     n, r = labels.shape
     keys = draw_keys(labels, None, bg_label)
+    if labels.is_cuda:                 # the product path: one radix-select kernel (the torch form below is the host-logic
+        from .. import ops             # statement the CPU tests pin and the GPU test compares the kernel with)
+        return ops.rpn_subsample_relabel(labels, keys, num_samples, int(num_samples * positive_fraction), bg_label)
     pos_m = (labels != -1) & (labels != bg_label)
     neg_m = labels == bg_label
     ip, vp = keyed_topk(pos_m, keys, int(num_samples * positive_fraction))

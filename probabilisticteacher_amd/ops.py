@@ -798,6 +798,20 @@ def sample_by_keys(cls_all: torch.Tensor, keys_all: torch.Tensor, offsets: torch
     return fg, bg, cnt
 
 
+def rpn_subsample_relabel(labels: torch.Tensor, keys: torch.Tensor, num_samples: int, num_pos_max: int,
+                          bg_label: int) -> torch.Tensor:
+    """RPN._subsample_labels for a batch (ptmi_rpn_subsample_relabel): labels (N, R) int8, keys (N, R) float32 >= 0 ->
+    (N, R) int8 with the sampled positives = 1, sampled negatives = 0, everything else -1."""
+    labels = _chk(labels.contiguous(), torch.int8)
+    keys = _chk(keys.contiguous())
+    assert labels.dim() == 2 and keys.shape == labels.shape
+    out = torch.empty_like(labels)
+    if labels.numel():
+        _lib.call("ptmi_rpn_subsample_relabel", _ptr(labels), _ptr(keys), _ptr(out), labels.shape[0], labels.shape[1],
+                  int(num_samples), int(num_pos_max), int(bg_label), _stream())
+    return out
+
+
 # ============================================================================ sort / proposals / NMS
 def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Stable descending sort inside each segment.  Returns (sorted keys, index within segment int32)."""

@@ -280,3 +280,59 @@ def test_label_and_sample_anchors_identical_inputs_baseline_size():
         assert torch.equal(m, masks[i]), f"image {i}: positive mask"
         sel = midx[i][m.to(DEV)] + gt_off[i].long()
         assert torch.equal(all_logits[sel].cpu(), soft[i]), f"image {i}: soft labels of the matched pseudo boxes"
+
+
+def _relabel_spec(labels, keys, num_samples, num_pos_max, bg):
+    """The selection ptmi_rpn_subsample_relabel documents, stated with a stable argsort (ties -> lowest index)."""
+    out = torch.full_like(labels, -1)
+    for i in range(labels.shape[0]):
+        pos = ((labels[i] != -1) & (labels[i] != bg)).nonzero().squeeze(1)
+        neg = (labels[i] == bg).nonzero().squeeze(1)
+        n_f = min(len(pos), num_pos_max)
+        n_b = min(len(neg), num_samples - n_f)
+        out[i, pos[torch.argsort(keys[i, pos], stable=True)[:n_f]]] = 1
+        out[i, neg[torch.argsort(keys[i, neg], stable=True)[:n_b]]] = 0
+    return out
+
+
+@pytest.mark.parametrize("r", [37350, 1000, 63])
+def test_rpn_subsample_relabel_kernel(r):
+    """a12's sampler as its own kernel (rpn.py:433): the radix select against the stable-argsort statement and
+    against sampling.keyed_relabel's torch form on the CPU, on rows that cover every branch: many / few / no positives, fewer
+    negatives than the quota, nothing to sample, heavy ties (keys quantised to 4 values), all keys equal."""
+    from probabilisticteacher_amd import ops
+    from probabilisticteacher_amd.modeling import sampling
+    g = torch.Generator().manual_seed(r)
+    n = 9
+    labels = torch.full((n, r), -1, dtype=torch.int8)
+    u = torch.rand(n, r, generator=g)
+    labels[0][u[0] < 0.02] = 1
+    labels[0][u[0] > 0.3] = 0                     # > 128 positives at r = 37350, plenty of negatives
+    labels[1][u[1] < 0.0005] = 1
+    labels[1][u[1] > 0.5] = 0                     # a handful of positives
+    labels[2][u[2] > 0.1] = 0                     # no positives
+    labels[3][u[3] < 0.5] = 1
+    labels[3][:7] = 0
+    labels[3][7:] = torch.where(labels[3][7:] == 0, torch.tensor(-1, dtype=torch.int8), labels[3][7:])   # 7 negatives only
+    labels[4][:] = -1                             # nothing to sample
+    labels[5][u[5] < 0.3] = 3                     # "anything else = positive"
+    labels[5][u[5] > 0.6] = 0
+    labels[6] = labels[0]
+    labels[7] = labels[0]
+    labels[8] = labels[5]
+    keys = torch.rand(n, r, generator=g)
+    keys[6] = torch.floor(keys[6] * 4) / 4        # heavy ties
+    keys[7] = 0.5                                 # all equal: lowest indices win
+    keys[8, ::2] = keys[8, 1::2][: keys[8, ::2].numel()] if r % 2 == 0 else keys[8, ::2]
+    for ns, npm in ((256, 128), (256, 64), (16, 8), (5, 0)):
+        got = ops.rpn_subsample_relabel(labels.to(DEV), keys.to(DEV), ns, npm, 0).cpu()
+        assert torch.equal(got, _relabel_spec(labels, keys, ns, npm, 0)), f"num_samples {ns}, num_pos_max {npm}"
+    # the torch form the host-logic tests pin (distinct keys: torch.topk's tie order is unspecified)
+    rows = [0, 1, 2, 3, 4, 5]
+    sampling.set_key_source(lambda lab, sizes, bg: keys[rows].to(lab.device))
+    try:
+        cpu = sampling.keyed_relabel(labels[rows], 256, 0.5, 0)
+        dev = sampling.keyed_relabel(labels[rows].to(DEV), 256, 0.5, 0)
+    finally:
+        sampling.set_key_source(None)
+    assert dev.is_cuda and torch.equal(dev.cpu(), cpu)
