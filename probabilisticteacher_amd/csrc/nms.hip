@@ -48,6 +48,11 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
     const int lim = min(64, n - cb * 64);
     u64 bits = 0;
     const int start = (cb == rb) ? t + 1 : 0;
+    // `inter / uni > thr` decided without the division wherever the quotient is not within 2^-20 of the threshold: the IEEE
+    // quotient q = fl(inter / uni) is within 2^-24 (relative) of inter / uni and p = fl(thr uni) within 2^-24 of thr uni, so
+    // inter > p (1 + 2^-20) implies q > thr and inter < p (1 - 2^-20) implies q < thr; everything else (and uni <= 0 / NaN) takes
+    // the division -- the same decisions bit for bit, a tenth of the instructions for almost every pair
+    constexpr float HI = 1.f + 0x1p-20f, LO = 1.f - 0x1p-20f;
     for (int k = start; k < lim; ++k) {
         const float4 b = cbox[k];
         const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
@@ -56,76 +61,100 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
         w = w < 0.f ? 0.f : w;
         h = h < 0.f ? 0.f : h;
         const float inter = w * h;
-        const float iou = inter / (aarea + carea[k] - inter);
-        if (iou > thr) bits |= 1ull << k;
+        const float uni = aarea + carea[k] - inter;
+        const float p = thr * uni;
+        bool sup;
+        if (uni > 0.f && inter > p * HI) sup = true;
+        else if (uni > 0.f && inter < p * LO) sup = false;
+        else sup = inter / uni > thr;
+        if (sup) bits |= 1ull << k;
     }
     mask[((size_t)img * max_count + i) * words + cb] = bits;
 }
 
-// One wave per image walks the boxes in order, 64 at a time.
-__global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ seg,
-                                                      const int32_t* __restrict__ cnt, int words, int64_t max_count,
-                                                      int max_keep,
-                                                      int32_t* __restrict__ keep, int32_t* __restrict__ keep_count)
+// One workgroup per image walks the boxes in order, 64 at a time: wave 0 resolves the chunk's 64 x 64 diagonal block (only the
+// candidates that survive are visited: a bit scan, one readlane pair each), then all four waves fold the kept rows into the
+// remaining words of the `removed` vector (a thread per word, the loads of up to sixteen kept rows in flight together).
+constexpr int SCAN_THREADS = 256;
+
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const u64* __restrict__ mask, const int32_t* __restrict__ seg,
+                                                                const int32_t* __restrict__ cnt, int words, int64_t max_count,
+                                                                int max_keep, int32_t* __restrict__ keep,
+                                                                int32_t* __restrict__ keep_count)
 {
     extern __shared__ u64 removed[];   // words entries
-    const int img = blockIdx.x, lane = threadIdx.x;
+    __shared__ u64 kept_s;
+    __shared__ int count_s;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = seg_count(seg, cnt, img);
     const u64* M = mask + (size_t)img * max_count * words;
-    for (int w = lane; w < words; w += 64) removed[w] = 0;
+    for (int w = tid; w < words; w += SCAN_THREADS) removed[w] = 0;
+    if (tid == 0) count_s = 0;
     __syncthreads();
     int count = 0;
     const int chunks = (n + 63) / 64;
-    u64 diag_next = (lane < n) ? M[(size_t)lane * words] : 0;          // diagonal block of chunk 0
-    for (int c = 0; c < chunks && count < max_keep; ++c) {
-        const int row = c * 64 + lane;
-        const u64 diag = diag_next;
-        if (c + 1 < chunks) {                                           // prefetch the next diagonal block: its load
-            const int rn = row + 64;                                    // latency hides behind this chunk's resolve
-            diag_next = (rn < n) ? M[(size_t)rn * words + c + 1] : 0;
-        }
-        u64 cur = removed[c];
-        if (c == chunks - 1 && (n & 63)) cur |= ~0ull << (n & 63);   // rows past n do not exist
-        // resolve the 64x64 diagonal block in order (wave-uniform)
-        u64 kept = 0;
-        const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-        for (int i = 0; i < 64; ++i) {
-            if (!((cur >> i) & 1ull)) {
+    u64 diag_next = (wave == 0 && lane < n) ? M[(size_t)lane * words] : 0;          // diagonal block of chunk 0
+    for (int c = 0; c < chunks; ++c) {
+        if (wave == 0) {
+            const int row = c * 64 + lane;
+            const u64 diag = diag_next;
+            if (c + 1 < chunks) {                                           // prefetch the next diagonal block: its load
+                const int rn = row + 64;                                    // latency hides behind this chunk's resolve
+                diag_next = (rn < n) ? M[(size_t)rn * words + c + 1] : 0;
+            }
+            u64 cur = removed[c];
+            if (c == chunks - 1 && (n & 63)) cur |= ~0ull << (n & 63);   // rows past n do not exist
+            // candidates still alive, as a wave-uniform scalar pair
+            u64 alive = ~(((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(cur >> 32)) << 32) |
+                          (u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)cur));
+            u64 kept = 0;
+            const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
+            while (alive) {
+                const int i = __builtin_ctzll(alive);
                 kept |= 1ull << i;
                 const u64 di = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
                                (u64)(unsigned)__builtin_amdgcn_readlane((int)dlo, i);
-                cur |= di;
+                alive &= ~(di | (1ull << i));                               // (row i's block only has bits above i)
+            }
+            // emit kept indices in order, capped at max_keep
+            if ((kept >> lane) & 1ull) {
+                const int pos = count + __popcll(kept & ((1ull << lane) - 1ull));
+                if (pos < max_keep) keep[(size_t)img * max_keep + pos] = row;
+            }
+            if (lane == 0) {
+                kept_s = kept;
+                count_s = count + __popcll(kept);
             }
         }
-        // emit kept indices in order, capped at max_keep
-        const int nk = __popcll(kept);
-        if ((kept >> lane) & 1ull) {
-            const int pos = count + __popcll(kept & ((1ull << lane) - 1ull));
-            if (pos < max_keep) keep[(size_t)img * max_keep + pos] = row;
-        }
-        count += nk;
+        __syncthreads();
+        count = count_s;
         if (count >= max_keep) break;
-        // fold the kept rows into the remaining words (lanes stride over words; loads coalesced).  The rows are
-        // visited eight at a time with the loads of a group issued together (zero row index 0 stands in for rows that
-        // were not kept: OR-ing a row twice is harmless, OR-ing an unkept row is not, hence the mask).
-        for (int w = c + 1 + lane; w < chunks; w += 64) {
+        const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)kept_s);
+        const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(kept_s >> 32));
+        const u64 kept = ((u64)khi << 32) | klo;
+        for (int w = c + 1 + tid; w < chunks; w += SCAN_THREADS) {
             u64 acc = removed[w];
             const u64* Mw = M + (size_t)c * 64 * words + w;
-#pragma unroll 1
-            for (int i0 = 0; i0 < 64; i0 += 8) {
-                const unsigned kb = (unsigned)(kept >> i0) & 0xFFu;
-                if (!kb) continue;
-                u64 v[8];
+            u64 k = kept;
+            while (k) {
+                u64 v[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ((kb >> j) & 1u) ? Mw[(size_t)(i0 + j) * words] : 0ull;
+                for (int j = 0; j < 16; ++j) {
+                    if (k) {                                                 // (scalar: k is wave-uniform)
+                        const int i = __builtin_ctzll(k);
+                        k &= k - 1;
+                        v[j] = Mw[(size_t)i * words];
+                    } else v[j] = 0ull;
+                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc |= v[j];
+                for (int j = 0; j < 16; ++j) acc |= v[j];
             }
             removed[w] = acc;
         }
         __syncthreads();
     }
-    if (lane == 0) keep_count[img] = count < max_keep ? count : max_keep;
+    if (tid == 0) keep_count[img] = count < max_keep ? count : max_keep;
 }
 
 }  // namespace
@@ -157,7 +186,7 @@ int ptmi_nms_batched(const float* boxes, const int32_t* seg_offsets, const int32
     hipLaunchKernelGGL(nms_mask_kernel, grid, dim3(64), 0, st, boxes, seg_offsets, seg_counts, thr, words, max_count,
                        reinterpret_cast<u64*>(ws));
     PTMI_LAUNCH_CHECK("nms_mask");
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(nimg), dim3(64), (size_t)words * 8, st, reinterpret_cast<const u64*>(ws),
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(nimg), dim3(SCAN_THREADS), (size_t)words * 8, st, reinterpret_cast<const u64*>(ws),
                        seg_offsets, seg_counts, words, max_count, max_keep, keep_out, keep_count);
     PTMI_LAUNCH_CHECK("nms_scan");
     return 0;
