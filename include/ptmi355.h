@@ -115,7 +115,8 @@ int ptmi_p8_relu_bwd(const void* dy, const void* y, void* dz, int64_t pixels16, 
  * Weights packed by ptmi_p8_pack_weights (bf16, MFMA A-operand order [coTile][cin/16][tap][mt][64 lanes][8]; mode 0 forward,
  * mode 1 dgrad = flipped taps, transposed channels; ptmi_p8_packed_elems bf16 elements).
  * epilogue 0: + bias; 1: + bias, ReLU; 2: none (dgrad); 3: dgrad times (mask_ref > 0), mask_ref = the producing layer's stored
- * activation (P8, cout channels). */
+ * activation (P8, cout channels); 4: + bias, ReLU, 2x2 max-pool (floor) -- y is the P8 tensor of the POOLED map (n, cout, h/2,
+ * w/2), pads included, and the full-resolution activation never reaches HBM (layers without a backward pass). */
 int64_t ptmi_p8_packed_elems(int cin, int cout);
 int ptmi_p8_pack_weights(const float* w, void* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s);
 int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void* mask_ref, void* y, int n,

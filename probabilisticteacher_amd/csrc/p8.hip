@@ -169,6 +169,18 @@ __global__ __launch_bounds__(256) void p8_relu_bwd_kernel(const u32x4* __restric
     dz[i] = o;
 }
 
+// zero pad row / column vectors of a P8 tensor whose interior another kernel writes (the pooling epilogue of the conv kernel)
+__global__ __launch_bounds__(256) void p8_zero_pads_kernel(u32x4* __restrict__ y, int HS, int WS, int ROWS, int64_t PT)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nimg1 = (ROWS - 1) / HS + 1;                 // pad rows
+    int64_t f;
+    if (i < ROWS) f = (int64_t)i * WS;                                       // column 0 of row i
+    else if (i - ROWS < nimg1 * WS) f = (int64_t)((i - ROWS) / WS) * HS * WS + (i - ROWS) % WS;
+    else return;
+    y[(int64_t)blockIdx.y * PT + f] = (u32x4){0u, 0u, 0u, 0u};
+}
+
 // ------------------------------------------------------------------------------------------------ weight pack (forward / dgrad)
 // wp[coTile][chunk][tap][mt][lane = 32 h + r][e]:  A operand of v_mfma_f32_32x32x16_bf16 -- row r = output channel
 // coTile (32 MT) + 32 mt + r, k = 8 h + e = input channel within the 16-channel chunk; 16 B per lane, lane-linear: the kernel
@@ -223,7 +235,7 @@ struct P8G {
     static constexpr int NDMA = PIN + WIN;
 };
 
-template <int MT, bool FLAT>
+template <int MT, bool FLAT, bool POOL = false>
 __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
     const u16* __restrict__ x, const u16* __restrict__ wp, const float* __restrict__ bias, const u16* __restrict__ mref,
     u16* __restrict__ y, int Cout, int ycb, int HS, int WS, int ROWS, long long PT, int nChunks, int epi, int coTiles, int tilesC,
@@ -249,6 +261,10 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
         if constexpr (FLAT) {                          // R0_ carries the tile's first FLAT pixel, C0_ is unused
             R0_ = pix * G::TP;
             C0_ = 0;
+        } else if constexpr (POOL) {                   // tiles per IMAGE, origin at its pixel (0, 0): 2x2 windows never straddle tiles
+            const int rt = pix / tilesC, bands = (HS - 1 + G::TR - 1) / G::TR;
+            R0_ = (rt / bands) * HS + 1 + (rt % bands) * G::TR;
+            C0_ = 1 + (pix % tilesC) * G::TC;
         } else {
             R0_ = (pix / tilesC) * G::TR;
             C0_ = (pix % tilesC) * G::TC;
@@ -477,6 +493,52 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
             }
         }
 
+    if constexpr (POOL) {
+        // bias + ReLU + 2x2 max-pool (floor): y has the POOLED geometry.  A wave's NTB rows are NTB / 2 window rows (tile origins are
+        // even image rows / columns), the two columns of a window sit in neighbouring lanes (quad_perm 1,0,3,2); lanes with an even
+        // column hold the pooled pixel, and permlane32_swap pairs two pooled rows into 16-byte stores as below.
+        const int Ho = (HS - 1) >> 1, Wo = (WS - 1) >> 1, HSo = Ho + 1, WSo = Wo + 1;
+        const long long PTo = ((long long)((ROWS - 1) / HS) * HSo + 1) * WSo;
+        const unsigned oplane_bytes = (unsigned)(PTo * 16);
+        const int img = (R0 - 1) / HS;
+        const int pr0 = (R0 - 1 - img * HS + wave * NTB) >> 1, pcol = (C0 - 1 + px) >> 1;
+        unsigned psv[NTB / 4];
+#pragma unroll
+        for (int j = 0; j < NTB / 4; ++j) {
+            const int prow = pr0 + 2 * j + h;              // lower lanes store pooled row 2 j, upper lanes 2 j + 1
+            const bool ok = !(px & 1) && prow < Ho && pcol < Wo;
+            psv[j] = ok ? (unsigned)((((long long)img * HSo + 1 + prow) * WSo + 1 + pcol) * 16) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cb = (cot * MT + m) * 4 + q;
+                if (cb >= ycb) continue;
+                const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)cb * PTo * 8, oplane_bytes);
+                u32x2 o[NTB / 2];
+#pragma unroll
+                for (int n2 = 0; n2 < NTB / 2; ++n2) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = rd(acc[m][2 * n2][4 * q + e]) + bv[m][q][e], b = rd(acc[m][2 * n2 + 1][4 * q + e]) + bv[m][q][e];
+                        const float vm = fmaxf(fmaxf(a, b), 0.f);
+                        const float nb = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, vm), 0xB1, 0xF, 0xF, true));
+                        v[e] = fmaxf(vm, nb);
+                    }
+                    o[n2] = (u32x2){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                }
+#pragma unroll
+                for (int j = 0; j < NTB / 4; ++j) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(o[2 * j][0], o[2 * j + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(o[2 * j][1], o[2 * j + 1][1], false, false);
+                    const u32x4 w = {s0[0], s1[0], s0[1], s1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)psv[j], 0, 0);
+                }
+            }
+        }
+    } else {
     unsigned mvoff[NTB];                     // byte offset of the lane's 8-byte half (mask loads; 0xFFFFFFFF: outside the grid)
     bool zero[NTB];                          // pad position: store zeros
     unsigned svoff[NTB / 2];                 // byte offset of the 16-byte vector this lane stores for the block pair (n0, n1)
@@ -552,6 +614,7 @@ __global__ __launch_bounds__(P8T, 1) void p8_conv3x3_kernel(
                 __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)svoff[j], 0, 0);
             }
         }
+    }
     }
         // ---- next tile of this workgroup (its first chunk is already in LDS, its first operands in registers)
         if (!more_tiles) break;
@@ -877,17 +940,19 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
                     int h, int w, int epilogue, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_conv3x3: bad args");
-    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 3, "p8_conv3x3: bad epilogue %d", epilogue);
-    PTMI_CHECK_ARG(epilogue > 1 || bias, "p8_conv3x3: bias required for epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "p8_conv3x3: bad epilogue %d", epilogue);
+    PTMI_CHECK_ARG((epilogue > 1 && epilogue != 4) || bias, "p8_conv3x3: bias required for epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue != 4 || (h > 1 && w > 1), "p8_conv3x3: pooling epilogue on a %d x %d map", h, w);
     PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "p8_conv3x3: mask_ref required for epilogue 3");
     const P8Dims d = p8_dims(n, h, w);
     PTMI_CHECK_ARG(d.PT * 32 < (1ll << 32), "p8_conv3x3: %lld pixels per plane exceed the 32-bit buffer offsets", (long long)d.PT);
     const int MT = p8_mt(cout), coTiles = cdiv(cout, 32 * MT), nChunks = cdiv(cin, 16), ycb = ptmi_p8_planes(cout);
     // narrow maps: flat tile line (no column padding); wide maps: 2-D tiles (a flat tile's halo -- two whole rows -- would not fit)
-    const bool flat = d.WS <= P8_FLAT_MAX_WS;
+    const bool pool = epilogue == 4;                                     // 2-D tiles per image (see the kernel's decode)
+    const bool flat = !pool && d.WS <= P8_FLAT_MAX_WS;
     const int TR = MT == 4 ? P8G<4, false>::TR : P8G<2, false>::TR, TP = MT == 4 ? P8G<4, true>::TP : P8G<2, true>::TP;
-    const int tilesC = cdiv(d.WS, 32);
-    const int64_t nPix = flat ? cdiv64(d.PT, TP) : (int64_t)cdiv(d.ROWS, TR) * tilesC;
+    const int tilesC = pool ? cdiv(w, 32) : cdiv(d.WS, 32);
+    const int64_t nPix = flat ? cdiv64(d.PT, TP) : (int64_t)(pool ? n * cdiv(h, TR) : cdiv(d.ROWS, TR)) * tilesC;
     const int64_t nWork = cdiv64(nPix, 8) * 8 * coTiles;                // work items (some beyond nPix: skipped by the kernel)
     PTMI_CHECK_ARG(nWork < (1ll << 31), "p8_conv3x3: too many tiles");
     // persistent workgroups: one per CU (a multiple of 8: a work item stays on the XCD of its id mod 8)
@@ -895,14 +960,21 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
         cus = 256;
     const int64_t grid = nWork < (cus / 8) * 8 ? nWork : (cus / 8) * 8;
-#define P8_LAUNCH(MT_, FLAT_)                                                                                                              \
-    hipLaunchKernelGGL((p8_conv3x3_kernel<MT_, FLAT_>), dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias, \
+#define P8_LAUNCH(MT_, FLAT_, POOL_)                                                                                                       \
+    hipLaunchKernelGGL((p8_conv3x3_kernel<MT_, FLAT_, POOL_>), dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias, \
                        (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC,   \
                        (int)nPix, (int)nWork)
-    if (MT == 4 && flat) P8_LAUNCH(4, true);
-    else if (MT == 4) P8_LAUNCH(4, false);
-    else if (flat) P8_LAUNCH(2, true);
-    else P8_LAUNCH(2, false);
+    if (pool) {
+        const P8Dims q = p8_dims(n, h / 2, w / 2);
+        hipLaunchKernelGGL(p8_zero_pads_kernel, dim3((unsigned)cdiv(q.ROWS + (n + 1) * q.WS, 256), ycb), dim3(256), 0, (hipStream_t)s, (u32x4*)y,
+                           q.HS, q.WS, q.ROWS, q.PT);
+        epilogue = 1;
+        if (MT == 4) P8_LAUNCH(4, false, true);
+        else P8_LAUNCH(2, false, true);
+    } else if (MT == 4 && flat) P8_LAUNCH(4, true, false);
+    else if (MT == 4) P8_LAUNCH(4, false, false);
+    else if (flat) P8_LAUNCH(2, true, false);
+    else P8_LAUNCH(2, false, false);
 #undef P8_LAUNCH
     PTMI_LAUNCH_CHECK("p8_conv3x3");
     return 0;

@@ -127,10 +127,11 @@ class VGG(nn.Module):
                 with torch.no_grad():
                     for i in range(blk.num_convs):
                         wt, b = params[2 * i], params[2 * i + 1]
-                        t = p8.conv3x3_raw(t, p8.pack_weights(wt, 0), ops._chk(b.contiguous()), None, n, c, wt.shape[0], h, w, 1)
+                        # a block without a backward pass: its last convolution pools in its epilogue (the full-resolution
+                        # activation is never written)
+                        epi = 4 if (blk.pool and i == blk.num_convs - 1) else 1
+                        t = p8.conv3x3_raw(t, p8.pack_weights(wt, 0), ops._chk(b.contiguous()), None, n, c, wt.shape[0], h, w, epi)
                         c = wt.shape[0]
-                    if blk.pool:
-                        t = p8.maxpool_fwd(t, n, c, h, w)
             c = blk.out_channels
             if blk.pool:
                 h, w = h // 2, w // 2

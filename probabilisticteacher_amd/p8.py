@@ -72,10 +72,11 @@ def pack_weights(w: torch.Tensor, mode: int) -> torch.Tensor:
 
 def conv3x3_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], mask_ref: Optional[torch.Tensor], n: int,
                 cin: int, cout: int, h: int, w: int, epilogue: int) -> torch.Tensor:
-    """one launch of ptmi_p8_conv3x3 (epilogue 0: + bias, 1: + bias + ReLU, 2: none, 3: times (mask_ref > 0))"""
-    y = _alloc(cout, n, h, w, x.device)
+    """one launch of ptmi_p8_conv3x3 (epilogue 0: + bias, 1: + bias + ReLU, 2: none, 3: times (mask_ref > 0), 4: + bias + ReLU + 2x2
+    max-pool: the result is the P8 tensor of the pooled map)"""
+    y = _alloc(cout, n, h // 2, w // 2, x.device) if epilogue == 4 else _alloc(cout, n, h, w, x.device)
     flops = 2.0 * 9 * cin * cout * h * w * n
-    nbytes = 2.0 * plane_pixels(n, h, w) * (cin + cout * (2 if epilogue == 3 else 1)) + 2.0 * 9 * cin * cout
+    nbytes = 2.0 * plane_pixels(n, h, w) * (cin + cout * (2 if epilogue == 3 else (0.25 if epilogue == 4 else 1))) + 2.0 * 9 * cin * cout
     if mask_ref is not None:
         _chk(mask_ref, cout, n, h, w, "p8 conv mask")
     with ops._prof("p8_conv3x3", flops, nbytes):
@@ -235,8 +236,8 @@ def vgg_block_nchw(x: torch.Tensor, pool: bool, params) -> torch.Tensor:
 def conv3x3_relu_pool_nograd_nchw(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     n, cin, h, w = x.shape
     cout = weight.shape[0]
-    y = conv3x3_raw(from_nchw(x), pack_weights(weight, 0), ops._chk(bias.contiguous()), None, n, cin, cout, h, w, 1)
-    return to_nchw(maxpool_fwd(y, n, cout, h, w), n, cout, h // 2, w // 2)
+    y = conv3x3_raw(from_nchw(x), pack_weights(weight, 0), ops._chk(bias.contiguous()), None, n, cin, cout, h, w, 4)
+    return to_nchw(y, n, cout, h // 2, w // 2)
 
 
 # ============================================================================ bf16-storage GEMM (the box head's large Linear layer)

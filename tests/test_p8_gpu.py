@@ -128,6 +128,28 @@ def test_p8_maxpool_forward_backward_exact(n, c, h, w):
     assert torch.equal(p8.to_nchw(dz, n, c, h, w).cpu(), d * (y > 0))
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 16, 64, 8, 10), (3, 32, 128, 33, 37), (1, 64, 48, 7, 9), (2, 16, 200, 2, 3),
+                                            (5, 24, 64, 40, 70), (2, 64, 64, 800, 1333), (2, 128, 128, 400, 666)])
+def test_p8_conv_with_pooling_epilogue_equals_conv_then_pool(n, cin, cout, h, w):
+    """epilogue 4 (bias + ReLU + 2x2 max-pool in the conv kernel's epilogue, blocks without a backward pass): bit for bit the
+    pooled tensor that the ReLU launch followed by the pool kernel writes, pads included -- odd heights / widths (floor),
+    both channel-tile widths, several images (the tile grid restarts per image), the two frozen layers at 1333 x 800."""
+    from probabilisticteacher_amd import p8
+    x = rb(torch.randn(n, cin, h, w, generator=g(31)))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g(32)) * (2.0 / (9 * cin)) ** 0.5)
+    b = torch.randn(cout, generator=g(33)) * 0.1
+    xp = p8.from_nchw(x.to(DEV))
+    wp = p8.pack_weights(wt.to(DEV), 0)
+    full = p8.conv3x3_raw(xp, wp, b.to(DEV), None, n, cin, cout, h, w, 1)
+    want = p8.maxpool_fwd(full, n, cout, h, w)
+    got = torch.full_like(want, float("nan"))
+    from probabilisticteacher_amd import _lib, ops
+    _lib.call("ptmi_p8_conv3x3", ops._ptr(xp), ops._ptr(wp), ops._ptr(b.to(DEV)), None, ops._ptr(got), n, cin, cout, h, w, 4, ops._stream())
+    pads_are_zero(got, n, h // 2, w // 2)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(p8.conv3x3_raw(xp, wp, b.to(DEV), None, n, cin, cout, h, w, 4).view(torch.int16), want.view(torch.int16))
+
+
 @pytest.mark.parametrize("name,cin,cout,h,w", [("conv1_2", 64, 64, 800, 1333), ("conv2_2", 128, 128, 400, 666),
                                                ("conv3_2", 256, 256, 200, 333), ("conv4_2", 512, 512, 100, 166),
                                                ("conv5_2", 512, 512, 50, 83)])
