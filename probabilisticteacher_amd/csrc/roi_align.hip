@@ -238,27 +238,14 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
     }
 }
 
-// Backward without any atomics (7x7 pooling, W <= 128, H <= 64: the hot-path maps).  ROIAlign is separable: a
-// sample's bilinear weight is wy(sample_y, cell_y) * wx(sample_x, cell_x) and its bin is (ph(sample_y),
-// pw(sample_x)), so for one ROI and one channel
+// Backward without any atomics (7x7 pooling).  ROIAlign is separable: a sample's bilinear weight is
+// wy(sample_y, cell_y) * wx(sample_x, cell_x) and its bin is (ph(sample_y), pw(sample_x)), so for one ROI and one channel
 //     dF[fy][fx] += (1/count) * sum_{ph,pw} Wy[fy][ph] * dOut[ph][pw] * Wx[fx][pw]
-// with Wy[fy][ph] = sum of the y-weights that the gh sample rows of bin-row ph put on feature row fy (same for Wx).
-//   * the per-ROI 1-D weight tables (Wy rows y0..y1, Wx rows x0..x1, 8 floats per row) are built ONCE per ROI by
-//     roi_bwd_tables_kernel into a workspace, and
-//   * a workgroup owns 4 channel planes of ONE image in LDS (rois are grouped by image) and every thread owns a FIXED
-//     column (channel c = tid / 128, feature column fx = tid % 128) of the LDS planes for the whole ROI walk, so
-//     consecutive ROIs never hand a cell from one thread to another: the ROI loop has no barrier at all, the
-//     summation order is fixed (deterministic) and each plane is written to HBM once.
-// Each wave stages the ROI's Wy table in a private LDS strip (broadcast reads in the column loop); lanes 0-48 hold
-// dOut[r][c] (broadcast with v_readlane) and every lane its own Wx row.  The tables are indexed by absolute feature
-// row / column, so none of these loads depends on the ROI header and all of them are issued one ROI ahead.
+// with Wy[fy][ph] = sum of the y-weights that the gh sample rows of bin-row ph put on feature row fy (same for Wx).  The per-ROI
+// 1-D weight tables (8 floats per feature row / column, indexed by ABSOLUTE row / column and zero outside the ROI's range, so that
+// the consumer's loads do not depend on the header; the Wx rows carry the 1 / count) are built ONCE per ROI by
+// roi_bwd_tables_kernel into a workspace.
 struct RoiBwdHeader { int y0, y1, x0, x1; float count; int pad[3]; };
-__device__ __forceinline__ float rdl(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-constexpr int RB2_THREADS = 512, RB2_XP = 128;
-
 __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restrict__ rois, void* __restrict__ ws,
                                                             int H, int W, float scale)
 {
@@ -305,127 +292,155 @@ __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restr
     }
     // rows are stored by ABSOLUTE feature row / column (zeros outside the ROI's range), so the consumer's loads do
     // not depend on the header and can be prefetched a whole ROI ahead
+    // the Wx rows carry the ROI's 1 / count
     float* wt = reinterpret_cast<float*>(base + sizeof(RoiBwdHeader));
-    for (int i = tid; i < (H + W) * 8; i += 64) wt[i] = tsm[i];
+    const float inv_count = 1.f / g.count;
+    for (int i = tid; i < (H + W) * 8; i += 64) wt[i] = i < H * 8 ? tsm[i] : tsm[i] * inv_count;
 }
 
-// NP = 16-B pieces of the Wy table per lane: 2 for maps up to 64 rows (the landscape hot path: 50 x 83), 4 up to 128 rows
-// (portrait / mixed batches: 83 x 50, 83 x 83).  The workgroup has two waves per channel plane it holds (CG planes,
-// blockDim = 128 CG), CG chosen by the launcher from the LDS budget.
-template <int NP>
-__global__ __launch_bounds__(RB2_THREADS) void roi_align_bwd_col_kernel(const float* __restrict__ dout,
-                                                                        const void* __restrict__ ws,
-                                                                        const int32_t* __restrict__ img_off,
-                                                                        float* __restrict__ dfeat, int C, int H, int W,
-                                                                        int CG)
+// The accumulation kernel (round 4; lanes laid out for the ROIs the path actually sees -- median 11 x 12 feature cells: its
+// predecessor, a wave with one lane per map column of ONE channel, kept 10-20 of its 64 lanes busy).
+//   * a workgroup owns CG <= 4 channel planes of one image in LDS (plane pitch = 16 banks mod 64: the four channels of a wave's
+//     16-column window fall on disjoint bank quarters); wave w owns the ROWS [w BR, (w + 1) BR) of all planes -- fixed row
+//     ownership, so consecutive ROIs never hand a cell from one wave to another (a wave's LDS operations execute in order): no
+//     barrier in the ROI walk, a fixed summation order per cell (ROI order), each plane written to HBM once;
+//   * lane = (channel c = lane / 16, column j = lane % 16 of a 16-column window that starts at the ROI's first column and
+//     slides in steps of 16): t[ph] = sum_pw dOut[c][ph][pw] Wx[x][pw] / count once per window, then one read-modify-write
+//     per owned row.  A wave whose band the ROI does not touch skips it on the (scalar) header alone;
+//   * everything a ROI needs is fetched while the previous one is accumulated: headers two ROIs ahead (scalar), the 4 x 49
+//     gradients, the band's rows of the Wy table and the first window's Wx rows one ahead.
+constexpr int RB3_PLANES = 4;
+#ifndef RB3_WAVES
+#define RB3_WAVES 8          // row bands = waves per workgroup (6 and 4 measured slower: tools/exp/roi_variants.sh)
+#endif
+#ifndef RB3_UNROLL
+#define RB3_UNROLL 2         // rows in flight per lane
+#endif
+
+__global__ __launch_bounds__(64 * RB3_WAVES, RB3_WAVES == 6 ? 3 : 4) void roi_align_bwd_band_kernel(const float* __restrict__ dout, const void* __restrict__ ws,
+                                                                 const int32_t* __restrict__ img_off, float* __restrict__ dfeat,
+                                                                 int C, int H, int W, int CG, int PITCH, int BR)
 {
     extern __shared__ float smem[];
     const int HW = H * W;
-    float* plane = smem;                                         // CG * HW
-    float* wystage = plane + CG * HW;                            // 2 CG waves x H x 8
+    float* plane = smem;                                         // CG * PITCH
     const int n = blockIdx.y, c0 = blockIdx.x * CG;
     const int cg = min(CG, C - c0);
     const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < cg * HW; i += nthreads) plane[i] = 0.f;
+    float* wyl = plane + CG * PITCH + wave * (64 * 4 + 4 * 52);  // this wave's strip: Wy rows of its band (64 x 16 B) | 4 x 52 gradients
+    float* gl = wyl + 64 * 4;
+    for (int i = tid; i < CG * PITCH; i += nthreads) plane[i] = 0.f;
     __syncthreads();
-    const int c = wave >> 1;                                     // wave-uniform channel; two waves cover 128 columns
-    const int fx = (wave & 1) * 64 + lane;
-    const int fxc = fx < W ? fx : W - 1;                         // clamped: lanes past the map only read
-    float* wyl = wystage + wave * H * 8;
-    float* gl = wystage + (nthreads >> 6) * H * 8 + wave * 52;        // this wave's copy of dOut[r][c] (49 values + pad)
+    const int b0 = wave * BR, b1 = min(H, b0 + BR);              // owned rows [b0, b1)
+    const int c = lane >> 4, j = lane & 15;
     const size_t stride = sizeof(RoiBwdHeader) + (size_t)(H + W) * 8 * sizeof(float);
     const int r0 = img_off[n], r1 = img_off[n + 1];
-    const int nwy = H * 2;                                       // f32x4 pieces of a Wy table (<= 64 NP: NP per lane)
-    if (c < cg && r0 < r1) {
-        float* col = plane + c * HW + fx;
-        // everything ROI r needs is fetched while ROI r-1 is being accumulated: its header (scalar), this lane's
-        // dOut value (lanes 0-48 hold the 7x7 gradient of channel c), its Wx row and its two pieces of the Wy table
-        auto fetch = [&](int r, RoiBwdHeader& hd, float& g, f32x4& wxa, f32x4& wxb, f32x4 (&wy)[NP]) {
-            const char* base = (const char*)ws + (size_t)r * stride;
-            hd = *reinterpret_cast<const RoiBwdHeader*>(base);
-            const f32x4* wyg = reinterpret_cast<const f32x4*>(base + sizeof(RoiBwdHeader));
-            const f32x4* wxg = wyg + (size_t)H * 2;
-            g = dout[((size_t)r * C + c0 + c) * 49 + (lane < 49 ? lane : 48)];
-            wxa = wxg[fxc * 2];
-            wxb = wxg[fxc * 2 + 1];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) wy[q] = wyg[lane + 64 * q < nwy ? lane + 64 * q : 0];
+    if (b0 < b1 && r0 < r1) {
+        struct Pre { float g[4]; f32x4 wy, wxa, wxb; };
+        auto header = [&](int r) { return *reinterpret_cast<const RoiBwdHeader*>((const char*)ws + (size_t)r * stride); };
+        auto touches = [&](const RoiBwdHeader& hd) { return hd.y1 >= 0 && hd.x1 >= 0 && max(hd.y0, b0) <= min(hd.y1, b1 - 1); };
+        auto wxrow = [&](int r, int x, f32x4& a, f32x4& b) {
+            const f32x4* wxg = reinterpret_cast<const f32x4*>((const char*)ws + (size_t)r * stride + sizeof(RoiBwdHeader)) + (size_t)H * 2;
+            const int xc = x < W ? x : W - 1;                    // lanes past the ROI only read
+            a = wxg[xc * 2];
+            b = wxg[xc * 2 + 1];
         };
-        RoiBwdHeader hd, hdn;
-        float g, gn;
-        f32x4 wxa, wxb, wy[NP], wxan, wxbn, wyn[NP];
-        fetch(r0, hd, g, wxa, wxb, wy);
-        for (int r = r0; r < r1; ++r) {
-            if (r + 1 < r1) fetch(r + 1, hdn, gn, wxan, wxbn, wyn);
-            const int lo = (wave & 1) * 64;
-            if (hd.y1 >= 0 && hd.x1 >= 0 && hd.x1 >= lo && hd.x0 <= lo + 63) {      // wave-uniform
+        // range-checked buffer loads: lanes past the 49 cg gradients / past the band's table rows read zeros without a branch
+        const unsigned gbytes = 49u * (unsigned)cg * 4u, wybytes = (unsigned)(b1 - b0) * 32u;
+        auto fetch = [&](int r, const RoiBwdHeader& hd, Pre& p) {
+            const char* base = (const char*)ws + (size_t)r * stride + sizeof(RoiBwdHeader);
+            const __amdgpu_buffer_rsrc_t rg = ptmi_rsrc(dout + ((size_t)r * C + c0) * 49, gbytes);
+            const __amdgpu_buffer_rsrc_t rwy = ptmi_rsrc(base + (size_t)b0 * 32, wybytes);
 #pragma unroll
-                for (int q = 0; q < NP; ++q)
-                    if (lane + 64 * q < nwy) reinterpret_cast<f32x4*>(wyl)[lane + 64 * q] = wy[q];
-                if (lane < 52) gl[lane] = g;
+            for (int q = 0; q < 4; ++q)
+                p.g[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (lane + 64 * q) * 4, 0, 0));
+            p.wy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rwy, lane * 16, 0, 0));
+            wxrow(r, hd.x0 + j, p.wxa, p.wxb);
+        };
+        int gslot[4];                                            // LDS slot of gradient lane + 64 q: [channel][52]; slot 51 of channel 0 is a pad
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = lane + 64 * q;
+            gslot[q] = idx < 196 ? (idx / 49) * 52 + idx % 49 : 51;
+        }
+        RoiBwdHeader hd = header(r0), hdn = hd, hdnn = hd;
+        if (r0 + 1 < r1) hdn = header(r0 + 1);
+        Pre cur, nxt;
+        if (touches(hd)) fetch(r0, hd, cur);
+        for (int r = r0; r < r1; ++r) {
+            if (r + 2 < r1) hdnn = header(r + 2);
+            const bool actn = r + 1 < r1 && touches(hdn);
+            if (actn) fetch(r + 1, hdn, nxt);
+            if (touches(hd)) {                                   // wave-uniform
+#pragma unroll
+                for (int q = 0; q < 4; ++q) gl[gslot[q]] = cur.g[q];
+                reinterpret_cast<f32x4*>(wyl)[lane] = cur.wy;    // (64 entries per wave: rows past the band are zeros)
                 __builtin_amdgcn_wave_barrier();                 // the strip is read by other lanes of this wave
-                const float inv_count = 1.f / hd.count;          // (wave-uniform; the seven quotients below were a third of the ROI's VALU work)
-                float t[7];
-                float gq[52];                                    // the 7x7 gradient, broadcast-read from the strip
+                float gq[52];
 #pragma unroll
                 for (int q = 0; q < 13; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(gl + 4 * q);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(gl + c * 52 + 4 * q);
                     gq[4 * q] = v[0]; gq[4 * q + 1] = v[1]; gq[4 * q + 2] = v[2]; gq[4 * q + 3] = v[3];
                 }
+                const int ya = max(hd.y0, b0), yb = min(hd.y1, b1 - 1);
+                f32x4 wxa = cur.wxa, wxb = cur.wxb;
+                for (int xs = hd.x0; xs <= hd.x1; xs += 16) {
+                    const int x = xs + j;
+                    if (xs != hd.x0) wxrow(r, x, wxa, wxb);
+                    float t[7];
 #pragma unroll
-                for (int ph = 0; ph < 7; ++ph) {
-                    float a = gq[ph * 7 + 0] * wxa[0];
-                    a += gq[ph * 7 + 1] * wxa[1];
-                    a += gq[ph * 7 + 2] * wxa[2];
-                    a += gq[ph * 7 + 3] * wxa[3];
-                    a += gq[ph * 7 + 4] * wxb[0];
-                    a += gq[ph * 7 + 5] * wxb[1];
-                    a += gq[ph * 7 + 6] * wxb[2];
-                    t[ph] = a * inv_count;
-                }
-                if (fx >= hd.x0 && fx <= hd.x1) {
-                    // rows are independent read-modify-writes of this lane's LDS column: four at a time, so that the
-                    // LDS round trips (table row, cell read, cell write) of different rows overlap
-                    auto rowsum = [&](const f32x4& wa, const f32x4& wb) {
-                        float a = wa[0] * t[0];
-                        a += wa[1] * t[1];
-                        a += wa[2] * t[2];
-                        a += wa[3] * t[3];
-                        a += wb[0] * t[4];
-                        a += wb[1] * t[5];
-                        a += wb[2] * t[6];
-                        return a;
-                    };
-                    int fy = hd.y0;
-                    for (; fy + 3 <= hd.y1; fy += 4) {
-                        f32x4 wa[4], wb[4];
-                        float cv[4];
+                    for (int ph = 0; ph < 7; ++ph) {
+                        float a = gq[ph * 7 + 0] * wxa[0];
+                        a = __builtin_fmaf(gq[ph * 7 + 1], wxa[1], a);
+                        a = __builtin_fmaf(gq[ph * 7 + 2], wxa[2], a);
+                        a = __builtin_fmaf(gq[ph * 7 + 3], wxa[3], a);
+                        a = __builtin_fmaf(gq[ph * 7 + 4], wxb[0], a);
+                        a = __builtin_fmaf(gq[ph * 7 + 5], wxb[1], a);
+                        t[ph] = __builtin_fmaf(gq[ph * 7 + 6], wxb[2], a);
+                    }
+                    if (x <= hd.x1 && c < cg) {
+                        float* col = plane + c * PITCH + x;
+                        auto rowsum = [&](const f32x4& wa, const f32x4& wb, float acc) {
+                            acc = __builtin_fmaf(wa[0], t[0], acc);
+                            acc = __builtin_fmaf(wa[1], t[1], acc);
+                            acc = __builtin_fmaf(wa[2], t[2], acc);
+                            acc = __builtin_fmaf(wa[3], t[3], acc);
+                            acc = __builtin_fmaf(wb[0], t[4], acc);
+                            acc = __builtin_fmaf(wb[1], t[5], acc);
+                            acc = __builtin_fmaf(wb[2], t[6], acc);
+                            return acc;
+                        };
+                        int fy = ya;
+                        for (; fy + RB3_UNROLL - 1 <= yb; fy += RB3_UNROLL) {
+                            f32x4 wa[RB3_UNROLL], wb[RB3_UNROLL];
+                            float cv[RB3_UNROLL];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            wa[u] = *reinterpret_cast<const f32x4*>(wyl + (fy + u) * 8);
-                            wb[u] = *reinterpret_cast<const f32x4*>(wyl + (fy + u) * 8 + 4);
-                            cv[u] = col[(fy + u) * W];
+                            for (int u = 0; u < RB3_UNROLL; ++u) {
+                                wa[u] = *reinterpret_cast<const f32x4*>(wyl + (fy + u - b0) * 8);
+                                wb[u] = *reinterpret_cast<const f32x4*>(wyl + (fy + u - b0) * 8 + 4);
+                                cv[u] = col[(fy + u) * W];
+                            }
+#pragma unroll
+                            for (int u = 0; u < RB3_UNROLL; ++u) col[(fy + u) * W] = rowsum(wa[u], wb[u], cv[u]);
                         }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) col[(fy + u) * W] = cv[u] + rowsum(wa[u], wb[u]);
-                    }
-                    for (; fy <= hd.y1; ++fy) {
-                        const f32x4 wa = *reinterpret_cast<const f32x4*>(wyl + fy * 8);
-                        const f32x4 wb = *reinterpret_cast<const f32x4*>(wyl + fy * 8 + 4);
-                        col[fy * W] += rowsum(wa, wb);
+                        for (; fy <= yb; ++fy) {
+                            const f32x4 wa = *reinterpret_cast<const f32x4*>(wyl + (fy - b0) * 8);
+                            const f32x4 wb = *reinterpret_cast<const f32x4*>(wyl + (fy - b0) * 8 + 4);
+                            col[fy * W] = rowsum(wa, wb, col[fy * W]);
+                        }
                     }
                 }
-                __builtin_amdgcn_wave_barrier();                 // next ROI overwrites the strip
+                __builtin_amdgcn_wave_barrier();                 // the next ROI overwrites the strip
             }
-            hd = hdn; g = gn; wxa = wxan; wxb = wxbn;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) wy[q] = wyn[q];
+            hd = hdn; hdn = hdnn; cur = nxt;
         }
     }
     __syncthreads();
-    float* dst = dfeat + ((size_t)n * C + c0) * HW;
-    for (int i = tid; i < cg * HW; i += nthreads) dst[i] = plane[i];
+    for (int i = tid; i < cg * HW; i += nthreads) {
+        const int cc = i / HW;
+        dfeat[((size_t)n * C + c0 + cc) * HW + (i - cc * HW)] = plane[cc * PITCH + (i - cc * HW)];
+    }
 }
 
 }  // namespace
@@ -509,13 +524,17 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
                    "roi_align_bwd_grouped: bad args");
     hipStream_t st = (hipStream_t)s;
     const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    // channel planes per workgroup (two waves each): as many as fit next to the per-wave table strips in half a CU's LDS
-    const size_t strip = (size_t)2 * (h * 8 + 52) * sizeof(float);       // per plane: two waves' Wy table + gradient strips
-    int cg = (int)((79 * 1024) / (plane_bytes + strip));
-    if (cg > 4) cg = 4;
+    // the band kernel: RB3_WAVES row bands (at most 32 rows each), up to four channel planes per workgroup at a pitch of
+    // 16 (mod 64) floats, two workgroups per CU if they fit, one otherwise
+    const int nb = RB3_WAVES, br = cdiv(h, nb);
+    const int pitch = ((h * w + 47) / 64) * 64 + 16;
+    const size_t strips = (size_t)nb * (64 * 4 + 4 * 52) * sizeof(float);
+    int cg = (int)((80 * 1024 - strips) / ((size_t)pitch * 4));
+    if (cg < 1) cg = (int)((160 * 1024 - strips) / ((size_t)pitch * 4));
+    if (cg > RB3_PLANES) cg = RB3_PLANES;
     if (cg > c) cg = c;
-    const bool col_ok = pooled == 7 && ws && w <= RB2_XP && h <= 128 && cg >= 1;
-    if (!col_ok || r == 0) {              // not the hot-path shape (or no ROI at all): zero + atomic scatter kernel
+    const bool band_ok = pooled == 7 && ws && br <= 32 && cg >= 1;
+    if (!band_ok || r == 0) {             // not the hot-path shape (or no ROI at all): zero + atomic scatter kernel
         hipError_t e = hipMemsetAsync(dfeat, 0, (size_t)n * c * plane_bytes, st);
         if (e != hipSuccess) { ptmi_set_error("roi_align_bwd_grouped: memset failed"); return -2; }
         return r == 0 ? 0 : ptmi_roi_align_bwd(dout, rois, dfeat, n, c, h, w, r, pooled, scale, s);
@@ -524,22 +543,14 @@ int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32
     hipLaunchKernelGGL(roi_bwd_tables_kernel, dim3(r), dim3(64), (size_t)(h + w) * 8 * sizeof(float), st, rois, ws, h, w,
                        scale);
     PTMI_LAUNCH_CHECK("roi_align_bwd_tables");
-    static bool attr2 = false;
-    if (!attr2) {
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_col_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr2 = true;
+    static bool attr3 = false;
+    if (!attr3) {
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr3 = true;
     }
-    const size_t lds = (size_t)cg * (plane_bytes + strip);
-    if (h <= 64)
-        hipLaunchKernelGGL(roi_align_bwd_col_kernel<2>, dim3(cdiv(c, cg), n), dim3(128 * cg), lds, st, dout, ws, img_offsets,
-                           dfeat, c, h, w, cg);
-    else
-        hipLaunchKernelGGL(roi_align_bwd_col_kernel<4>, dim3(cdiv(c, cg), n), dim3(128 * cg), lds, st, dout, ws, img_offsets,
-                           dfeat, c, h, w, cg);
-    PTMI_LAUNCH_CHECK("roi_align_bwd_grouped(col)");
+    hipLaunchKernelGGL(roi_align_bwd_band_kernel, dim3(cdiv(c, cg), n), dim3(64 * nb), (size_t)cg * pitch * 4 + strips, st, dout, ws,
+                       img_offsets, dfeat, c, h, w, cg, pitch, br);
+    PTMI_LAUNCH_CHECK("roi_align_bwd_grouped(band)");
     return 0;
 }
 
