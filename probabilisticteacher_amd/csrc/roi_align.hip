@@ -106,61 +106,76 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restr
     }
 }
 
-struct TapEntry { int lo, hi; float wlo, whi; };   // wlo = 1 - frac (weight of `lo`), whi = frac; lo < 0 => skipped
+// Forward for rois grouped by image.  The samples of a bin are separable: a bin's value is
+//     (1 / count) sum_{y, x} Wy_ph[y] F[y][x] Wx_pw[x]
+// over the (at most gh + 1) x (gw + 1) feature cells its gh x gw samples touch, with Wy_ph[y] = the summed y-weights of the bin's
+// sample rows on feature row y (same for x) -- about half of the 4 gh gw tap reads of the sample-by-sample form (12 instead of 24
+// for the step's average 2 x 3 samples per bin).  roi_bin_tables_kernel writes, once per ROI, the first cell and the weights of
+// every bin row / bin column (the x weights carry the 1 / count); the gather kernel keeps CG = 4 channel planes of one image in
+// LDS (read from HBM / L2 once, coalesced), runs 20 ROIs at a time on 980 of its 1024 threads (thread = (roi slot, bin); it
+// walks the four planes itself, so a ROI's table entries are fetched once per FOUR outputs) and needs no barrier after the
+// planes are loaded.  Not the torchvision summation order: equal to the plain gather kernel to fp32 rounding, not bit for bit.
+struct RoiBinHeader { int sy, sx, pad0, pad1; int ylo[8]; int xlo[8]; };      // then wy[7][TS], wx[7][TS] (floats)
 
-// Forward for rois grouped by image.  Per ROI the sample geometry is separable and identical for every channel:
-// roi_tables_kernel writes one table entry per sample row / column (taps + weights; header + 2 * TS entries per ROI)
-// into a workspace, once per ROI.  The gather kernel keeps CG = 4 channel planes of one image in LDS (read from
-// HBM/L2 once, coalesced), runs 5 ROIs at a time on 980 of its 1024 threads (thread = (roi slot, channel, bin)) and
-// needs no barrier after the planes are loaded; a bin's column taps stay in registers across its sample rows.  The
-// arithmetic per sample is exactly the torchvision expression (w1*f1 + w2*f2 + w3*f3 + w4*f4 summed in sample
-// order, / count), so results equal the plain gather kernel bit for bit.  (Its predecessor rebuilt the tables in
-// every channel-group workgroup -- 128 times per ROI -- behind two barriers per pair of ROIs.)
-struct RoiHeader { int gh, gw; float count; int pad; };
-
-__global__ __launch_bounds__(256) void roi_tables_kernel(const float* __restrict__ rois, void* __restrict__ ws, int R,
-                                                         int H, int W, float scale, int TS)
+__global__ __launch_bounds__(64) void roi_bin_tables_kernel(const float* __restrict__ rois, void* __restrict__ ws, int H, int W,
+                                                            float scale, int TS)
 {
+    extern __shared__ float tw[];                    // [14][TS]
+    __shared__ int slo[14], sn[14];
     const int r = blockIdx.x, t = threadIdx.x;
     const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, 7);
-    char* base = (char*)ws + (size_t)r * (sizeof(RoiHeader) + 2 * (size_t)TS * sizeof(TapEntry));
-    if (t == 0) {
-        RoiHeader h;
-        h.gh = g.gh; h.gw = g.gw; h.count = g.count; h.pad = 0;
-        *reinterpret_cast<RoiHeader*>(base) = h;
-    }
-    TapEntry* tab = reinterpret_cast<TapEntry*>(base + sizeof(RoiHeader));
-    const int ny = 7 * g.gh, nx = 7 * g.gw;
-    for (int i = t; i < ny + nx; i += 256) {
-        const bool isx = i >= ny;
-        const int sidx = isx ? i - ny : i;
+    for (int i = t; i < 14 * TS; i += 64) tw[i] = 0.f;
+    __syncthreads();
+    if (t < 14) {
+        const bool isx = t >= 7;
+        const int pb = isx ? t - 7 : t;
         const int gn = isx ? g.gw : g.gh, L = isx ? W : H;
-        const int pb = sidx / gn, k = sidx - pb * gn;
         const float start = isx ? g.sw : g.sh, bsz = isx ? g.bw : g.bh;
-        float v = start + (float)pb * bsz + ((float)k + .5f) * bsz / (float)gn;
-        TapEntry e;
-        if (v < -1.0f || v > (float)L) { e.lo = -1; e.hi = -1; e.wlo = e.whi = 0.f; }
-        else {
+        float* wv = tw + t * TS;
+        int lo0 = -1, n = 0;
+        for (int i = 0; i < gn; ++i) {
+            float v = start + (float)pb * bsz + ((float)i + .5f) * bsz / (float)gn;
+            if (v < -1.0f || v > (float)L) continue;
             if (v <= 0.f) v = 0.f;
             int l = (int)v, h2;
             if (l >= L - 1) { h2 = l = L - 1; v = (float)l; } else h2 = l + 1;
-            const float lw = v - (float)l;
-            e.lo = l; e.hi = h2; e.whi = lw; e.wlo = 1.f - lw;
+            const float lw = v - (float)l, hw = 1.f - lw;
+            if (lo0 < 0) lo0 = l;                    // samples ascend: the first valid one has the lowest cell
+            if (h2 - lo0 < TS) {
+                wv[l - lo0] += hw;
+                wv[h2 - lo0] += lw;
+                n = h2 - lo0 + 1;
+            } else n = -(1 << 20);                   // a box many times the map: a bin spans more cells than the table holds
         }
-        if (sidx < TS) tab[(isx ? TS : 0) + sidx] = e;
+        slo[t] = lo0 < 0 ? 0 : lo0;
+        sn[t] = n;
     }
+    __syncthreads();
+    char* base = (char*)ws + (size_t)r * (sizeof(RoiBinHeader) + 14 * (size_t)TS * sizeof(float));
+    if (t == 0) {
+        RoiBinHeader hd;
+        hd.sy = hd.sx = 0; hd.pad0 = hd.pad1 = 0;
+        bool fits = true;
+        for (int i = 0; i < 7; ++i) {
+            fits = fits && sn[i] >= 0 && sn[7 + i] >= 0;
+            hd.sy = max(hd.sy, sn[i]); hd.sx = max(hd.sx, sn[7 + i]); hd.ylo[i] = slo[i]; hd.xlo[i] = slo[7 + i];
+        }
+        if (!fits) hd.sy = hd.sx = -1;               // the gather kernel walks this ROI sample by sample
+        hd.ylo[7] = hd.xlo[7] = 0;
+        *reinterpret_cast<RoiBinHeader*>(base) = hd;
+    }
+    float* wt = reinterpret_cast<float*>(base + sizeof(RoiBinHeader));
+    const float inv_count = 1.f / g.count;
+    for (int i = t; i < 14 * TS; i += 64) wt[i] = i < 7 * TS ? tw[i] : tw[i] * inv_count;
 }
 
 constexpr int RF2_THREADS = 1024, RF2_SLOTS = 20, RF2_CG = 4;
 
-// thread = (roi slot, bin); it walks the workgroup's (up to) four channel planes itself, so the ROI's header and the bin's
-// row / column taps are fetched once per FOUR outputs (the first version had a thread per (slot, channel, bin): the tap
-// loads, nine 16-B requests per thread and ROI, cost as much TA time as the gathers themselves).
-__global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const float* __restrict__ feat,
+__global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_bin_kernel(const float* __restrict__ feat,
                                                                         const void* __restrict__ ws,
                                                                         const int32_t* __restrict__ img_off,
                                                                         float* __restrict__ out, int C, int H, int W,
-                                                                        int CG, int TS)
+                                                                        int CG, int TS, const float* __restrict__ rois, float scale)
 {
     extern __shared__ float smem[];
     const int HW = H * W;
@@ -174,67 +189,64 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_tab_kernel(const fl
     const int slot = tid / 49, bin = tid - slot * 49;
     const int ph = bin / 7, pw = bin - ph * 7;
     if (slot >= RF2_SLOTS) return;
-    const size_t rstride = sizeof(RoiHeader) + 2 * (size_t)TS * sizeof(TapEntry);
+    const size_t rstride = sizeof(RoiBinHeader) + 14 * (size_t)TS * sizeof(float);
     const int r1 = img_off[n + 1];
+    // planes past the workgroup's last channel alias plane 0 (their sums are not stored)
+    const int o1 = cg > 1 ? HW : 0, o2 = cg > 2 ? 2 * HW : 0, o3 = cg > 3 ? 3 * HW : 0;
     for (int r = img_off[n] + slot; r < r1; r += RF2_SLOTS) {
         const char* base = (const char*)ws + (size_t)r * rstride;
-        const RoiHeader hd = *reinterpret_cast<const RoiHeader*>(base);
-        const TapEntry* yt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + ph * hd.gh;
-        const TapEntry* xt = reinterpret_cast<const TapEntry*>(base + sizeof(RoiHeader)) + TS + pw * hd.gw;
-        float acc[RF2_CG] = {0.f, 0.f, 0.f, 0.f};
-        // (per channel the arithmetic is the torchvision expression in sample order: bit-identical to the plain kernel)
-        if (hd.gw <= 4 && hd.gh <= 4) {
-            // common case (ROIs up to 28 feature cells a side): all taps of the bin are fetched up front and the
-            // 4 x 4 sample grid is fully unrolled, so the LDS reads of different samples and channels overlap
-            TapEntry ex[4], ey[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k < hd.gw) ex[k] = xt[k];
-                else { ex[k].lo = -1; ex[k].hi = -1; ex[k].wlo = ex[k].whi = 0.f; }
-                if (k < hd.gh) ey[k] = yt[k];
-                else { ey[k].lo = -1; ey[k].hi = -1; ey[k].wlo = ey[k].whi = 0.f; }
+        const RoiBinHeader* hd = reinterpret_cast<const RoiBinHeader*>(base);
+        const int sy = hd->sy, sx = hd->sx, ylo = hd->ylo[ph], xlo = hd->xlo[pw];
+        const float* wyp = reinterpret_cast<const float*>(base + sizeof(RoiBinHeader)) + ph * TS;
+        const float* wxp = reinterpret_cast<const float*>(base + sizeof(RoiBinHeader)) + (7 + pw) * TS;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        auto cell = [&](float w, int y, int x) {
+            const float* f = plane + min(y, H - 1) * W + min(x, W - 1);      // (cells past the map carry zero weights)
+            a0 = __builtin_fmaf(w, f[0], a0);
+            a1 = __builtin_fmaf(w, f[o1], a1);
+            a2 = __builtin_fmaf(w, f[o2], a2);
+            a3 = __builtin_fmaf(w, f[o3], a3);
+        };
+        if (sy < 0) {
+            // no table (see roi_bin_tables_kernel): the torchvision loop over the bin's samples
+            const RoiGeom g = roi_geom(rois + 5 * (size_t)r, scale, 7);
+            for (int iy = 0; iy < g.gh; ++iy) {
+                const float y = g.sh + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+                for (int ix = 0; ix < g.gw; ++ix) {
+                    const float x = g.sw + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                    int yl, xl, yh, xh;
+                    float w1, w2, w3, w4;
+                    if (!bilin(y, x, H, W, yl, xl, yh, xh, w1, w2, w3, w4)) continue;
+                    cell(w1 / g.count, yl, xl);
+                    cell(w2 / g.count, yl, xh);
+                    cell(w3 / g.count, yh, xl);
+                    cell(w4 / g.count, yh, xh);
+                }
             }
+        } else if (sy <= 4 && sx <= 4) {
+            // common case (bins of up to 3 samples a side): the bin's weights arrive as two 16-byte loads, the 4 x 4 cell grid is
+            // unrolled under per-lane predicates
+            const f32x4 wy = *reinterpret_cast<const f32x4*>(wyp), wx = *reinterpret_cast<const f32x4*>(wxp);
 #pragma unroll
-            for (int iy = 0; iy < 4; ++iy) {
-                if (ey[iy].lo < 0) continue;
-                const float* f0 = plane + ey[iy].lo * W;
-                const float* f1 = plane + ey[iy].hi * W;
+            for (int a = 0; a < 4; ++a) {
+                if (a >= sy) break;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (ex[k].lo < 0) continue;
-                    const float w1 = ey[iy].wlo * ex[k].wlo, w2 = ey[iy].wlo * ex[k].whi, w3 = ey[iy].whi * ex[k].wlo,
-                                w4 = ey[iy].whi * ex[k].whi;
-#pragma unroll
-                    for (int c = 0; c < RF2_CG; ++c) {
-                        if (c >= cg) break;
-                        const int o = c * HW;
-                        acc[c] += w1 * f0[o + ex[k].lo] + w2 * f0[o + ex[k].hi] + w3 * f1[o + ex[k].lo] + w4 * f1[o + ex[k].hi];
-                    }
+                for (int b = 0; b < 4; ++b) {
+                    if (b >= sx) break;
+                    cell(wy[a] * wx[b], ylo + a, xlo + b);
                 }
             }
         } else {
-            for (int iy = 0; iy < hd.gh; ++iy) {
-                const TapEntry ey = yt[iy];
-                if (ey.lo < 0) continue;
-                const float* f0 = plane + ey.lo * W;
-                const float* f1 = plane + ey.hi * W;
-                for (int ix = 0; ix < hd.gw; ++ix) {
-                    const TapEntry ex = xt[ix];
-                    if (ex.lo < 0) continue;
-                    const float w1 = ey.wlo * ex.wlo, w2 = ey.wlo * ex.whi, w3 = ey.whi * ex.wlo, w4 = ey.whi * ex.whi;
-#pragma unroll
-                    for (int c = 0; c < RF2_CG; ++c) {
-                        if (c >= cg) break;
-                        const int o = c * HW;
-                        acc[c] += w1 * f0[o + ex.lo] + w2 * f0[o + ex.hi] + w3 * f1[o + ex.lo] + w4 * f1[o + ex.hi];
-                    }
-                }
+            for (int a = 0; a < sy; ++a) {
+                const float wya = wyp[a];
+                for (int b = 0; b < sx; ++b) cell(wya * wxp[b], ylo + a, xlo + b);
             }
         }
         float* dst = out + ((size_t)r * C + c0) * 49 + bin;
-#pragma unroll
-        for (int c = 0; c < RF2_CG; ++c)
-            if (c < cg) dst[c * 49] = acc[c] / hd.count;
+        dst[0] = a0;
+        if (cg > 1) dst[49] = a1;
+        if (cg > 2) dst[98] = a2;
+        if (cg > 3) dst[147] = a3;
     }
 }
 
@@ -473,14 +485,14 @@ int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n
 
 static int roi_tab_stride(int h, int w)
 {
-    // adaptive grid g = ceil(roi/7) in feature cells is at most ceil((dim+1)/7) (+1 slack); a table holds 7*g entries
+    // a bin's samples touch at most g + 1 cells, g = ceil(roi extent / 7) <= ceil((dim + 1) / 7) (+ 1 slack), rounded up to 16 bytes
     const int gmax = ((h > w ? h : w) + 1 + 6) / 7 + 1;
-    return (7 * gmax + 3) & ~3;
+    return (gmax + 1 + 3) & ~3;
 }
 
 int64_t ptmi_roi_align_ws_bytes(int r, int h, int w)
 {
-    return (int64_t)(r > 0 ? r : 1) * (int64_t)(sizeof(RoiHeader) + 2 * (size_t)roi_tab_stride(h, w) * sizeof(TapEntry));
+    return (int64_t)(r > 0 ? r : 1) * (int64_t)(sizeof(RoiBinHeader) + 14 * (size_t)roi_tab_stride(h, w) * sizeof(float));
 }
 
 int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32_t* img_offsets, float* out, void* ws,
@@ -498,16 +510,16 @@ int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32
     if (cg > c) cg = c;
     const int TS = roi_tab_stride(h, w);
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(roi_tables_kernel, dim3(r), dim3(256), 0, st, rois, ws, r, h, w, scale, TS);
+    hipLaunchKernelGGL(roi_bin_tables_kernel, dim3(r), dim3(64), (size_t)14 * TS * sizeof(float), st, rois, ws, h, w, scale, TS);
     PTMI_LAUNCH_CHECK("roi_align_tables");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)roi_align_fwd_tab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)roi_align_fwd_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(roi_align_fwd_tab_kernel, dim3(cdiv(c, cg), n), dim3(RF2_THREADS), (size_t)cg * plane_bytes, st,
-                       feat, ws, img_offsets, out, c, h, w, cg, TS);
+    hipLaunchKernelGGL(roi_align_fwd_bin_kernel, dim3(cdiv(c, cg), n), dim3(RF2_THREADS), (size_t)cg * plane_bytes, st,
+                       feat, ws, img_offsets, out, c, h, w, cg, TS, rois, scale);
     PTMI_LAUNCH_CHECK("roi_align_fwd_grouped");
     return 0;
 }
