@@ -192,9 +192,10 @@ int ptmi_rowsum_batched(const float* a, float* out, int batch, int rows, int col
  * pt/modeling/roi_heads/roi_heads.py:68-73 and called at :126.  rois (R,5)=[img,x1,y1,x2,y2]. */
 int ptmi_roi_align_fwd(const float* feat, const float* rois, float* out, int n, int c, int h,
                        int w, int r, int pooled, float scale, ptmi_stream_t s);
-/* Same result (bit for bit) for rois GROUPED BY IMAGE (img_offsets int32 (n+1) device array): the per-ROI sample
- * taps are tabulated once into `ws` (ptmi_roi_align_ws_bytes(r, h, w) bytes of device scratch), channel planes are
- * staged in LDS once per image.  ws == NULL falls back to ptmi_roi_align_fwd. */
+/* Same result to fp32 rounding (a bin's cells are summed with separable row / column weights, not sample by sample) for rois
+ * GROUPED BY IMAGE (img_offsets int32 (n+1) device array): every bin row's / column's first cell and weights are tabulated
+ * once into `ws` (ptmi_roi_align_ws_bytes(r, h, w) bytes of device scratch), channel planes are staged in LDS once per image.
+ * ws == NULL falls back to ptmi_roi_align_fwd. */
 int64_t ptmi_roi_align_ws_bytes(int r, int h, int w);
 int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32_t* img_offsets,
                                float* out, void* ws, int n, int c, int h, int w, int r, int pooled,
@@ -202,10 +203,11 @@ int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32
 /* dfeat must be zeroed by the caller (atomic scatter-add). */
 int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n, int c, int h,
                        int w, int r, int pooled, float scale, ptmi_stream_t s);
-/* Same result for rois GROUPED BY IMAGE (rows img_offsets[i]..img_offsets[i+1] belong to image i; int32
- * device array of n+1): each workgroup accumulates a few channel planes of one image in LDS and writes them
- * once -- no global atomics, dfeat need not be zeroed (every element is written).  `ws`:
- * ptmi_roi_align_bwd_ws_bytes(r, h, w) bytes of device scratch for the per-ROI weight tables (NULL: slower kernel). */
+/* Same result (to summation order) for rois GROUPED BY IMAGE (rows img_offsets[i]..img_offsets[i+1] belong to image i; int32
+ * device array of n+1): each workgroup accumulates up to four channel planes of one image in LDS, every plane row owned
+ * by one wave, and writes them once -- no global atomics, a fixed summation order (bitwise reproducible), dfeat need not be
+ * zeroed (every element is written).  `ws`: ptmi_roi_align_bwd_ws_bytes(r, h, w) bytes of device scratch for the per-ROI
+ * weight tables (NULL, or planes that do not fit the LDS: the atomic kernel on a zeroed dfeat). */
 int64_t ptmi_roi_align_bwd_ws_bytes(int r, int h, int w);
 int ptmi_roi_align_bwd_grouped(const float* dout, const float* rois, const int32_t* img_offsets,
                                float* dfeat, void* ws, int n, int c, int h, int w, int r, int pooled,

@@ -11,6 +11,7 @@ tail -c 300 gpurun_out/${TAG}_bench_b16.err
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof -o ${TAG} --output-format csv -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --pmc-traffic off > $R/gpurun_out/${TAG}_bench_b16_under_rocprof.json 2> $R/gpurun_out/${TAG}_rocprof.err
 cp $R/gpurun_out/${TAG}_prof/${TAG}_kernel_stats.csv $R/gpurun_out/${TAG}_bench_b16_kernel_stats.csv
+python $R/tools/exp/gaps.py $R/gpurun_out/${TAG}_prof/${TAG}_kernel_trace.csv > $R/gpurun_out/${TAG}_bench_b16_gpu_idle_gaps.txt 2>&1
 cd $R
 timeout 1200 python tools/pmc_collect.py ${TAG}_bench_b16 2>&1 | tail -2
 timeout 600 python tools/kbench.py --n 16 --iters 3 > gpurun_out/${TAG}_kbench_per_layer_n16.txt 2>&1
@@ -20,11 +21,16 @@ timeout 900 python bench.py --amp --steps 20 --warmup 5 --no-cpu-baseline > gpur
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_prof_amp -o ${TAG}amp --output-format csv -- python $R/bench.py --amp --steps 2 --warmup 1 --no-cpu-baseline --pmc-traffic off > /dev/null 2> $R/gpurun_out/${TAG}_rocprof_amp.err
 cp $R/gpurun_out/${TAG}_prof_amp/${TAG}amp_kernel_stats.csv $R/gpurun_out/${TAG}_bench_b16_amp_kernel_stats.csv
+python $R/tools/exp/gaps.py $R/gpurun_out/${TAG}_prof_amp/${TAG}amp_kernel_trace.csv > $R/gpurun_out/${TAG}_bench_b16_amp_gpu_idle_gaps.txt 2>&1
 cd $R
 timeout 600 python tools/kbench_p8.py --n 16 --which conv,dgrad,wgrad,pool --iters 5 > gpurun_out/${TAG}_kbench_p8_per_layer_n16_bf16.txt 2>&1
 timeout 600 python tools/kbench_p8.py --n 48 --which conv,dgrad,wgrad --iters 3 > gpurun_out/${TAG}_kbench_p8_per_layer_n48_bf16.txt 2>&1
 timeout 600 bash tools/exp/p8_pmc.sh conv3_2 conv 48 > gpurun_out/${TAG}_p8_conv3_2_fwd_n48_pmc.txt 2>&1
 timeout 600 bash tools/exp/p8_pmc.sh conv3_2 wgrad 48 > gpurun_out/${TAG}_p8_conv3_2_wgrad_n48_pmc.txt 2>&1
+# ROIAlign at the step's launch shapes / ROI extents, host-boundness of the step
+timeout 300 python tools/exp/roi_bench.py > gpurun_out/${TAG}_roi_align_step_shapes.txt 2>&1
+timeout 600 python tools/exp/host_bound.py > gpurun_out/${TAG}_host_bound_fp32.txt 2>&1
+timeout 600 python tools/exp/host_bound.py --amp > gpurun_out/${TAG}_host_bound_amp.txt 2>&1
 # BASELINE configs[1] at its own batch (8 images = 4 labelled x 2 views)
 timeout 600 python bench.py --student-only --per-gpu-batch 4 --steps 20 --warmup 5 --pmc-traffic off > gpurun_out/${TAG}_bench_config1_student_only_b8.json 2> /dev/null
 # BASELINE configs[3] per-GPU share (8 + 8) on one GPU: the N = 1 point of its weak-scaling curve
