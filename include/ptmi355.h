@@ -270,6 +270,13 @@ int64_t ptmi_segsort_ws_bytes(int64_t total, int nseg);
 int ptmi_segsort_desc(const float* keys_in, float* keys_out, int32_t* idx_out, int64_t total,
                       int nseg, const int32_t* seg_offsets, void* ws, int64_t ws_bytes,
                       ptmi_stream_t s);
+/* The same order from ONE workgroup per segment sorting in LDS (bitonic network on (key, index) pairs): whole segments of up to
+ * 16 384 keys; of longer segments (< 65 536 keys) only the first `topk` <= 16 384 entries of the sorted order (radix select +
+ * ordered compaction first) -- entries past topk come back as (-inf, 0).  max_len = the longest segment (the caller knows it;
+ * no device read).  ptmi_segsort_topk_fits tells whether a (max_len, topk) pair is served; otherwise use ptmi_segsort_desc. */
+int ptmi_segsort_topk_fits(int64_t max_len, int64_t topk);
+int ptmi_segsort_topk_desc(const float* keys_in, float* keys_out, int32_t* idx_out, int nseg, const int32_t* seg_offsets,
+                           int64_t max_len, int64_t topk, ptmi_stream_t s);
 /* proposal_utils.py:92-138 for one batch: for image i and rank j < k:
  *   box = clip(decoded[i][sorted_idx[i][j]], image_size[i]); kept = finite & w>min & h>min;
  *   score = sorted_logit[i][j] * (1 - mean4(sigmoid(sigma_logits[i][j])))   <- row j, NOT idx (:94)

@@ -75,6 +75,8 @@ SIGNATURES = {
     "ptmi_sample_by_keys": (_i, [_vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ptmi_segsort_ws_bytes": (_i64, [_i64, _i]),
     "ptmi_segsort_desc": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
+    "ptmi_segsort_topk_fits": (_i, [_i64, _i64]),
+    "ptmi_segsort_topk_desc": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i64, _vp]),
     "ptmi_rpn_prepare": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _f, _vp]),
     "ptmi_nms_ws_bytes": (_i64, [_i64, _i]),
     "ptmi_nms_batched": (_i, [_vp, _vp, _vp, _i, _i64, _f, _i, _vp, _vp, _vp, _vp]),

@@ -813,8 +813,12 @@ def rpn_subsample_relabel(labels: torch.Tensor, keys: torch.Tensor, num_samples:
 
 
 # ============================================================================ sort / proposals / NMS
-def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Stable descending sort inside each segment.  Returns (sorted keys, index within segment int32)."""
+def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor, max_len: Optional[int] = None,
+                 topk: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable descending sort inside each segment.  Returns (sorted keys, index within segment int32).
+    max_len: the longest segment, if the caller knows it (no device read here) -- segments of up to 16 384 keys are then sorted
+    by the LDS kernel; topk: the caller only reads the first topk entries of every segment (longer segments come back with
+    their first topk entries in order and (-inf, 0) behind them)."""
     keys = _chk(keys.contiguous())
     seg_offsets = _chk(seg_offsets.contiguous(), torch.int32)
     total, nseg = keys.numel(), seg_offsets.numel() - 1
@@ -822,7 +826,13 @@ def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor) -> Tuple[torch.T
     idx = torch.empty(total, dtype=torch.int32, device=keys.device)
     if total == 0:
         return out, idx
-    nbytes = _lib.load().ptmi_segsort_ws_bytes(total, nseg)
+    lib = _lib.load()
+    if max_len is not None and lib.ptmi_segsort_topk_fits(int(max_len), int(topk or 0)):
+        with _prof("segsort_desc"):
+            _lib.call("ptmi_segsort_topk_desc", _ptr(keys), _ptr(out), _ptr(idx), nseg, _ptr(seg_offsets), int(max_len),
+                      int(topk or 0), _stream())
+        return out, idx
+    nbytes = lib.ptmi_segsort_ws_bytes(total, nseg)
     ws = _ws("sort", nbytes, keys.device)
     with _prof("segsort_desc"):
         _lib.call("ptmi_segsort_desc", _ptr(keys), _ptr(out), _ptr(idx), total, nseg, _ptr(seg_offsets), _ptr(ws),

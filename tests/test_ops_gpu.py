@@ -398,6 +398,37 @@ def test_segsort_desc(ops):
         assert torch.equal(si[a:b].cpu().long(), ri)
 
 
+def _special_keys(n, gen):
+    keys = torch.randn(n, generator=gen)
+    if n >= 64:
+        keys[10:20] = keys[10]                 # ties -> stable order
+        keys[3], keys[n - 2] = float("inf"), float("inf")
+        keys[5], keys[n // 2] = float("-inf"), float("-inf")
+        keys[7], keys[n - 5] = 0.0, -0.0       # equal for a comparison sort: index order
+        keys[n // 3] = float("nan")            # first in a descending torch.sort
+        keys[40:60] = torch.floor(keys[40:60] * 2) / 2
+    return keys
+
+
+@pytest.mark.parametrize("sizes,topk", [([12000, 16384, 0, 5, 16000, 1, 127, 129, 128, 2048], None),
+                                        ([37350, 20000, 16385, 300, 0, 16384], 12000), ([37350, 37350], 16384), ([65535], 6000)])
+def test_segsort_lds_kernel(ops, sizes, topk):
+    """the one-workgroup-per-segment LDS sort (bitonic network on (key, index) pairs; radix select + compaction for segments
+    beyond 16 384 keys): whole segments / the first topk entries equal torch's stable descending sort, incl. ties, +-inf, +-0, NaN"""
+    gen = g(sum(sizes) + (topk or 0))
+    keys = torch.cat([_special_keys(n, gen) for n in sizes]) if sum(sizes) else torch.zeros(0)
+    offs = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+    sk, si = ops.segsort_desc(keys.to(DEV), offs.to(DEV), max_len=max(sizes), topk=topk)
+    sk, si = sk.cpu(), si.cpu().long()
+    for a, b in zip(offs[:-1].tolist(), offs[1:].tolist()):
+        rk, ri = torch.sort(keys[a:b], descending=True, stable=True)
+        m = b - a if (b - a <= 16384 or topk is None) else topk
+        assert torch.equal(si[a:a + m], ri[:m]), f"segment of {b - a}: order"
+        assert torch.equal(sk[a:a + m].view(torch.int32), rk[:m].view(torch.int32)), f"segment of {b - a}: keys (bit patterns)"
+        assert bool((sk[a + m:b] == float("-inf")).all()) and bool((si[a + m:b] == 0).all()), "entries past topk"
+    assert torch.equal(ops.segsort_desc(keys.to(DEV), offs.to(DEV), max_len=max(sizes), topk=topk)[1].cpu().long(), si), "repeatable"
+
+
 @pytest.mark.parametrize("counts,thr,max_keep", [([300, 0, 1, 65, 1000], 0.7, 2000), ([12000, 9000], 0.7, 2000),
                                                  ([5000], 0.5, 100)])
 def test_nms_bit_exact(ops, counts, thr, max_keep):
