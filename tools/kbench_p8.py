@@ -68,8 +68,11 @@ def main():
             del dy
         if "wgrad" in which and hasattr(p8, "wgrad") and cin >= 64:
             dy = (torch.randn((cout // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * (0.0 if a.zeros else 0.5)).to(torch.bfloat16)
-            ms = timeit(lambda: p8.wgrad(x, dy, n, cin, cout, h, w), a.iters)
-            print(f"{name:8s} wgrad n={n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+            try:
+                ms = timeit(lambda: p8.wgrad(x, dy, n, cin, cout, h, w), a.iters)
+                print(f"{name:8s} wgrad n={n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}", flush=True)
+            except _lib.PtmiError as e:          # blocks 1-2 at n = 48: beyond the 32-bit offsets (frozen in the step: never launched)
+                print(f"{name:8s} wgrad n={n}   rejected: {str(e).split(': ', 1)[-1]}", flush=True)
             del dy
         if "pool" in which and name in ("conv1_2", "conv2_2", "conv3_2", "conv4_2"):
             xo = (torch.randn((cout // 8, n * (h + 1) + 1, w + 1, 8), device=dev) * 0.5).to(torch.bfloat16)
