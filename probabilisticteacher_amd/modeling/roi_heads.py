@@ -37,11 +37,18 @@ class ROIPooler(nn.Module):
 
     def forward(self, x: List[torch.Tensor], box_lists: List[Boxes]) -> torch.Tensor:
         dev = x[0].device
-        rows = [torch.cat([torch.full((len(b), 1), float(i), device=dev), b.tensor], 1) for i, b in enumerate(box_lists)]
-        rois = torch.cat(rows, 0) if rows else torch.zeros((0, 5), device=dev)
+        counts = [len(b) for b in box_lists]
         offs = [0]
-        for b in box_lists:
-            offs.append(offs[-1] + len(b))
+        for c in counts:
+            offs.append(offs[-1] + c)
+        if not box_lists or offs[-1] == 0:
+            rois = torch.zeros((0, 5), device=dev)
+        else:
+            # the image-index column in one repeat_interleave (a `full` + `cat` pair per image was 2 n tiny launches); only the n
+            # counts travel from the host (a fixed-size pinned staging block: no host allocation in the step)
+            img_col = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.float32, device=dev),
+                                              ops.dev_i32(counts, dev).long(), output_size=offs[-1])
+            rois = torch.cat([img_col.unsqueeze(1), torch.cat([b.tensor for b in box_lists], 0)], 1)
         img_offsets = torch.tensor(offs, dtype=torch.int32, device=dev) if len(box_lists) == x[0].shape[0] else None
         return ops.roi_align(x[0], rois.contiguous(), self.output_size, self.scale, img_offsets)
 
@@ -178,7 +185,8 @@ class GuassianFastRCNNOutputLayers(nn.Module):
                                      seg_counts=img_cnt)
         host = torch.cat([kcnt, img_inv]).cpu().tolist()                  # the one sync
         kc, dropped = host[:n], host[n:]
-        pos = torch.cat([keep[i, :kc[i]].long() + K * roff[i] for i in range(n)], 0) if n else seg[:0].long()
+        keep_g = keep.long() + seg[:-1].long().unsqueeze(1)                # (seg[i] = K * roff[i])
+        pos = torch.cat([keep_g[i, :kc[i]] for i in range(n)], 0) if n else seg[:0].long()
         img_base = torch.repeat_interleave(seg[:-1].long(), ops.dev_i32(kc, dev).long(), output_size=sum(kc))
         dense = img_base + order[pos].long()                              # flat (roi, class) index of every detection
         roi, cls = torch.div(dense, K, rounding_mode="floor"), dense % K
@@ -195,6 +203,7 @@ class GuassianFastRCNNOutputLayers(nn.Module):
         r_logits = scores[row]
         results, kept_rows = [], []
         c0 = 0
+        row_local = row - img_start                                        # ROI index within the image (img_start = roff[i])
         for i, prop in enumerate(proposals):
             k = kc[i]
             res = FreeInstances(prop.image_size)
@@ -204,7 +213,7 @@ class GuassianFastRCNNOutputLayers(nn.Module):
             res.scores_logists = r_logits[c0:c0 + k]
             res.boxes_sigma = r_sig[c0:c0 + k]
             results.append(res)
-            kept_rows.append(row[c0:c0 + k] - roff[i])                    # ROI index within the image
+            kept_rows.append(row_local[c0:c0 + k])
             c0 += k
         return results, kept_rows
 

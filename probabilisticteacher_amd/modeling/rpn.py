@@ -92,12 +92,17 @@ def find_top_rpn_proposals(decoded, logits, sigma_logits, image_sizes, nms_thres
     kc, bad = host[:n], host[n:]
     if any(bad) and training:
         raise FloatingPointError("Predicted boxes or scores contain Inf/NaN. Training has diverged.")
-    results = []
+    # one gather for the whole batch (a per-image loop of cast + add + two index launches was 4 n tiny launches per call, issued
+    # while the GPU had nothing else queued); the per-image results are row ranges of it
+    keep_g = keep.long() + (torch.arange(n, device=dev) * k).unsqueeze(1)
+    sel = torch.cat([keep_g[i, :kc[i]] for i in range(n)]) if n else keep_g.reshape(-1)
+    boxes_all, logits_all = sb[sel], s2[sel]
+    results, c0 = [], 0
     for i, size in enumerate(image_sizes):
-        sel = keep[i, :kc[i]].long() + i * k
         res = FreeInstances(size)
-        res.proposal_boxes = Boxes(sb[sel])
-        res.objectness_logits = s2[sel]
+        res.proposal_boxes = Boxes(boxes_all[c0:c0 + kc[i]])
+        res.objectness_logits = logits_all[c0:c0 + kc[i]]
+        c0 += kc[i]
         results.append(res)
     return results
 
