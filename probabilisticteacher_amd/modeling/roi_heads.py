@@ -49,7 +49,8 @@ class ROIPooler(nn.Module):
             img_col = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.float32, device=dev),
                                               ops.dev_i32(counts, dev).long(), output_size=offs[-1])
             rois = torch.cat([img_col.unsqueeze(1), torch.cat([b.tensor for b in box_lists], 0)], 1)
-        img_offsets = torch.tensor(offs, dtype=torch.int32, device=dev) if len(box_lists) == x[0].shape[0] else None
+        # (ops.dev_i32: pinned + asynchronous -- torch.tensor(list, device=...) copies from pageable memory, which waits for the stream)
+        img_offsets = ops.dev_i32(offs, dev) if len(box_lists) == x[0].shape[0] else None
         return ops.roi_align(x[0], rois.contiguous(), self.output_size, self.scale, img_offsets)
 
 
