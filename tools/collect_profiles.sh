@@ -25,6 +25,7 @@ python $R/tools/exp/gaps.py $R/gpurun_out/${TAG}_prof_amp/${TAG}amp_kernel_trace
 cd $R
 timeout 600 python tools/kbench_p8.py --n 16 --which conv,dgrad,wgrad,pool --iters 5 > gpurun_out/${TAG}_kbench_p8_per_layer_n16_bf16.txt 2>&1
 timeout 600 python tools/kbench_p8.py --n 48 --which conv,dgrad,wgrad --iters 3 > gpurun_out/${TAG}_kbench_p8_per_layer_n48_bf16.txt 2>&1
+timeout 600 python tools/kbench_p8.py --n 16 --which gemm --iters 3 > gpurun_out/${TAG}_kbench_p8_fc1_gemm_bf16.txt 2>&1
 timeout 600 bash tools/exp/p8_pmc.sh conv3_2 conv 48 > gpurun_out/${TAG}_p8_conv3_2_fwd_n48_pmc.txt 2>&1
 timeout 600 bash tools/exp/p8_pmc.sh conv3_2 wgrad 48 > gpurun_out/${TAG}_p8_conv3_2_wgrad_n48_pmc.txt 2>&1
 # ROIAlign at the step's launch shapes / ROI extents, host-boundness of the step
