@@ -200,6 +200,14 @@ int64_t ptmi_roi_align_ws_bytes(int r, int h, int w);
 int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32_t* img_offsets,
                                float* out, void* ws, int n, int c, int h, int w, int r, int pooled,
                                float scale, ptmi_stream_t s);
+/* The grouped forward writing the box head's first Linear layer's bf16 operands directly (SOLVER.AMP.ENABLED; replaces the
+ * ROIPooler -> flatten -> autocast Linear hand-over of roi_heads.py:126-128): xk = "P8 matrix" [c*49/8][r][8] of the flattened
+ * ROI features (what ptmi_p8m_pack(k_major) of the fp32 result would hold, round to nearest even), xt (may be NULL) =
+ * [ceil(r/8)][c*49][8], the weight gradient's operand (contraction over ROIs; rows beyond r are zeros).  pooled = 7 and maps
+ * whose planes fit the LDS budget only: ptmi_roi_align_fwd_p8m_fits. */
+int ptmi_roi_align_fwd_p8m_fits(int c, int h, int w, int pooled);
+int ptmi_roi_align_fwd_p8m(const float* feat, const float* rois, const int32_t* img_offsets, void* xk, void* xt, void* ws,
+                           int n, int c, int h, int w, int r, int pooled, float scale, ptmi_stream_t s);
 /* dfeat must be zeroed by the caller (atomic scatter-add). */
 int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n, int c, int h,
                        int w, int r, int pooled, float scale, ptmi_stream_t s);

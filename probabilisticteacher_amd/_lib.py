@@ -64,6 +64,8 @@ SIGNATURES = {
     "ptmi_roi_align_ws_bytes": (_i64, [_i, _i, _i]),
     "ptmi_roi_align_fwd_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ptmi_roi_align_bwd_ws_bytes": (_i64, [_i, _i, _i]),
+    "ptmi_roi_align_fwd_p8m_fits": (_i, [_i, _i, _i, _i]),
+    "ptmi_roi_align_fwd_p8m": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ptmi_roi_align_bwd_grouped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "ptmi_grid_anchors": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp]),
     "ptmi_apply_deltas": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i64, _f, _f, _f, _f, _f, _vp]),

@@ -171,11 +171,18 @@ __global__ __launch_bounds__(64) void roi_bin_tables_kernel(const float* __restr
 
 constexpr int RF2_THREADS = 1024, RF2_SLOTS = 20, RF2_CG = 4;
 
+// PACK: instead of the fp32 (R, C, 7, 7) tensor the kernel writes the flattened ROI features as the bf16 "P8 matrix" operands of the
+// box head's first Linear layer under SOLVER.AMP.ENABLED (csrc/p8gemm.hip): xk[k / 8][R][8] (k = c * 49 + bin: the forward GEMM's
+// operand) and, if xt != null, xt[r / 8][C * 49][8] (the weight gradient's operand, contraction over ROIs) -- the values a pack of
+// the fp32 tensor would hold (round to nearest even), without the fp32 tensor and the two pack passes over it.
+template <bool PACK>
 __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_bin_kernel(const float* __restrict__ feat,
                                                                         const void* __restrict__ ws,
                                                                         const int32_t* __restrict__ img_off,
                                                                         float* __restrict__ out, int C, int H, int W,
-                                                                        int CG, int TS, const float* __restrict__ rois, float scale)
+                                                                        int CG, int TS, const float* __restrict__ rois, float scale,
+                                                                        unsigned short* __restrict__ xk, unsigned short* __restrict__ xt,
+                                                                        int R)
 {
     extern __shared__ float smem[];
     const int HW = H * W;
@@ -242,11 +249,24 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_bin_kernel(const fl
                 for (int b = 0; b < sx; ++b) cell(wya * wxp[b], ylo + a, xlo + b);
             }
         }
-        float* dst = out + ((size_t)r * C + c0) * 49 + bin;
-        dst[0] = a0;
-        if (cg > 1) dst[49] = a1;
-        if (cg > 2) dst[98] = a2;
-        if (cg > 3) dst[147] = a3;
+        if constexpr (PACK) {
+            const float av[4] = {a0, a1, a2, a3};
+            const size_t KD = (size_t)C * 49;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c >= cg) break;
+                const size_t k = (size_t)(c0 + c) * 49 + bin;
+                const unsigned short b = __builtin_bit_cast(unsigned short, (__bf16)av[c]);      // round to nearest even, as the pack kernels
+                xk[((k >> 3) * (size_t)R + r) * 8 + (k & 7)] = b;
+                if (xt) xt[((size_t)(r >> 3) * KD + k) * 8 + (r & 7)] = b;
+            }
+        } else {
+            float* dst = out + ((size_t)r * C + c0) * 49 + bin;
+            dst[0] = a0;
+            if (cg > 1) dst[49] = a1;
+            if (cg > 2) dst[98] = a2;
+            if (cg > 3) dst[147] = a3;
+        }
     }
 }
 
@@ -455,6 +475,43 @@ __global__ __launch_bounds__(64 * RB3_WAVES, RB3_WAVES == 6 ? 3 : 4) void roi_al
     }
 }
 
+static int roi_tab_stride(int h, int w)
+{
+    // a bin's samples touch at most g + 1 cells, g = ceil(roi extent / 7) <= ceil((dim + 1) / 7) (+ 1 slack), rounded up to 16 bytes
+    const int gmax = ((h > w ? h : w) + 1 + 6) / 7 + 1;
+    return (gmax + 1 + 3) & ~3;
+}
+
+static int roi_fwd_planes(int c, int h, int w, int pooled)
+{
+    const size_t plane_bytes = (size_t)h * w * sizeof(float);
+    const size_t budget = 72 * 1024;                         // two workgroups per CU
+    if (pooled != 7 || plane_bytes > budget) return 0;
+    int cg = (int)(budget / plane_bytes);
+    if (cg > RF2_CG) cg = RF2_CG;
+    if (cg > c) cg = c;
+    return cg;
+}
+
+template <bool PACK>
+static int roi_fwd_grouped_launch(const float* feat, const float* rois, const int32_t* img_offsets, float* out, void* ws, int n, int c,
+                                  int h, int w, int r, float scale, unsigned short* xk, unsigned short* xt, hipStream_t st)
+{
+    const int cg = roi_fwd_planes(c, h, w, 7);
+    const int TS = roi_tab_stride(h, w);
+    hipLaunchKernelGGL(roi_bin_tables_kernel, dim3(r), dim3(64), (size_t)14 * TS * sizeof(float), st, rois, ws, h, w, scale, TS);
+    PTMI_LAUNCH_CHECK("roi_align_tables");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)roi_align_fwd_bin_kernel<PACK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(roi_align_fwd_bin_kernel<PACK>, dim3(cdiv(c, cg), n), dim3(RF2_THREADS), (size_t)cg * h * w * sizeof(float), st,
+                       feat, ws, img_offsets, out, c, h, w, cg, TS, rois, scale, xk, xt, r);
+    PTMI_LAUNCH_CHECK("roi_align_fwd_grouped");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -483,13 +540,6 @@ int ptmi_roi_align_bwd(const float* dout, const float* rois, float* dfeat, int n
     return 0;
 }
 
-static int roi_tab_stride(int h, int w)
-{
-    // a bin's samples touch at most g + 1 cells, g = ceil(roi extent / 7) <= ceil((dim + 1) / 7) (+ 1 slack), rounded up to 16 bytes
-    const int gmax = ((h > w ? h : w) + 1 + 6) / 7 + 1;
-    return (gmax + 1 + 3) & ~3;
-}
-
 int64_t ptmi_roi_align_ws_bytes(int r, int h, int w)
 {
     return (int64_t)(r > 0 ? r : 1) * (int64_t)(sizeof(RoiBinHeader) + 14 * (size_t)roi_tab_stride(h, w) * sizeof(float));
@@ -501,27 +551,28 @@ int ptmi_roi_align_fwd_grouped(const float* feat, const float* rois, const int32
     if (r == 0) return 0;
     PTMI_CHECK_ARG(feat && rois && img_offsets && out && n > 0 && c > 0 && h > 0 && w > 0 && r > 0 && pooled > 0,
                    "roi_align_fwd_grouped: bad args");
-    const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    const size_t budget = 72 * 1024;                         // two workgroups per CU
-    if (pooled != 7 || plane_bytes > budget || !ws)
+    if (!roi_fwd_planes(c, h, w, pooled) || !ws)
         return ptmi_roi_align_fwd(feat, rois, out, n, c, h, w, r, pooled, scale, s);
-    int cg = (int)(budget / plane_bytes);
-    if (cg > RF2_CG) cg = RF2_CG;
-    if (cg > c) cg = c;
-    const int TS = roi_tab_stride(h, w);
+    return roi_fwd_grouped_launch<false>(feat, rois, img_offsets, out, ws, n, c, h, w, r, scale, nullptr, nullptr, (hipStream_t)s);
+}
+
+int ptmi_roi_align_fwd_p8m_fits(int c, int h, int w, int pooled) { return roi_fwd_planes(c, h, w, pooled) > 0 && (c * pooled * pooled) % 8 == 0; }
+
+int ptmi_roi_align_fwd_p8m(const float* feat, const float* rois, const int32_t* img_offsets, void* xk, void* xt, void* ws, int n,
+                           int c, int h, int w, int r, int pooled, float scale, ptmi_stream_t s)
+{
+    if (r == 0) return 0;
+    PTMI_CHECK_ARG(feat && rois && img_offsets && xk && ws && n > 0 && c > 0 && h > 0 && w > 0 && r > 0, "roi_align_fwd_p8m: bad args");
+    PTMI_CHECK_ARG(ptmi_roi_align_fwd_p8m_fits(c, h, w, pooled), "roi_align_fwd_p8m: shape (c=%d h=%d w=%d pooled=%d) is not served",
+                   c, h, w, pooled);
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(roi_bin_tables_kernel, dim3(r), dim3(64), (size_t)14 * TS * sizeof(float), st, rois, ws, h, w, scale, TS);
-    PTMI_LAUNCH_CHECK("roi_align_tables");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)roi_align_fwd_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
+    if (xt && (r & 7)) {                 // the last row octet is partly beyond R: zeros there (the GEMM contracts over whole octets)
+        const size_t slab = (size_t)c * 49 * 16;
+        hipError_t e = hipMemsetAsync((char*)xt + (size_t)(r >> 3) * slab, 0, slab, st);
+        if (e != hipSuccess) { ptmi_set_error("roi_align_fwd_p8m: memset failed"); return -2; }
     }
-    hipLaunchKernelGGL(roi_align_fwd_bin_kernel, dim3(cdiv(c, cg), n), dim3(RF2_THREADS), (size_t)cg * plane_bytes, st,
-                       feat, ws, img_offsets, out, c, h, w, cg, TS, rois, scale);
-    PTMI_LAUNCH_CHECK("roi_align_fwd_grouped");
-    return 0;
+    return roi_fwd_grouped_launch<true>(feat, rois, img_offsets, nullptr, ws, n, c, h, w, r, scale, (unsigned short*)xk,
+                                        (unsigned short*)xt, st);
 }
 
 int64_t ptmi_roi_align_bwd_ws_bytes(int r, int h, int w)

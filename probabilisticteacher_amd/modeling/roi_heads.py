@@ -51,7 +51,22 @@ class ROIPooler(nn.Module):
             rois = torch.cat([img_col.unsqueeze(1), torch.cat([b.tensor for b in box_lists], 0)], 1)
         # (ops.dev_i32: pinned + asynchronous -- torch.tensor(list, device=...) copies from pageable memory, which waits for the stream)
         img_offsets = ops.dev_i32(offs, dev) if len(box_lists) == x[0].shape[0] else None
+        if (img_offsets is not None and offs[-1] > 0 and ops._native_bf16() and x[0].is_cuda
+                and ops.roi_align_p8m_fits(x[0].shape[1], x[0].shape[2], x[0].shape[3], self.output_size)):
+            # SOLVER.AMP.ENABLED: the pooling is deferred to its consumer -- the box head's first Linear layer takes its bf16
+            # operands straight from the ROIAlign kernel (p8._RoiAlignLinearP8)
+            return DeferredROIAlign(x[0], rois.contiguous(), img_offsets, self.output_size, self.scale)
         return ops.roi_align(x[0], rois.contiguous(), self.output_size, self.scale, img_offsets)
+
+
+class DeferredROIAlign:
+    """What ROIPooler hands to the box head in the bf16-storage mode: the ROIAlign call, not yet made."""
+
+    def __init__(self, feat, rois, img_offsets, output_size, scale):
+        self.feat, self.rois, self.img_offsets, self.output_size, self.scale = feat, rois, img_offsets, output_size, scale
+
+    def materialize(self) -> torch.Tensor:
+        return ops.roi_align(self.feat, self.rois, self.output_size, self.scale, self.img_offsets)
 
 
 @ROI_BOX_HEAD_REGISTRY.register()
@@ -72,8 +87,17 @@ class FastRCNNConvFCHead(nn.Module):
         self.output_size = dim
 
     def forward(self, x):
-        x = x.flatten(1)
-        for k in range(self.num_fc):
+        first = 0
+        if isinstance(x, DeferredROIAlign):
+            from .. import p8
+            if self.num_fc and self.fc1.weight.shape[1] >= p8.LINEAR_MIN_K:
+                x = p8.roi_align_linear(x.feat, x.rois, x.img_offsets, x.output_size, x.scale, self.fc1.weight, self.fc1.bias, True)
+                first = 1
+            else:
+                x = x.materialize()
+        if first == 0:
+            x = x.flatten(1)
+        for k in range(first, self.num_fc):
             fc = getattr(self, f"fc{k + 1}")
             x = ops.linear(x, fc.weight, fc.bias, True)
         return x

@@ -651,18 +651,46 @@ class _ROIAlign(torch.autograd.Function):
         dout = _chk(dout.contiguous())
         if img_offsets is not None:
             # rois grouped by image: LDS-accumulating kernel, no global atomics, writes every element of dfeat
-            dfeat = torch.empty((n, c, h, w), dtype=F32, device=dout.device)
-            with _prof("roi_align_bwd"):
-                ws = torch.empty(_lib.load().ptmi_roi_align_bwd_ws_bytes(rois.shape[0], h, w), dtype=torch.uint8,
-                                 device=dout.device)
-                _lib.call("ptmi_roi_align_bwd_grouped", _ptr(dout), _ptr(rois), _ptr(_chk(img_offsets, torch.int32)),
-                          _ptr(dfeat), _ptr(ws), n, c, h, w, rois.shape[0], pooled, scale, _stream())
+            dfeat = roi_align_bwd_grouped(dout, rois, img_offsets, n, c, h, w, pooled, scale)
         else:
             dfeat = torch.zeros((n, c, h, w), dtype=F32, device=dout.device)
             with _prof("roi_align_bwd"):
                 _lib.call("ptmi_roi_align_bwd", _ptr(dout), _ptr(rois), _ptr(dfeat), n, c, h, w, rois.shape[0], pooled,
                           scale, _stream())
         return dfeat, None, None, None, None
+
+
+def roi_align_bwd_grouped(dout: torch.Tensor, rois: torch.Tensor, img_offsets: torch.Tensor, n: int, c: int, h: int, w: int,
+                          pooled: int, scale: float) -> torch.Tensor:
+    """d(feature map) (n, c, h, w) from the gradient of ROIAlign's output (R, c * pooled * pooled) for rois grouped by image"""
+    dout = _chk(dout.contiguous())
+    dfeat = torch.empty((n, c, h, w), dtype=F32, device=dout.device)
+    with _prof("roi_align_bwd"):
+        ws = torch.empty(_lib.load().ptmi_roi_align_bwd_ws_bytes(rois.shape[0], h, w), dtype=torch.uint8, device=dout.device)
+        _lib.call("ptmi_roi_align_bwd_grouped", _ptr(dout), _ptr(rois), _ptr(_chk(img_offsets, torch.int32)), _ptr(dfeat), _ptr(ws),
+                  n, c, h, w, rois.shape[0], pooled, scale, _stream())
+    return dfeat
+
+
+def roi_align_p8m_fits(c: int, h: int, w: int, pooled: int) -> bool:
+    return bool(_lib.load().ptmi_roi_align_fwd_p8m_fits(int(c), int(h), int(w), int(pooled)))
+
+
+def roi_align_p8m(feat: torch.Tensor, rois: torch.Tensor, img_offsets: torch.Tensor, pooled: int, scale: float, need_xt: bool):
+    """ROIAlign (rois grouped by image) straight into the bf16 "P8 matrix" operands of the box head's first Linear layer:
+    xk (c * pooled^2 / 8, R, 8) and, if need_xt, xt (ceil(R / 8), c * pooled^2, 8)  (ptmi_roi_align_fwd_p8m)"""
+    feat = _chk(feat.contiguous())
+    rois = _chk(rois.contiguous())
+    n, c, h, w = feat.shape
+    r, kd = rois.shape[0], c * pooled * pooled
+    xk = torch.empty((kd // 8, r, 8), dtype=torch.bfloat16, device=feat.device)
+    xt = torch.empty((-(-r // 8), kd, 8), dtype=torch.bfloat16, device=feat.device) if need_xt else None
+    if r:
+        with _prof("roi_align_fwd"):
+            ws = torch.empty(_lib.load().ptmi_roi_align_ws_bytes(r, h, w), dtype=torch.uint8, device=feat.device)
+            _lib.call("ptmi_roi_align_fwd_p8m", _ptr(feat), _ptr(rois), _ptr(_chk(img_offsets, torch.int32)), _ptr(xk), _ptr(xt), _ptr(ws),
+                      n, c, h, w, r, pooled, float(scale), _stream())
+    return xk, xt
 
 
 def roi_align(feat, rois, pooled: int, scale: float, img_offsets=None):

@@ -300,6 +300,44 @@ class _LinearP8(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _RoiAlignLinearP8(torch.autograd.Function):
+    """ROIPooler -> flatten -> Linear (+ ReLU) of the box head (roi_heads.py:126-128 -> FastRCNNConvFCHead.fc1) as ONE node under
+    SOLVER.AMP.ENABLED: the ROIAlign kernel writes the Linear layer's bf16 operands itself (no fp32 ROI-feature tensor, no pack passes
+    over it); backward = _LinearP8's three GEMMs, then the grouped ROIAlign backward on dX."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, img_offsets, pooled: int, scale: float, weight, bias, relu: bool):
+        weight, bias = ops._chk(weight.contiguous()), ops._chk(bias.contiguous())
+        n_img, c, h, w = feat.shape
+        r, k, n = rois.shape[0], c * pooled * pooled, weight.shape[0]
+        need_w = ctx.needs_input_grad[5]
+        xk, xt = ops.roi_align_p8m(feat, rois, img_offsets, pooled, scale, need_w)
+        y = gemm_nt(xk, pack_matrix(weight, n, k, k, True), r, n, k, bias, relu)
+        ctx.meta = (r, k, n, relu, (n_img, c, h, w), pooled, float(scale))
+        ctx.save_for_backward(xt, weight, y if relu else None, rois, img_offsets)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xt, weight, y, rois, img_offsets = ctx.saved_tensors
+        r, k, n, relu, (n_img, c, h, w), pooled, scale = ctx.meta
+        dy = ops._chk(dy.contiguous())
+        dz = ops.relu_bwd(dy, y) if relu else dy
+        dfeat = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm_nt(pack_matrix(dz, r, n, n, True), pack_matrix(weight, k, n, k, False), r, k, n, swapped=True)
+            dfeat = ops.roi_align_bwd_grouped(dx, rois, img_offsets, n_img, c, h, w, pooled, scale)
+        if ctx.needs_input_grad[5]:
+            dw = gemm_nt(pack_matrix(dz, n, r, n, False), xt, n, k, r)
+        if ctx.needs_input_grad[6]:
+            db = ops.colsum(dz.to(BF16).to(F32))
+        return dfeat, None, None, None, None, dw, db, None
+
+
+def roi_align_linear(feat, rois, img_offsets, pooled: int, scale: float, weight, bias, relu: bool) -> torch.Tensor:
+    return _RoiAlignLinearP8.apply(feat, rois, img_offsets, pooled, scale, weight, bias, relu)
+
+
 LINEAR_MIN_K = 4096        # below this (fc2, the predictors) the operand packs cost what the GEMM saves: ptmi_gemm_bf16 keeps those
 
 

@@ -315,3 +315,41 @@ def test_p8_conv3_2_at_n48_bench_launch_shape_vs_torch():
     s, sb = float(wr.grad.abs().max()), float(br.grad.abs().max())
     assert float((dw.cpu() - wr.grad).abs().max()) <= 1e-4 * s, "conv3_2 wgrad n=48"
     assert float((db.cpu() - br.grad).abs().max()) <= 1e-4 * sb, "conv3_2 bias grad n=48"
+
+
+@pytest.mark.parametrize("n,c,h,w,per", [(2, 16, 25, 31, 19), (3, 64, 50, 83, 171), (1, 8, 12, 9, 8)])
+def test_roi_align_writing_the_linear_layers_bf16_operands_equals_pool_then_pack(n, c, h, w, per):
+    """SOLVER.AMP.ENABLED box head: ROIAlign -> flatten -> Linear + ReLU as one node whose ROIAlign kernel writes the GEMM's bf16
+    operands (xk, and xt for the weight gradient) itself == the fp32 ROIAlign followed by p8.linear's operand packs: the same bf16
+    values, hence y, dW, db and the feature-map gradient bit for bit (ROI counts that are not multiples of 8: the zero tail of xt)"""
+    from probabilisticteacher_amd import ops, p8
+    gen = g(n * 1000 + c)
+    feat = torch.randn(n, c, h, w, generator=gen)
+    r = n * per
+    ctr = torch.rand(r, 2, generator=gen) * torch.tensor([w * 16.0, h * 16.0])
+    wh = 24 + torch.rand(r, 2, generator=gen) * 200
+    img = torch.arange(n).repeat_interleave(per).float()
+    rois = torch.cat([img[:, None], ctr - wh / 2, ctr + wh / 2], 1).to(DEV)
+    offs = torch.arange(0, (n + 1) * per, per, dtype=torch.int32, device=DEV)
+    k, nout = c * 49, 40
+    wt = (torch.randn(nout, k, generator=gen) * 0.05).to(DEV)
+    b = (torch.randn(nout, generator=gen) * 0.1).to(DEV)
+    gy = torch.randn(r, nout, generator=gen).to(DEV)
+    assert ops.roi_align_p8m_fits(c, h, w, 7)
+    # the operands themselves
+    xk, xt = ops.roi_align_p8m(feat.to(DEV), rois, offs, 7, 1 / 16, True)
+    x32 = ops.roi_align(feat.to(DEV), rois, 7, 1 / 16, offs).flatten(1)
+    assert torch.equal(xk.view(torch.int16), p8.pack_matrix(x32, r, k, k, True).view(torch.int16)), "xk"
+    assert torch.equal(xt.view(torch.int16), p8.pack_matrix(x32, k, r, k, False).view(torch.int16)), "xt (incl. its zero tail)"
+    res = []
+    for fused in (True, False):
+        f = feat.to(DEV).requires_grad_()
+        w_, b_ = wt.clone().requires_grad_(), b.clone().requires_grad_()
+        if fused:
+            y = p8.roi_align_linear(f, rois, offs, 7, 1 / 16, w_, b_, True)
+        else:
+            y = p8.linear(ops.roi_align(f, rois, 7, 1 / 16, offs).flatten(1), w_, b_, True)
+        y.backward(gy)
+        res.append((y.detach(), f.grad, w_.grad, b_.grad))
+    for a, bb, what in zip(res[0], res[1], ("y", "d feature map", "dW", "db")):
+        assert torch.equal(a, bb), what
