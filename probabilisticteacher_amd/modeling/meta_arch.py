@@ -71,6 +71,7 @@ class GuassianGeneralizedRCNN(nn.Module):
         features = self.backbone(images.tensor)
         feats = [features[f] for f in self.proposal_generator.in_features]
         obj, deltas = self.proposal_generator.head_outputs(feats)
+        all_props = self.proposal_generator.proposals_from_head(images, features, (obj, deltas))
         out = []
         for sl, inputs, branch, da in ((slice(0, ns), sup_inputs, "supervised", False),
                                        (slice(ns, None), unsup_inputs, "unsupervised", danchor)):
@@ -79,7 +80,7 @@ class GuassianGeneralizedRCNN(nn.Module):
             head = ([o[sl] for o in obj], [d[sl] for d in deltas])
             gt = [x["instances"].to(self.device) for x in inputs]
             proposals, l_rpn = self.proposal_generator(img, feat, gt, branch=branch if branch == "unsupervised" else "",
-                                                       danchor=da, head_out=head)
+                                                       danchor=da, head_out=head, proposals=all_props[sl])
             _, l_det = self.roi_heads(img, feat, proposals, gt, branch=branch)
             losses = {}
             losses.update(l_det)

@@ -136,23 +136,35 @@ class GuassianRPN(nn.Module):
         return flat(feats) if flat is not None else self.rpn_head(feats)
 
     # ------------------------------------------------------------------ forward (rpn.py:80-154)
+    @staticmethod
+    def _flat_outputs(obj, deltas):
+        if obj[0].dim() == 2:               # already (N, H*W*A) and (N, H*W*A, 8): GuassianRPNHead.forward_flat
+            return obj[0], deltas[0]
+        n, a, h, w = obj[0].shape
+        # (N,A,H,W) -> (N,H*W*A);  (N,A*8,H,W) -> (N,H*W*A,8)   (rpn.py:97-113)
+        return (obj[0].permute(0, 2, 3, 1).reshape(n, -1),
+                deltas[0].view(n, a, 8, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 8))
+
+    def proposals_from_head(self, images, features, head_out):
+        """the proposals of a whole batch from head outputs already computed (the joint student pass: ONE sort / NMS chain and ONE
+        host read for its two branches; per image exactly what `forward` returns)"""
+        feats = [features[f] for f in self.in_features]
+        anchors = self.anchor_generator(feats)[0].tensor.detach()
+        logits, d8 = self._flat_outputs(*head_out)
+        return self.predict_proposals(anchors, logits, d8, images.image_sizes)
+
     def forward(self, images, features, gt_instances: Optional[List[FreeInstances]] = None, compute_loss=True,
-                branch="", danchor=False, head_out=None):
+                branch="", danchor=False, head_out=None, proposals=None):
         """`head_out` = (objectness, deltas) already computed by `self.rpn_head` on these features (the joint
-        student pass runs the head once for both branches)."""
+        student pass runs the head once for both branches); `proposals` = this batch's proposals if they were already predicted
+        (`proposals_from_head`)."""
         feats = [features[f] for f in self.in_features]
         assert len(feats) == 1, "single-level RPN (vgg_block5)"
         anchors = self.anchor_generator(feats)[0].tensor
         if not danchor:
             anchors = anchors.detach()      # grad_zero (rpn.py:91-94): the anchor table gets an all-zero gradient
         obj, deltas = head_out if head_out is not None else self.head_outputs(feats)
-        if obj[0].dim() == 2:               # already (N, H*W*A) and (N, H*W*A, 8): GuassianRPNHead.forward_flat
-            logits, d8 = obj[0], deltas[0]
-        else:
-            n, a, h, w = obj[0].shape
-            # (N,A,H,W) -> (N,H*W*A);  (N,A*8,H,W) -> (N,H*W*A,8)   (rpn.py:97-113)
-            logits = obj[0].permute(0, 2, 3, 1).reshape(n, -1)
-            d8 = deltas[0].view(n, a, 8, h, w).permute(0, 3, 4, 1, 2).reshape(n, -1, 8)
+        logits, d8 = self._flat_outputs(obj, deltas)
 
         if branch == "unsupervised":
             losses = self._losses_unsup(anchors, logits, d8, gt_instances)
@@ -163,7 +175,8 @@ class GuassianRPN(nn.Module):
             losses = {k: v * self.loss_weight.get(k, 1.0) * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
         else:
             losses = {}
-        proposals = self.predict_proposals(anchors, logits, d8, images.image_sizes)
+        if proposals is None:
+            proposals = self.predict_proposals(anchors, logits, d8, images.image_sizes)
         return proposals, losses
 
     @torch.no_grad()

@@ -359,25 +359,33 @@ class _ProposalLog:
         self.hip, self.ref, self.calls, self.hip_in, self.ref_in, self.ocfg = [], [], [], [], [], ocfg
         f_hip, f_ref = hip_rpn.find_top_rpn_proposals, opt.find_top_rpn_proposals
 
+        # records are kept PER IMAGE: the two sides may group the same images into different calls of the stage (the HIP joint
+        # student pass predicts the proposals of both branches in one call, the oracle one call per branch)
         def w_hip(decoded, logits, sigma_logits, image_sizes, nms_thresh, pre_nms_topk, post_nms_topk, min_box_size, training):
             out = f_hip(decoded, logits, sigma_logits, image_sizes, nms_thresh, pre_nms_topk, post_nms_topk, min_box_size,
                         training)
-            self.calls.append([(o.proposal_boxes.tensor.cpu(), o.objectness_logits.cpu(), o.image_size) for o in out])
-            self.hip += [c[0] for c in self.calls[-1]]
-            self.hip_in.append((decoded.detach().cpu().clone(), logits.detach().cpu().clone(), sigma_logits.detach().cpu().clone(),
-                                list(image_sizes), pre_nms_topk, post_nms_topk, training, [c[:2] for c in self.calls[-1]]))
+            n = len(out)
+            dec, lg, sg = decoded.detach().cpu().view(n, -1, 4), logits.detach().cpu().view(n, -1), sigma_logits.detach().cpu().view(n, -1, 4)
+            for i, o in enumerate(out):
+                rec = (o.proposal_boxes.tensor.cpu(), o.objectness_logits.cpu(), o.image_size)
+                self.calls.append(rec)
+                self.hip.append(rec[0])
+                self.hip_in.append((dec[i].clone(), lg[i].clone(), sg[i].clone(), image_sizes[i], pre_nms_topk, post_nms_topk, training,
+                                    rec[:2]))
             return out
 
         def w_ref(cfg, proposals, logits, image_sizes, sigma_logits, pre_nms_topk, post_nms_topk, training):
             own = f_ref(cfg, proposals, logits, image_sizes, sigma_logits, pre_nms_topk, post_nms_topk, training)
+            n = len(own)
             self.ref += [o.proposal_boxes.tensor.clone() for o in own]
-            self.ref_in.append((proposals.detach().clone(), logits.detach().clone(), sigma_logits.detach().clone()))
-            rec = self.calls.pop(0)
-            assert len(rec) == len(own), "the two sides call the proposal stage in the same order"
+            pr, lg, sg = proposals.detach().view(n, -1, 4), logits.detach().view(n, -1), sigma_logits.detach().view(n, -1, 4)
+            self.ref_in += [(pr[i].clone(), lg[i].clone(), sg[i].clone()) for i in range(n)]
+            assert len(self.calls) >= n, "the two sides send the images through the proposal stage in the same order"
             out = []
-            for boxes, lg, size in rec:
+            for _ in range(n):
+                boxes, lgt, size = self.calls.pop(0)
                 r = opt.FreeInstances(size)
-                r.proposal_boxes, r.objectness_logits = d2.Boxes(boxes.clone()), lg.clone()
+                r.proposal_boxes, r.objectness_logits = d2.Boxes(boxes.clone()), lgt.clone()
                 out.append(r)
             return out
         self._f_ref = f_ref
@@ -385,31 +393,29 @@ class _ProposalLog:
         monkeypatch.setattr(opt, "find_top_rpn_proposals", w_ref)
 
     def check(self, ocfg=None):
-        """(i) + (ii) of the class comment for every call and image; returns a one-line report"""
+        """(i) + (ii) of the class comment for every image that went through the stage; returns a one-line report"""
         ocfg = ocfg or self.ocfg
         assert len(self.hip) == len(self.ref) and not self.calls and len(self.hip_in) == len(self.ref_in)
-        out, k = [], 0
-        for (dec, lg, sg, sizes, pre, post, training, hip_out), (odec, olg, osg) in zip(self.hip_in, self.ref_in):
-            for name, a, b in (("logits", lg, olg), ("decoded boxes", dec.view_as(odec), odec), ("sigma logits", sg.view_as(osg), osg)):
+        out = []
+        for k, ((dec, lg, sg, size, pre, post, training, (hb, hs)), (odec, olg, osg)) in enumerate(zip(self.hip_in, self.ref_in)):
+            for name, a, b in (("logits", lg, olg), ("decoded boxes", dec, odec), ("sigma logits", sg, osg)):
                 err = (a.double() - b.double()).abs()
                 tol = 1e-4 * b.double().abs() + 1e-5 * float(b.abs().max())
                 assert bool((err <= tol).all()), (f"proposal-stage input {name}: {int((err > tol).sum())} of {err.numel()} elements "
                                                   f"beyond 1e-4 |b| + 1e-5 max|b| (worst {float(err.max()):.3e})")
-            replay = self._f_ref(ocfg, dec.view_as(odec), lg, sizes, sg.view_as(osg), pre, post, training)
-            for (hb, hs), r in zip(hip_out, replay):
-                rb, rs = r.proposal_boxes.tensor, r.objectness_logits
-                assert len(hb) == len(rb), f"proposal count {len(hb)} vs the oracle's stage on the same inputs {len(rb)}"
-                assert torch.equal(hb, rb), ("HIP proposals differ from the oracle's find_top_rpn_proposals run on the SAME inputs: "
-                                             f"first row {int(((hb != rb).any(dim=1)).nonzero()[0])} of {len(rb)}")
-                close(hs, rs, 1e-5, 1e-6, "proposal scores on identical inputs")
-                a, b = self.hip[k], self.ref[k]
-                k += 1
-                za, zb = np.zeros(len(a), np.int64), np.zeros(len(b), np.int64)
-                frac, _ = match_detections(a, za, b, zb, box_tol=5e-3)
-                n = min(len(a), len(b))
-                rows = ((a[:n] - b[:n]).abs() <= 1e-2).all(dim=1)
-                out.append(f"{len(a)}/{len(b)} boxes (exact vs the oracle stage on HIP inputs), {frac:.4f} in common with the "
-                           f"oracle's own, first differing row {int((~rows).nonzero()[0]) if not bool(rows.all()) else -1}")
+            r = self._f_ref(ocfg, dec.unsqueeze(0), lg.unsqueeze(0), [size], sg.unsqueeze(0), pre, post, training)[0]
+            rb, rs = r.proposal_boxes.tensor, r.objectness_logits
+            assert len(hb) == len(rb), f"proposal count {len(hb)} vs the oracle's stage on the same inputs {len(rb)}"
+            assert torch.equal(hb, rb), ("HIP proposals differ from the oracle's find_top_rpn_proposals run on the SAME inputs: "
+                                         f"first row {int(((hb != rb).any(dim=1)).nonzero()[0])} of {len(rb)}")
+            close(hs, rs, 1e-5, 1e-6, "proposal scores on identical inputs")
+            a, b = self.hip[k], self.ref[k]
+            za, zb = np.zeros(len(a), np.int64), np.zeros(len(b), np.int64)
+            frac, _ = match_detections(a, za, b, zb, box_tol=5e-3)
+            n = min(len(a), len(b))
+            rows = ((a[:n] - b[:n]).abs() <= 1e-2).all(dim=1)
+            out.append(f"{len(a)}/{len(b)} boxes (exact vs the oracle stage on HIP inputs), {frac:.4f} in common with the "
+                       f"oracle's own, first differing row {int((~rows).nonzero()[0]) if not bool(rows.all()) else -1}")
         return "; ".join(out)
 
     check_sets = check
