@@ -170,12 +170,15 @@ __global__ __launch_bounds__(64) void roi_bin_tables_kernel(const float* __restr
 }
 
 constexpr int RF2_THREADS = 1024, RF2_SLOTS = 20, RF2_CG = 4;
+#ifndef RF2_CG8
+#define RF2_CG8 8
+#endif
 
 // PACK: instead of the fp32 (R, C, 7, 7) tensor the kernel writes the flattened ROI features as the bf16 "P8 matrix" operands of the
 // box head's first Linear layer under SOLVER.AMP.ENABLED (csrc/p8gemm.hip): xk[k / 8][R][8] (k = c * 49 + bin: the forward GEMM's
 // operand) and, if xt != null, xt[r / 8][C * 49][8] (the weight gradient's operand, contraction over ROIs) -- the values a pack of
 // the fp32 tensor would hold (round to nearest even), without the fp32 tensor and the two pack passes over it.
-template <bool PACK>
+template <bool PACK, int NCH>
 __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_bin_kernel(const float* __restrict__ feat,
                                                                         const void* __restrict__ ws,
                                                                         const int32_t* __restrict__ img_off,
@@ -199,20 +202,22 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_bin_kernel(const fl
     const size_t rstride = sizeof(RoiBinHeader) + 14 * (size_t)TS * sizeof(float);
     const int r1 = img_off[n + 1];
     // planes past the workgroup's last channel alias plane 0 (their sums are not stored)
-    const int o1 = cg > 1 ? HW : 0, o2 = cg > 2 ? 2 * HW : 0, o3 = cg > 3 ? 3 * HW : 0;
+    int po[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) po[c] = c < cg ? c * HW : 0;
     for (int r = img_off[n] + slot; r < r1; r += RF2_SLOTS) {
         const char* base = (const char*)ws + (size_t)r * rstride;
         const RoiBinHeader* hd = reinterpret_cast<const RoiBinHeader*>(base);
         const int sy = hd->sy, sx = hd->sx, ylo = hd->ylo[ph], xlo = hd->xlo[pw];
         const float* wyp = reinterpret_cast<const float*>(base + sizeof(RoiBinHeader)) + ph * TS;
         const float* wxp = reinterpret_cast<const float*>(base + sizeof(RoiBinHeader)) + (7 + pw) * TS;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float acc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = 0.f;
         auto cell = [&](float w, int y, int x) {
             const float* f = plane + min(y, H - 1) * W + min(x, W - 1);      // (cells past the map carry zero weights)
-            a0 = __builtin_fmaf(w, f[0], a0);
-            a1 = __builtin_fmaf(w, f[o1], a1);
-            a2 = __builtin_fmaf(w, f[o2], a2);
-            a3 = __builtin_fmaf(w, f[o3], a3);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[c] = __builtin_fmaf(w, f[po[c]], acc[c]);
         };
         if (sy < 0) {
             // no table (see roi_bin_tables_kernel): the torchvision loop over the bin's samples
@@ -250,22 +255,20 @@ __global__ __launch_bounds__(RF2_THREADS) void roi_align_fwd_bin_kernel(const fl
             }
         }
         if constexpr (PACK) {
-            const float av[4] = {a0, a1, a2, a3};
             const size_t KD = (size_t)C * 49;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NCH; ++c) {
                 if (c >= cg) break;
                 const size_t k = (size_t)(c0 + c) * 49 + bin;
-                const unsigned short b = __builtin_bit_cast(unsigned short, (__bf16)av[c]);      // round to nearest even, as the pack kernels
+                const unsigned short b = __builtin_bit_cast(unsigned short, (__bf16)acc[c]);      // round to nearest even, as the pack kernels
                 xk[((k >> 3) * (size_t)R + r) * 8 + (k & 7)] = b;
                 if (xt) xt[((size_t)(r >> 3) * KD + k) * 8 + (r & 7)] = b;
             }
         } else {
             float* dst = out + ((size_t)r * C + c0) * 49 + bin;
-            dst[0] = a0;
-            if (cg > 1) dst[49] = a1;
-            if (cg > 2) dst[98] = a2;
-            if (cg > 3) dst[147] = a3;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+                if (c < cg) dst[c * 49] = acc[c];
         }
     }
 }
@@ -482,12 +485,14 @@ static int roi_tab_stride(int h, int w)
     return (gmax + 1 + 3) & ~3;
 }
 
+// channel planes per workgroup: 8 in 150 KB of LDS where they fit (one workgroup of 16 waves per CU: a thread's table loads --
+// the kernel's largest cost, 2.7 KB per ROI and workgroup -- serve eight outputs), else up to 4 in 72 KB (two workgroups per CU)
 static int roi_fwd_planes(int c, int h, int w, int pooled)
 {
     const size_t plane_bytes = (size_t)h * w * sizeof(float);
-    const size_t budget = 72 * 1024;                         // two workgroups per CU
-    if (pooled != 7 || plane_bytes > budget) return 0;
-    int cg = (int)(budget / plane_bytes);
+    if (pooled != 7 || plane_bytes > 72 * 1024) return 0;
+    if (c >= RF2_CG8 && RF2_CG8 * plane_bytes <= 150 * 1024) return RF2_CG8;
+    int cg = (int)(72 * 1024 / plane_bytes);
     if (cg > RF2_CG) cg = RF2_CG;
     if (cg > c) cg = c;
     return cg;
@@ -503,11 +508,17 @@ static int roi_fwd_grouped_launch(const float* feat, const float* rois, const in
     PTMI_LAUNCH_CHECK("roi_align_tables");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)roi_align_fwd_bin_kernel<PACK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_fwd_bin_kernel<PACK, RF2_CG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_fwd_bin_kernel<PACK, RF2_CG8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(roi_align_fwd_bin_kernel<PACK>, dim3(cdiv(c, cg), n), dim3(RF2_THREADS), (size_t)cg * h * w * sizeof(float), st,
-                       feat, ws, img_offsets, out, c, h, w, cg, TS, rois, scale, xk, xt, r);
+    const size_t lds = (size_t)cg * h * w * sizeof(float);
+    if (cg > RF2_CG)
+        hipLaunchKernelGGL((roi_align_fwd_bin_kernel<PACK, RF2_CG8>), dim3(cdiv(c, cg), n), dim3(RF2_THREADS), lds, st, feat, ws, img_offsets,
+                           out, c, h, w, cg, TS, rois, scale, xk, xt, r);
+    else
+        hipLaunchKernelGGL((roi_align_fwd_bin_kernel<PACK, RF2_CG>), dim3(cdiv(c, cg), n), dim3(RF2_THREADS), lds, st, feat, ws, img_offsets,
+                           out, c, h, w, cg, TS, rois, scale, xk, xt, r);
     PTMI_LAUNCH_CHECK("roi_align_fwd_grouped");
     return 0;
 }
