@@ -632,3 +632,61 @@ def test_rpn_loss_weight_quirk_matches_the_reference():
     finally:
         sampling.set_key_source(None)
 
+
+
+def test_trainer_resize_equals_the_reference_outputs_bit_for_bit():
+    """PTrainer.resize (trainer.py:557-590) as the step calls it -- the whole list in one image launch, the boxes of all records
+    in ONE multiply and ONE add over their concatenation -- against what the REAL reference's PTrainer.resize produced for the
+    same records and ratios (tests/golden/trainer_pieces.npz): uint8 canvases, gt boxes and pseudo boxes bit for bit; untouched
+    fields pass through; and against the record-by-record fp32 statement on a larger mixed batch."""
+    from probabilisticteacher_amd.config import setup_cfg
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    z = load("trainer_pieces")
+    recs = records(z, "rz_in", 2, FreeInstances)
+    recs[1]["instances"].pseudo_boxes = Boxes(torch.from_numpy(z["rz_in1_pseudo_boxes"]))
+    cfg = setup_cfg("configs/pt/final_c2f.yaml", ["MODEL.DEVICE", DEV, "MODEL.VGG.PRETRAIN", ""])
+    ratios = [float(q) for q in z["rz_ratios"]]
+    tr = PTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
+    out = tr.resize([dict(r) for r in recs])
+    for i, o in enumerate(out):
+        assert np.array_equal(o["image"].cpu().numpy(), z[f"rz_out{i}_image"]), f"canvas {i}"
+        assert np.array_equal(o["instances"].gt_boxes.tensor.cpu().numpy(), z[f"rz_out{i}_gt_boxes"]), f"gt boxes {i}"
+        assert torch.equal(o["instances"].gt_classes.cpu(), recs[i]["instances"].gt_classes.cpu())
+    assert np.array_equal(out[1]["instances"].pseudo_boxes.tensor.cpu().numpy(), z["rz_out1_pseudo_boxes"]), "pseudo boxes"
+    assert np.array_equal(recs[0]["instances"].gt_boxes.tensor.cpu().numpy(), z["rz_in0_gt_boxes"]), "the inputs are not modified"
+    # a larger mixed batch (records without boxes, with one field, with both; empty box sets) against the in-place statement
+    gen = torch.Generator().manual_seed(3)
+    big, want, rr = [], [], []
+    for i in range(9):
+        inst = FreeInstances((120, 160))
+        fields = {}
+        if i % 3 != 0:
+            fields["gt_boxes"] = torch.rand(0 if i == 4 else 5 + i, 4, generator=gen) * 150
+        if i % 2 == 0:
+            fields["pseudo_boxes"] = torch.rand(3 + i, 4, generator=gen) * 150
+        for k, v in fields.items():
+            inst.set(k, Boxes(v.clone()))
+        inst.set("tag", torch.full((1,), float(i)))
+        big.append({"image": torch.randint(0, 256, (3, 120, 160), generator=gen, dtype=torch.uint8), "instances": inst})
+        ratio = 0.5 + 0.05 * i
+        rr.append(ratio)
+        dh, dw = int(120 * ratio), int(160 * ratio)
+        x1, y1 = int((160 - dw) / 2), int((120 - dh) / 2)
+        w_ = {}
+        for k, v in fields.items():
+            t = v.clone()
+            t *= ratio
+            t[:, 0] += x1
+            t[:, 2] += x1
+            t[:, 1] += y1
+            t[:, 3] += y1
+            w_[k] = t
+        want.append(w_)
+    tr._ratio_fn = lambda: rr.pop(0)
+    got = tr.resize(big)
+    for o, w_, src in zip(got, want, big):
+        assert set(o["instances"].get_fields()) == set(src["instances"].get_fields())
+        for k, t in w_.items():
+            assert torch.equal(o["instances"].get(k).tensor.cpu(), t), k
+        assert torch.equal(o["instances"].get("tag"), src["instances"].get("tag"))
