@@ -649,9 +649,6 @@ constexpr int G_DYB = 16 * G_DYP;            // 33792
 constexpr int G_XB = 26 * 1024;              // 8 planes x 204 pieces = 1632 pieces, padded to 26 wave instructions
 constexpr int G_STAGE = G_DYB + G_XB;        // 60416
 
-typedef short p8_s4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) p8_s4 plds_s4_t;
-struct p8_s4x2 { p8_s4 lo, hi; };
 
 __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, float* __restrict__ ws,
                                                          float* __restrict__ wsb, int Cin, int Cout, int xcb, int dcb, int WS, int ROWS,
@@ -737,13 +734,8 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[m][t][e] = 0.f;
 
-    auto rd = [&](const char* p) {
-        p8_s4x2 v;
-        v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plds_s4_t*)p);
-        v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((plds_s4_t*)(p + 64));
-        return __builtin_bit_cast(ptmi_bf16x8, v);
-    };
     const ptmi_bf16x8 ones = __builtin_bit_cast(ptmi_bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+    const unsigned stage_addr = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)lds;      // LDS byte address of stage 0
 
     if (t0 < t1) {
         const int R0 = (t0 / tilesC) * 4, C0 = (t0 % tilesC) * 32;
@@ -757,7 +749,6 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
 
     for (int tile = t0; tile < t1; ++tile) {
         const int st = (tile - t0) & 1;
-        const char* base = lds + st * G_STAGE;
         const int R0 = (tile / tilesC) * 4, C0 = (tile % tilesC) * 32;
         const int R1 = ((tile + 1) / tilesC) * 4, C1 = ((tile + 1) % tilesC) * 32;
         const bool more = tile + 1 < t1;
@@ -777,10 +768,31 @@ __global__ __launch_bounds__(GT, 2) void p8_wgrad_kernel(const u16* __restrict__
             }
             // k-steps whose 16 pixels lie beyond the grid carry only zeros in dY: skip them (wave-uniform)
             if (R0 + (s >> 1) < ROWS && C0 + 16 * (s & 1) < WS) {
-                const ptmi_bf16x8 A0 = rd(base + a_base + s * 256), A1 = rd(base + a_base + 4 * G_DYP + s * 256);
+                // operand reads as inline asm: seen as LDS loads by the compiler, each k-step's first one gets an `s_waitcnt vmcnt(0)`
+                // in front once LDS-DMA instructions are in flight (it cannot tell the DMA's stage from the one being read) -- the
+                // waves then sat out the latency of the pieces they had just issued, four k-steps per tile (conv3_2: 3.76 -> 3.35 ms).
+                // (Requesting k-step s + 1's operands before k-step s's MFMAs -- two register sets, counted lgkmcnt -- was tried on
+                // top: 250 registers, 3.46 ms; the SIMD's second wave already fills those gaps.)
+                const unsigned sa = stage_addr + (unsigned)(st * G_STAGE);
+                constexpr int so = ((s >> 1) * 34 + 16 * (s & 1)) * 16;
+                u32x2 ra[4], rb[10];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ra[0]) : "v"(sa + (unsigned)a_base), "n"(s * 256));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ra[1]) : "v"(sa + (unsigned)a_base), "n"(s * 256 + 64));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ra[2]) : "v"(sa + (unsigned)a_base), "n"(4 * G_DYP + s * 256));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ra[3]) : "v"(sa + (unsigned)a_base), "n"(4 * G_DYP + s * 256 + 64));
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rb[2 * t]) : "v"(sa + (unsigned)b_base[t]), "n"(so));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rb[2 * t + 1]) : "v"(sa + (unsigned)b_base[t]), "n"(so + 64));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]),
+                               "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]), "+v"(rb[8]), "+v"(rb[9]));
+                const ptmi_bf16x8 A0 = __builtin_bit_cast(ptmi_bf16x8, (u32x4){ra[0][0], ra[0][1], ra[1][0], ra[1][1]});
+                const ptmi_bf16x8 A1 = __builtin_bit_cast(ptmi_bf16x8, (u32x4){ra[2][0], ra[2][1], ra[3][0], ra[3][1]});
                 ptmi_bf16x8 B[5];
 #pragma unroll
-                for (int t = 0; t < 5; ++t) B[t] = rd(base + b_base[t] + ((s >> 1) * 34 + 16 * (s & 1)) * 16);
+                for (int t = 0; t < 5; ++t) B[t] = __builtin_bit_cast(ptmi_bf16x8, (u32x4){rb[2 * t][0], rb[2 * t][1], rb[2 * t + 1][0], rb[2 * t + 1][1]});
                 if (ones_slot) B[4] = ones;
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {

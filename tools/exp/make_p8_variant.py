@@ -26,14 +26,14 @@ EDITS = [
     ("                __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)svoff[j], 0, 0);",
      "                if (!(P8X & 8)) __builtin_amdgcn_raw_buffer_store_b128(w, ry, (int)svoff[j], 0, 0);\n                else asm volatile(\"\" :: \"v\"(w));"),
     ("                if (more && (s >> 1) == tg) {", "                if (!(P8X & 16) && more && (s >> 1) == tg) {"),
-    ("                const ptmi_bf16x8 A0 = rd(base + a_base + s * 256), A1 = rd(base + a_base + 4 * G_DYP + s * 256);\n"
-     "                ptmi_bf16x8 B[5];\n#pragma unroll\n"
-     "                for (int t = 0; t < 5; ++t) B[t] = rd(base + b_base[t] + ((s >> 1) * 34 + 16 * (s & 1)) * 16);",
-     "                ptmi_bf16x8 A0 = ones, A1 = ones;\n                ptmi_bf16x8 B[5];\n"
-     "                if (!(P8X & 32)) { A0 = rd(base + a_base + s * 256); A1 = rd(base + a_base + 4 * G_DYP + s * 256); }\n#pragma unroll\n"
-     "                for (int t = 0; t < 5; ++t) B[t] = (P8X & 32) ? ones : rd(base + b_base[t] + ((s >> 1) * 34 + 16 * (s & 1)) * 16);"),
-    ("        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n    }\n\n    // ---- partials",
-     "        if (!(P8X & 64)) {\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        asm volatile(\"s_waitcnt lgkmcnt(0)\\n\\ts_barrier\" ::: \"memory\");\n        }\n    }\n\n    // ---- partials"),
+    ("                asm volatile(\"s_waitcnt lgkmcnt(0)\"\n                             : \"+v\"(ra[0])",
+     "                if (P8X & 32) {\n#pragma unroll\n                    for (int i_ = 0; i_ < 4; ++i_) ra[i_] = (u32x2){0x3F803F80u, 0x3F803F80u};\n"
+     "#pragma unroll\n                    for (int i_ = 0; i_ < 10; ++i_) rb[i_] = (u32x2){0x3F803F80u, 0x3F803F80u};\n                }\n"
+     "                asm volatile(\"s_waitcnt lgkmcnt(0)\"\n                             : \"+v\"(ra[0])"),
+    ("                asm volatile(\"ds_read_b64_tr_b16 %0, %1 offset:%2\" : \"=v\"(ra[0]) : \"v\"(sa + (unsigned)a_base), \"n\"(s * 256));",
+     "                if (!(P8X & 32)) {\n                asm volatile(\"ds_read_b64_tr_b16 %0, %1 offset:%2\" : \"=v\"(ra[0]) : \"v\"(sa + (unsigned)a_base), \"n\"(s * 256));"),
+    ("                    asm volatile(\"ds_read_b64_tr_b16 %0, %1 offset:%2\" : \"=v\"(rb[2 * t + 1]) : \"v\"(sa + (unsigned)b_base[t]), \"n\"(so + 64));\n                }",
+     "                    asm volatile(\"ds_read_b64_tr_b16 %0, %1 offset:%2\" : \"=v\"(rb[2 * t + 1]) : \"v\"(sa + (unsigned)b_base[t]), \"n\"(so + 64));\n                }\n                }"),
 ]
 
 
