@@ -86,21 +86,33 @@ struct OpTile {
     __device__ __forceinline__ void issue(float* dst_wave, int wave, int krem)
     {
         const __amdgpu_buffer_rsrc_t r = ptmi_rsrc(base, (unsigned)(left > 0xFFFFFFFEll ? 0xFFFFFFFEll : (left < 0 ? 0 : left)));
-        if constexpr (KF) {
+        // the K-tail masks belong to the LAST step only: as per-lane selects on every piece of every step (what the compiler makes of
+        // `if (krem < BKT) v = ...`) they were three VALU instructions per DMA instruction -- and VALU time adds to fp32 MFMA time
+        if (krem >= BKT) {                                   // (wave-uniform)
+            if constexpr (KF) {
 #pragma unroll
-            for (int i = 0; i < Cfg::KF_NI; ++i) {
-                if (i < Cfg::KF_NI - 1 || wave < 2) {
-                    unsigned v = voff[i];
-                    if (krem < BKT) v = ((int)((qpack >> (6 * i)) & 63) < krem) ? v : 0xFFFFFFFFu;
-                    ptmi_bdma16(r, v, 0, dst_wave + i * 1024);
-                }
+                for (int i = 0; i < Cfg::KF_NI; ++i)
+                    if (i < Cfg::KF_NI - 1 || wave < 2) ptmi_bdma16(r, voff[i], 0, dst_wave + i * 1024);
+            } else {
+#pragma unroll
+                for (int i = 0; i < Cfg::MF_NI; ++i) ptmi_bdma16(r, voff[0], i * row8_bytes, dst_wave + i * 1024);
             }
         } else {
+            asm volatile("" ::: "memory");                   // (keeps the two forms apart: merged, they are the selects again)
+            if constexpr (KF) {
 #pragma unroll
-            for (int i = 0; i < Cfg::MF_NI; ++i) {
-                unsigned v = voff[0];
-                if (krem < BKT) v = ((int)qpack + 8 * i < krem) ? v : 0xFFFFFFFFu;
-                ptmi_bdma16(r, v, i * row8_bytes, dst_wave + i * 1024);
+                for (int i = 0; i < Cfg::KF_NI; ++i) {
+                    if (i < Cfg::KF_NI - 1 || wave < 2) {
+                        const unsigned v = ((int)((qpack >> (6 * i)) & 63) < krem) ? voff[i] : 0xFFFFFFFFu;
+                        ptmi_bdma16(r, v, 0, dst_wave + i * 1024);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < Cfg::MF_NI; ++i) {
+                    const unsigned v = ((int)qpack + 8 * i < krem) ? voff[0] : 0xFFFFFFFFu;
+                    ptmi_bdma16(r, v, i * row8_bytes, dst_wave + i * 1024);
+                }
             }
         }
         base += step_bytes;

@@ -6,7 +6,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from probabilisticteacher_amd import ops  # noqa: E402
+from probabilisticteacher_amd import _lib, ops  # noqa: E402
+
+if "--lib" in sys.argv:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""
 
 
 def timeit(fn, iters=10):
@@ -24,6 +28,8 @@ def timeit(fn, iters=10):
 dev = "cuda:0"
 tot = 0.0
 for name, k, nout in (("fc1", 25088, 1024), ("fc2", 1024, 1024), ("bbox_pred", 1024, 64), ("cls_score", 1024, 9)):
+    if ONLY and name != ONLY:
+        continue
     for r, grad in ((32000, False), (16384, True), (2400, True)):
         x = torch.randn(r, k, device=dev)
         w = torch.randn(nout, k, device=dev) * 0.01
