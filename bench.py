@@ -80,7 +80,7 @@ def cpu_baseline(h, w, K, seed=0, student_only=False):
                        f"1 unlabelled {w}x{h} image, {dt:.1f} s")}
 
 
-PMC_PROFILE = "profiles/r03_bench_b16_pmc_by_kernel.json"
+PMC_PROFILE = "profiles/r04_bench_b16_pmc_by_kernel.json"
 DOMINANT = "conv3x3_wino_kernel"          # the kernel the roofline object describes (its rocprofv3 name contains this)
 DOMINANT_AMP = "p8_conv3x3_kernel"        # ... with --amp: the bf16-storage forward / dgrad kernel
 
