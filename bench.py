@@ -73,7 +73,8 @@ def cpu_baseline(h, w, K, seed=0, student_only=False):
     t0 = time.perf_counter()
     opt.run_step(cfg, state, data, {"label": [0.8, 0.75], "unlabel": [0.7]}, perm_fn=opt.SeededPerm(1))
     dt = time.perf_counter() - t0
-    return {"value": 2.0 / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": 2.0 / dt, "unit": "img/s", "cores": torch.get_num_threads(), "host_cores_total": os.cpu_count(),
+            "kind": "port",
             "sample": (f"1 supervised student step (2 fwd, 2 bwd, clip+SGD) on the strong + weak view of 1 labelled {w}x{h} "
                        f"image, {dt:.1f} s" if student_only else
                        f"1 full teacher+student step (EMA, teacher fwd, 3 student fwd, 3 bwd, clip+SGD) with 1 labelled + "
@@ -141,6 +142,28 @@ def measured_pmc_traffic(args):
             f"{disp} dispatches of {dominant}; FETCH_SIZE x2 per the gfx950 correction)")
 
 
+def extra_leg(flags, steps=20, warmup=5, pmc="auto"):
+    """One more leg of the SAME script in a fresh process, after the headline's timed region (so that nothing of it perturbs the
+    fp32 number): returns the leg's own JSON line reduced to what the headline line carries for it, or {"error": ...}."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-extras", "--pmc-traffic", pmc] + flags
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+    except Exception as e:      # noqa: BLE001  (an extra leg must not take the headline line with it)
+        return {"error": repr(e)[:300]}
+    rf = d["roofline"]
+    return {"metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+            "ms_per_step_median": d["ms_per_step_median"], "steps": d["steps"], "warmup": d["warmup"], "dtype": d["dtype"],
+            "workload": d["config"]["workload"], "global_batch": d["config"]["global_batch"],
+            "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                                            "algorithmic_bytes_per_launch", "kernel", "avg_launch_ms", "calls",
+                                            "effective_direct_tflops")},
+            "kernels": d["kernels"], "losses": d["losses"], "command": " ".join(["python", "bench.py"] + cmd[2:])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +187,10 @@ def main():
                          "for N = 1, 2, 4, 8 is that config's weak-scaling curve and N = 8 its own number")
     ap.add_argument("--grad-reduce", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: the bucketed gradient exchange as all-reduce or as reduce-scatter + all-gather (engine/flat.py)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1 default run only: skip the two extra legs that the JSON line carries next to the fp32 headline -- "
+                         "`amp` (the same workload with SOLVER.AMP.ENABLED, BASELINE configs[4]'s precision) and `student_only` "
+                         "(BASELINE configs[1], batch 8)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic after the timed region by re-running one step under rocprofv3 "
                          "PMC passes; off: report the committed profile's number, labelled as such")
@@ -323,6 +350,15 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not args.amp:
             out["cpu_baseline"] = cpu_baseline(H, W, K, student_only=args.student_only)
+        if world == 1 and not args.no_extras and not args.amp and not args.student_only and not args.config3:
+            # BASELINE configs[4]'s precision and configs[1] on the driver's record: the same PTrainer workload with
+            # SOLVER.AMP.ENABLED (pt/engine/trainer.py:98), and the student-only burn-in step at batch 8 -- each in its own
+            # process after the fp32 timed region; the headline keys above stay fp32
+            del trainer, batches
+            torch.cuda.empty_cache()
+            size = ["--height", str(H), "--width", str(W)]
+            out["amp"] = extra_leg(["--amp", "--per-gpu-batch", str(B)] + size)
+            out["student_only"] = extra_leg(["--student-only", "--per-gpu-batch", "4"] + size, pmc="off")
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
