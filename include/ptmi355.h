@@ -79,6 +79,21 @@ int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, co
  * to ptmi_conv3x3_fwd / ptmi_conv3x3_wgrad (the Winograd entry points themselves reject such shapes with an error). */
 int ptmi_conv3x3_wino_fwd_fits(int cin, int cout, int h, int w);
 int ptmi_conv3x3_wino_wgrad_fits(int h, int w);
+/* Fused Winograd F(4x4,3x3) variant (round 5, csrc/wino4.hip) of ptmi_conv3x3_wino_fwd for the same layers
+ * (pt/modeling/backbone/vgg.py:45-53,66-69, pt/modeling/proposal_generator/rpn.py:96) when the input channel count is a multiple
+ * of 8: 36 transform-domain products per 4x4 outputs instead of 64, on v_mfma_f32_16x16x4_f32; interpolation points
+ * 0, +-3/4, +-3/2, inf (every constant of B^T and A^T exact in fp32; measured error against an fp64 convolution 1.2e-5 of a
+ * unit-scale output at 512 channels -- inside the 1e-4 bar of the parity tests, which are unchanged).  Same arguments,
+ * epilogues and dgrad convention (mode 1 pack) as ptmi_conv3x3_fwd.  Packed weights: U = G g G^T as
+ * [ceil(Cout/64)][Cin/4][4 ci][9 (groups of four positions p = 6 i + j)][64 co][4] fp32, zero padded.
+ * ptmi_conv3x3_wino4_fwd_fits: 1 if the shape is served (cin % 8 == 0 and the 32-bit buffer offsets suffice). */
+int64_t ptmi_conv3x3_wino4_packed_floats(int cin, int cout);
+int ptmi_conv3x3_wino4_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode,
+                                    ptmi_stream_t s);
+int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                           float* y, int n, int cin, int cout, int h, int w, int epilogue,
+                           ptmi_stream_t s);
+int ptmi_conv3x3_wino4_fwd_fits(int cin, int cout, int h, int w);
 /* Winograd-domain weight gradient (same contract as ptmi_conv3x3_wgrad; replaces cuDNN's Winograd-nonfused BWD_FILTER
  * for the trainable 3x3 layers with >= 64 input and output channels): dU_p[co][ci] = sum over tiles of (A dY A^T)_p V_p on v_mfma_f32_32x32x2_f32 (16 instead
  * of 36 multiplies per tile and channel pair), split over contiguous tile ranges whose partials (workspace

@@ -31,6 +31,10 @@ SIGNATURES = {
     "ptmi_conv3x3_wino_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wino_fwd_fits": (_i, [_i, _i, _i, _i]),
     "ptmi_conv3x3_wino_wgrad_fits": (_i, [_i, _i]),
+    "ptmi_conv3x3_wino4_packed_floats": (_i64, [_i, _i]),
+    "ptmi_conv3x3_wino4_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_wino4_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_wino4_fwd_fits": (_i, [_i, _i, _i, _i]),
     "ptmi_conv3x3_wino_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_conv3x3_wino_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_p8_plane_pixels": (_i64, [_i, _i, _i]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libptmi355.so")
-SOURCES = ["abi.cpp", "conv.hip", "wino.hip", "p8.hip", "p8gemm.hip", "gemm.hip", "misc.hip", "boxes.hip", "nms.hip", "sort.hip", "roi_align.hip",
+SOURCES = ["abi.cpp", "conv.hip", "wino.hip", "wino4.hip", "p8.hip", "p8gemm.hip", "gemm.hip", "misc.hip", "boxes.hip", "nms.hip", "sort.hip", "roi_align.hip",
            "losses.hip", "augment.hip"]
 # -ffp-contract=off: index-producing kernels (IoU, NMS, matcher) must evaluate fp32 expressions exactly as the
 # CPU reference does.  -munsafe-fp-atomics: hardware fp32 atomic add for the ROIAlign backward scatter.

@@ -1,0 +1,681 @@
+// wino4.hip -- fused Winograd F(4x4, 3x3) convolution for gfx950 (CDNA4): 3x3 s1 p1, fp32 in / fp32 accumulate on
+// v_mfma_f32_16x16x4_f32: forward and dgrad of the fp32 layers with many input channels (round 5).
+//
+// Replaces the cuDNN conv2d (+bias, +ReLU) the reference reaches at pt/modeling/backbone/vgg.py:45-53,66-69 and the 3x3 conv of
+// D2's StandardRPNHead (pt/modeling/proposal_generator/rpn.py:96), like wino.hip -- with 36 instead of 64 transform-domain
+// products per 4x4 outputs (F(2x2,3x3): 16 per 2x2), i.e. 1.78x fewer MFMAs; the direct algorithm needs 144.
+//
+// Interpolation points 0, +-3/4, +-3/2, inf (NOT the textbook 0, +-1, +-2: on fp32 the textbook set's inverse transform
+// multiplies by up to 8 x 8 and its error against an fp64 convolution is 4e-5 at 512 channels; this set measures 1.2e-5
+// max / 1.2e-6 rms, F(2x2,3x3) 2.3e-6 / 4e-7, direct fp32 1.2e-6 / 1.8e-7 -- tools/exp/wino4_numerics.py).  Every constant
+// of B^T and A^T is exact in fp32:
+//   B^T (6x6), row order (0, +a, -a, +b, -b, inf), a = 3/4, b = 3/2:
+//       [a2b2, 0, -(a2+b2), 0, 1, 0]  [0, -ab2, -b2, a, 1, 0]  [0, ab2, -b2, -a, 1, 0]
+//       [0, -a2b, -a2, b, 1, 0]  [0, a2b, -a2, -b, 1, 0]  [0, a2b2, 0, -(a2+b2), 0, 1]
+//   A^T (4x6) = rows [p^k] over the same points (last column (0,0,0,1)); G (6x3) is whatever makes the identity hold:
+//       [64/81,0,0] [-128/243,-32/81,-8/27] [-128/243,32/81,-8/27] [32/243,16/81,8/27] [32/243,-16/81,8/27] [0,0,1]
+//   (G g G^T is evaluated in double by the pack kernel and rounded once).
+//
+// One kernel, nothing in HBM but x, the packed weights and y:
+//   * M_p[co][tile] = sum_ci U_p[co][ci] V_p[ci][tile] for the 36 positions p = 6 i + j; a workgroup = 4 wave64s owns 64
+//     output channels x (8 rows x 64 columns) = 2 x 16 tiles of the FLAT tile line of wino.hip (every (image, 8-row band) is a
+//     strip of `period` columns; strips concatenated; a workgroup may straddle strips); a wave owns 32 channels x 16 tiles
+//     (one tile row) x ALL 36 positions = 72 accumulator tiles of 16x16 = 288 registers: 256 AGPRs + 32 VGPRs, which is why
+//     the MFMAs are inline asm ("+a" / "+v" on f32x4): the compiler picks one register class per function for the builtin;
+//   * v_mfma_f32_16x16x4_f32 takes A[co = lane & 15][k = lane >> 4], B[k = lane >> 4][tile = lane & 15]: a lane IS one
+//     (tile, input channel) pair, reads its own 6x6 window from the LDS patch (per row: b32 + b128 + b32), transforms it in
+//     registers (12 FMAs per 1-D transform, 144 per window) and holds the B operands of all 36 positions; each feeds TWO
+//     MFMAs (the wave's two 16-channel tiles).  The A operands are 16-byte reads of four positions of one channel;
+//   * K is walked in chunks of 4 channels = ONE MFMA K = 72 MFMAs per wave (2304 matrix-pipe cycles); per chunk the weights
+//     slab is 36 KB (4x the F(2x2) slab per channel) and the patch 11 KB, through `buffer_load_dwordx4 ... lds` into THREE
+//     slab stages + FOUR patch stages (156 KB of the 160 KB): the patch of chunk c + 1 is transformed during chunk c, so it
+//     has to land one chunk earlier than the slab of chunk c + 1;
+//   * a chunk is 72 slots "MFMA + its share of the other work", pinned with sched_barrier: slot 60 is the hand-over for the
+//     NEXT chunk (counted vmcnt, fix-ups, one s_barrier), after the last A read of this chunk and before the first of the next;
+//   * epilogue: Y = A^T M A per (channel, tile) in registers (all 36 positions of a pair live in one lane), then the
+//     epilogues of wino.hip: bias / bias+ReLU / none / ReLU mask of the producer (dgrad) / bias+ReLU+2x2 max pool.
+// dgrad = the same kernel on dY with the flipped / transposed filter (pack mode 1).
+
+#include "common.h"
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 xlds_f32x4_t;
+typedef __attribute__((address_space(3))) float xlds_f32_t;
+typedef __attribute__((address_space(3))) void xlds_void_t;
+
+constexpr int XKC = 4;                  // input channels per chunk = K of one MFMA
+constexpr int XBM = 64;                 // output channels per workgroup
+constexpr int XTH = 8, XTW = 64;        // output pixels per workgroup: 8 rows x 64 flat columns = 2 x 16 tiles of 4x4
+constexpr int XPP = 72;                 // patch row pitch in floats: 18 pieces, LDS column c <-> flat column u0 - 4 + c
+constexpr int XPR = XTH + 2;            // patch rows (image rows y0-1 .. y0+8)
+constexpr int XPL = XPR * XPP;          // floats per channel plane (720)
+constexpr int XUS = XKC * 9 * XBM * 4;  // U floats per chunk: [ci 4][position group 9][co 64][4 positions] = 9216 (36 KB)
+constexpr int XPS = XKC * XPL;          // patch floats per chunk: 2880 = 720 pieces
+constexpr int XPSP = 3072;              // ... padded to 3 DMA instructions per lane (pieces 720 .. 767 carry offset 0xFFFFFFFF)
+constexpr int XNT = 256;
+constexpr int XUI = XUS / 4 / XNT;      // 9 U DMA instructions per lane and chunk
+constexpr int XPI = XPSP / 4 / XNT;     // 3 patch DMA instructions per lane and chunk
+constexpr int XDI = XUI + XPI;          // 12
+constexpr int XNU = 3, XNP = 4;         // stages
+constexpr int XLDS = XNU * XUS + XNP * XPSP;   // 39936 floats = 159744 B
+
+// transform constants (a = 3/4, b = 3/2)
+constexpr float XA = 0.75f, XB = 1.5f, XA2 = 0.5625f, XB2 = 2.25f, XA3 = 0.421875f, XB3 = 3.375f;
+constexpr float XA2B2 = 1.265625f, XS2 = 2.8125f;      // a^2 b^2, a^2 + b^2
+
+// r = c * x + y / r = -c * x + y with the constant in an SGPR: one VOP3 each, opaque to the SLP vectoriser (which otherwise
+// builds v_pk_fma_f32 out of register shuffles -- slower than two scalar FMAs next to MFMAs on this part)
+__device__ __forceinline__ float xfma(float c, float x, float y) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(c), "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float xfnma(float c, float x, float y) { float r; asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(r) : "s"(c), "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float xadd(float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float xsub(float x, float y) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ float xmul(float c, float x) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "s"(c), "v"(x)); return r; }
+
+// 1-D input transform t = B^T d: operation k of 12 (so that a slot can carry any sub-range of them).  E[] are the four
+// intermediates (even / odd parts at +-a and +-b).
+template <int K>
+__device__ __forceinline__ void xin_op(const float (&d)[6], float (&t)[6], float (&E)[4])
+{
+    if constexpr (K == 0) t[0] = xfnma(XS2, d[2], d[4]);
+    if constexpr (K == 1) t[0] = xfma(XA2B2, d[0], t[0]);
+    if constexpr (K == 2) t[5] = xfnma(XS2, d[3], d[5]);
+    if constexpr (K == 3) t[5] = xfma(XA2B2, d[1], t[5]);
+    if constexpr (K == 4) E[0] = xfnma(XB2, d[2], d[4]);        // even part at +-a
+    if constexpr (K == 5) E[1] = xfnma(XB2, d[1], d[3]);        // odd part at +-a (before the factor a)
+    if constexpr (K == 6) t[1] = xfma(XA, E[1], E[0]);
+    if constexpr (K == 7) t[2] = xfnma(XA, E[1], E[0]);
+    if constexpr (K == 8) E[2] = xfnma(XA2, d[2], d[4]);
+    if constexpr (K == 9) E[3] = xfnma(XA2, d[1], d[3]);
+    if constexpr (K == 10) t[3] = xfma(XB, E[3], E[2]);
+    if constexpr (K == 11) t[4] = xfnma(XB, E[3], E[2]);
+}
+
+// 1-D output transform y = A^T m (12 operations): y_k = sum_i p_i^k m_i (+ m_5 for k = 3)
+__device__ __forceinline__ void xout(const float (&m)[6], float (&y)[4])
+{
+    const float s1 = xadd(m[1], m[2]), d1 = xsub(m[1], m[2]), s2 = xadd(m[3], m[4]), d2 = xsub(m[3], m[4]);
+    y[0] = xadd(xadd(m[0], s1), s2);
+    y[1] = xfma(XB, d2, xmul(XA, d1));
+    y[2] = xfma(XB2, s2, xmul(XA2, s1));
+    y[3] = xfma(XB3, d2, xfma(XA3, d1, m[5]));
+}
+
+// the MFMAs: accumulator tile in AGPRs ("a") or VGPRs ("v")
+__device__ __forceinline__ void xmfma_a(f32x4& c, float a, float b) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void xmfma_v(f32x4& c, float a, float b) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+
+template <int... I, class F>
+__device__ __forceinline__ void xfor(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+
+// ---- the chunk schedule (compile-time tables; slot S = 8 g + 4 ct + q runs the MFMA of position 4 g + q, channel tile ct)
+constexpr int XHAND = 60;                                   // hand-over slot
+__host__ __device__ constexpr bool x_is_aread(int s) { return (s & 3) == 1; }
+// the k-th slot (k = 0 ..) that carries neither an A read nor the hand-over, from slot 2 on
+__host__ __device__ constexpr int x_free_slot(int k)
+{
+    int s = 2;
+    for (;; ++s) {
+        if (x_is_aread(s) || s == XHAND) continue;
+        if (k-- == 0) return s;
+    }
+}
+// window read r (0 .. 17: row r / 3, part r % 3) sits in the r-th free slot; DMA instruction i in slot 26 + 2 i
+__host__ __device__ constexpr int x_wread_at(int s)
+{
+    for (int r = 0; r < 18; ++r)
+        if (x_free_slot(r) == s) return r;
+    return -1;
+}
+__host__ __device__ constexpr int x_dma_at(int s) { return (s >= 26 && s < 26 + 2 * XDI && !(s & 1)) ? (s - 26) / 2 : -1; }
+// horizontal-transform operation h (0 .. 71: window row h / 12, operation h % 12) in slot 9 + h / 2; vertical operation v
+// (0 .. 71: column v / 12) in slot 45 + 3 v / 8
+__host__ __device__ constexpr int x_hop_lo(int s) { return s < 9 ? 0 : (s - 9) * 2 > 72 ? 72 : (s - 9) * 2; }
+__host__ __device__ constexpr int x_vop_lo(int s)
+{
+    if (s < 45) return 0;
+    int v = 0;
+    while (v < 72 && 45 + 3 * v / 8 < s) ++v;
+    return v;
+}
+
+template <bool RAGGED_UNUSED>
+__global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
+    const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
+    const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi,
+    int coTiles, int bands, int period, int nPix, int colocate)
+{
+    __shared__ __attribute__((aligned(16))) float lds[XLDS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // workgroup -> (channel tile, pixel tile): as wino.hip (colocate: the channel tiles of a pixel tile back to back on one XCD)
+    int cot, pix;
+    if (colocate) {
+        const int slot = blockIdx.x >> 3;
+        cot = slot % coTiles;
+        pix = (slot / coTiles) * 8 + (blockIdx.x & 7);
+        if (pix >= nPix) return;
+    } else {
+        cot = blockIdx.x % coTiles;
+        pix = blockIdx.x / coTiles;
+    }
+    const int HW = H * W;
+    const int nStrips = N * bands;
+    const int u0 = pix * XTW;                                // flat column of the workgroup's first output column
+    const int s_first = u0 / period;
+    const int n = s_first / bands;                           // image of the first tile column: the address base
+    const int s0 = (u0 > 4 ? u0 - 4 : 0) / period;           // strip / image / band of the patch's first column
+    const int n0 = s0 / bands, b0 = s0 - n0 * bands;
+
+    // ---- DMA descriptors: this lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first plane
+    // of image n.  Periods are multiples of 4, so a piece lies in ONE strip.
+    unsigned pvoff[XPI];
+    int fix = 0;                                             // words 1..3 of piece i (bits 4i+1 .. 4i+3) beyond the image edge
+#pragma unroll
+    for (int i = 0; i < XPI; ++i) {
+        const int pidx = tid + i * XNT;
+        const int ci = pidx / (XPR * 18), rem = pidx - ci * (XPR * 18);
+        const int r = rem / 18, q = rem - r * 18;
+        int gx = u0 - 4 + 4 * q - s0 * period, band = b0, sn = n0;       // gx < 0 only in the very first patch (u0 = 0, q = 0)
+        while (gx >= period) { gx -= period; ++band; }
+        while (band >= bands) { band -= bands; ++sn; }
+        const int gy = band * XTH - 1 + r;
+        pvoff[i] = 0xFFFFFFFFu;
+        if (pidx < XPS / 4 && gx >= 0 && sn < N && gy >= 0 && gy < H && gx < W) {
+            pvoff[i] = (unsigned)(((sn - n) * Cin + ci) * HW + gy * W + gx) * 4u;
+#pragma unroll
+            for (int e = 1; e < 4; ++e) fix |= (gx + e >= W) ? (1 << (4 * i + e)) : 0;
+        }
+    }
+    unsigned wv = (unsigned)tid * 16u;                      // byte offset of the lane's piece of the NEXT slab chunk to fetch (the range
+                                                             // check covers voffset only: beyond the slab = zero fill)
+    bool edge = false;                                       // some loaded piece may straddle the right edge of an image row
+    if (W & 3) {
+        const int e0 = W & ~3;
+        for (int st = s0; st < nStrips && st * period + e0 < u0 + XPP - 4; ++st)
+            edge |= st * period + e0 >= u0 - 4;
+    }
+
+    const char* xc = (const char*)(x + (size_t)n * Cin * HW);
+    // bytes from xc to the end of the tensor, clamped (offsets reach into the next image: (span Cin + 4) HW 4 < 2^32, launcher)
+    const long long xtail = (long long)(N - n) * Cin * HW * 4;
+    unsigned xleft = (unsigned)(xtail > 0xFFFFFFFEll ? 0xFFFFFFFEll : xtail);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        ptmi_uniform_ptr(wp + (size_t)cot * nChunks * XUS), 0, __builtin_amdgcn_readfirstlane(nChunks * XUS * 4), 0x00020000);
+
+    float* const ldsU = lds;
+    float* const ldsP = lds + XNU * XUS;
+    auto dma_patch = [&](int i, int stage) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            ptmi_uniform_ptr(xc), 0, __builtin_amdgcn_readfirstlane((int)xleft), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (xlds_void_t*)(ldsP + stage * XPSP + wave * 256 + i * XNT * 4), 16,
+                                                 (int)pvoff[i], 0, 0, 0);
+    };
+    auto dma_u = [&](int i, int stage) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (xlds_void_t*)(ldsU + stage * XUS + wave * 256 + i * XNT * 4), 16,
+                                                 (int)wv, i * XNT * 16, 0, 0);
+    };
+    auto advance_patch = [&]() __attribute__((always_inline)) {
+        xc += (size_t)XKC * HW * 4;
+        xleft = xleft == 0xFFFFFFFEu ? xleft : (xleft > (unsigned)XKC * (unsigned)HW * 4u ? xleft - (unsigned)XKC * (unsigned)HW * 4u : 0u);
+    };
+    auto advance_u = [&]() __attribute__((always_inline)) { wv += XUS * 4; };
+    auto fixup = [&](int stage) __attribute__((always_inline)) {
+        if (edge && fix) {
+            float* pw = ldsP + stage * XPSP + tid * 4;
+#pragma unroll
+            for (int i = 0; i < XPI; ++i) {
+#pragma unroll
+                for (int e = 1; e < 4; ++e)
+                    if (fix & (1 << (4 * i + e))) pw[i * XNT * 4 + e] = 0.f;
+            }
+        }
+    };
+
+    // ---- the lane's role in the MFMAs
+    const int wm = wave >> 1, wn = wave & 1;                 // channel half (32) / tile row (4 image rows) of the workgroup's tile
+    const int ttx = lane & 15, kq = lane >> 4;               // tile column / input channel of the chunk
+    auto tile_geometry = [&](int u0v, int& tsn_o, int& py_o, int& px_o) __attribute__((always_inline)) {
+        const int sf = u0v / period;
+        int px_t = u0v + 4 * ttx - sf * period, sn = sf / bands, band = sf - sn * bands;
+        while (px_t >= period) { px_t -= period; ++band; }
+        while (band >= bands) { band -= bands; ++sn; }
+        tsn_o = sn;
+        py_o = band * XTH + wn * 4;
+        px_o = px_t;
+        return sn < N && px_o < W && py_o < H;
+    };
+    bool active;
+    {
+        int a0, a1, a2;
+        active = __any(tile_geometry(u0, a0, a1, a2));        // (wave-uniform) some tile of the wave lies inside an image
+    }
+    // LDS float offsets of the lane: A = U[kq][group][co = wm 32 + ct 16 + ttx][4], window = patch[kq][4 wn + row][4 ttx + 3 ..]
+    const int a_off = (kq * 9 * XBM + wm * 32 + ttx) * 4;                                  // + g * 256 + ct * 64
+    const int b_off = kq * XPL + (wn * 4) * XPP + 4 * ttx + 3;                             // + row * 72 + {0, 1 (b128), 5}
+
+    // the lane's 8 biases (channels co_w + 16 ct + 4 kq + r), fetched BEFORE the first DMA
+    const int co_w = cot * XBM + wm * 32;
+    f32x4 bv[2];
+    {
+        const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            bv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (epi <= 1 || epi == 4)
+                bv[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (co_w + ct * 16 + 4 * kq) * 4, 0, 0));
+        }
+    }
+
+    // prologue DMA, in the order the counted waits assume: patch 0, U 0, patch 1 | U 1, patch 2
+    auto issue_patch = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XPI; ++i) dma_patch(i, stage);
+        advance_patch();
+    };
+    auto issue_u = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < XUI; ++i) dma_u(i, stage);
+        advance_u();
+    };
+    issue_patch(0);
+    issue_u(0);
+    issue_patch(1);
+    issue_u(1);
+    issue_patch(2);
+    // the accumulators, zeroed while the first pieces are in flight (the wave would sit in the wait below anyway)
+    f32x4 accA[64];                        // positions 0 .. 31 (x 2 channel tiles): AGPRs
+    f32x4 accV[8];                         // positions 32 .. 35: VGPRs
+    xfor(std::make_integer_sequence<int, 64>{}, [&](auto i_c) __attribute__((always_inline)) {
+        accA[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+a"(accA[decltype(i_c)::value]));
+    });
+    xfor(std::make_integer_sequence<int, 8>{}, [&](auto i_c) __attribute__((always_inline)) {
+        accV[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("" : "+v"(accV[decltype(i_c)::value]));
+    });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
+    fixup(0);
+    fixup(1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (active) {
+        float V0[36], V1[36];              // B operands of the current / next chunk
+        float Hh[6][6];                    // horizontally transformed window of the next chunk: Hh[row][j]
+        float D[6][6];                     // raw window rows
+        float E[4];
+
+        auto wread = [&](auto r_c, const float* pb) __attribute__((always_inline)) {         // window read r: row r / 3, part r % 3
+            constexpr int a = decltype(r_c)::value / 3, part = decltype(r_c)::value % 3;
+            const float* p = pb + a * XPP;
+            if constexpr (part == 0) D[a][0] = *(const volatile xlds_f32_t*)p;
+            if constexpr (part == 1) {
+                const f32x4 v = *(const volatile xlds_f32x4_t*)(p + 1);
+                D[a][1] = v[0]; D[a][2] = v[1]; D[a][3] = v[2]; D[a][4] = v[3];
+            }
+            if constexpr (part == 2) D[a][5] = *(const volatile xlds_f32_t*)(p + 5);
+        };
+        auto hop = [&](auto h_c) __attribute__((always_inline)) {                           // horizontal operation h: row h / 12 -> Hh[row][0..5]
+            constexpr int h = decltype(h_c)::value;
+            xin_op<h % 12>(D[h / 12], Hh[h / 12], E);
+        };
+        auto vop = [&](auto v_c, float (&Vn)[36]) __attribute__((always_inline)) {          // vertical operation v: column j = v / 12 -> Vn[6 i + j]
+            constexpr int v = decltype(v_c)::value;
+            constexpr int j = v / 12;
+            const float d[6] = {Hh[0][j], Hh[1][j], Hh[2][j], Hh[3][j], Hh[4][j], Hh[5][j]};
+            float t[6] = {Vn[j], Vn[6 + j], Vn[12 + j], Vn[18 + j], Vn[24 + j], Vn[30 + j]};
+            xin_op<v % 12>(d, t, E);
+            Vn[j] = t[0]; Vn[6 + j] = t[1]; Vn[12 + j] = t[2]; Vn[18 + j] = t[3]; Vn[24 + j] = t[4]; Vn[30 + j] = t[5];
+        };
+
+        {   // B operands of chunk 0: window from patch stage 0
+            const float* pb = ldsP + b_off;
+            xfor(std::make_integer_sequence<int, 18>{}, [&](auto r_c) __attribute__((always_inline)) { wread(r_c, pb); });
+            xfor(std::make_integer_sequence<int, 72>{}, [&](auto h_c) __attribute__((always_inline)) { hop(h_c); });
+            xfor(std::make_integer_sequence<int, 72>{}, [&](auto v_c) __attribute__((always_inline)) { vop(v_c, V0); });
+        }
+
+        // One chunk = 72 slots; EVERY chunk runs the same body -- the last one's work for "the next chunk" (window reads,
+        // transforms, zero-filled DMA, hand-over) is wasted, 1 / nChunks of that work, in exchange for a loop without joins: at
+        // every join of differently specialised copies the register allocator moved accumulator tiles around (hundreds of
+        // v_accvgpr copies per tile, scratch spills).  PAR: parity of the chunk (which of V0 / V1 is current).
+        // A operands: eighteen half-groups (four positions of one channel tile) per chunk rotate through THREE registers
+        // quads -- 18 = 0 mod 3, so the rotation carries across chunks; half-group h + 2 is read during half-group h.
+        f32x4 A[3];
+        A[0] = *(const volatile xlds_f32x4_t*)(ldsU + a_off);
+        A[1] = *(const volatile xlds_f32x4_t*)(ldsU + a_off + 64);
+        auto chunk = [&](auto par_c, int c) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_c)::value;
+            float(&Vc)[36] = PAR ? V1 : V0;
+            float(&Vn)[36] = PAR ? V0 : V1;
+            const int uc = c % XNU, un = (c + 1) % XNU, ud = (c + 2) % XNU;
+            const int pr = (c + 1) % XNP, pf = (c + 2) % XNP, pd = (c + 3) % XNP;
+            const float* ap = ldsU + uc * XUS + a_off;
+            const float* apn = ldsU + un * XUS + a_off;
+            const float* pb = ldsP + pr * XPSP + b_off;
+            {   // one address register each for the chunk's A reads and window reads (immediate offsets)
+                unsigned va = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)ap;
+                unsigned vn = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)apn;
+                unsigned vb = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)pb;
+                asm volatile("" : "+v"(va), "+v"(vn), "+v"(vb));
+                ap = (const float*)(const __attribute__((address_space(3))) float*)(size_t)va;
+                apn = (const float*)(const __attribute__((address_space(3))) float*)(size_t)vn;
+                pb = (const float*)(const __attribute__((address_space(3))) float*)(size_t)vb;
+            }
+            xfor(std::make_integer_sequence<int, 72>{}, [&](auto s_c) __attribute__((always_inline)) {
+                constexpr int S = decltype(s_c)::value;
+                constexpr int hg = S >> 2, g = S >> 3, ct = hg & 1, q = S & 3, p = 4 * g + q;
+                const float av = A[hg % 3][q], bvv = Vc[p];
+                if constexpr (p < 32) xmfma_a(accA[2 * p + ct], av, bvv);
+                else xmfma_v(accV[2 * (p - 32) + ct], av, bvv);
+                if constexpr (q == 1) {                      // half-group hg + 2 (of this chunk, or 0 / 1 of the next one)
+                    constexpr int h2 = hg + 2;
+                    if constexpr (h2 < 18) A[h2 % 3] = *(const volatile xlds_f32x4_t*)(ap + (h2 >> 1) * 256 + (h2 & 1) * 64);
+                    else A[h2 % 3] = *(const volatile xlds_f32x4_t*)(apn + (h2 & 1) * 64);
+                }
+                if constexpr (S == XHAND) {
+                    // everything but the 12 newest DMA instructions (this chunk's) has landed: slab c + 1, patch c + 2
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
+                    fixup(pf);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                constexpr int wr = x_wread_at(S);
+                if constexpr (wr >= 0) wread(std::integral_constant<int, (wr >= 0 ? wr : 0)>{}, pb);
+                constexpr int di = x_dma_at(S);
+                if constexpr (di >= 0) {
+                    if constexpr (di < XUI) dma_u(di, ud);
+                    else dma_patch(di - XUI, pd);
+                    if constexpr (di == XUI - 1) advance_u();
+                    if constexpr (di == XDI - 1) advance_patch();
+                }
+                constexpr int h0 = x_hop_lo(S), h1 = x_hop_lo(S + 1);
+                xfor(std::make_integer_sequence<int, h1 - h0>{}, [&](auto k_c) __attribute__((always_inline)) { hop(std::integral_constant<int, h0 + decltype(k_c)::value>{}); });
+                constexpr int v0 = x_vop_lo(S), v1 = x_vop_lo(S + 1);
+                xfor(std::make_integer_sequence<int, v1 - v0>{}, [&](auto k_c) __attribute__((always_inline)) { vop(std::integral_constant<int, v0 + decltype(k_c)::value>{}, Vn); });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        for (int c = 0; c < nChunks; c += 2) {              // nChunks is even (launcher: Cin % 8 == 0)
+            chunk(std::integral_constant<int, 0>{}, c);
+            chunk(std::integral_constant<int, 1>{}, c + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filled pieces of the chunks that do not exist
+    } else {
+        // a wave whose rows all lie below the image: the same DMA issue / wait / barrier sequence, no MFMAs
+        for (int c = 0; c < nChunks; ++c) {
+#pragma unroll
+            for (int i = 0; i < XUI; ++i) dma_u(i, (c + 2) % XNU);
+            advance_u();
+#pragma unroll
+            for (int i = 0; i < XPI; ++i) dma_patch(i, (c + 3) % XNP);
+            advance_patch();
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
+            fixup((c + 2) % XNP);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ---- epilogue: Y = A^T M A per (channel, tile) in registers, then bias / ReLU / mask / pool and buffer stores.
+    // Accumulator element r of tile (p, ct): channel co_w + 16 ct + 4 kq + r, tile ttx, position p.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs' results (inline asm: the compiler pads nothing)
+    int tsn, py, px;
+    int u0e = u0;
+    asm volatile("" : "+s"(u0e));
+    const bool tile_ok = tile_geometry(u0e, tsn, py, px);
+    const int cmax = Cout - co_w - 4 * kq;                   // channel 16 ct + r of this lane exists iff 16 ct + r < cmax
+    auto rd = [](float a) __attribute__((always_inline)) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; };
+    // the 4x4 outputs of channel (ct, r): o[k][l], k = output row, l = output column
+    auto inverse = [&](auto ct_c, auto r_c, float (&o)[4][4]) __attribute__((always_inline)) {
+        constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
+        float z[6][4];
+        xfor(std::make_integer_sequence<int, 6>{}, [&](auto i_c) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_c)::value;
+            float m[6];
+            xfor(std::make_integer_sequence<int, 6>{}, [&](auto j_c) __attribute__((always_inline)) {
+                constexpr int p = 6 * i + decltype(j_c)::value;
+                if constexpr (p < 32) m[decltype(j_c)::value] = rd(accA[2 * p + ct][r]);
+                else m[decltype(j_c)::value] = accV[2 * (p - 32) + ct][r];
+            });
+            xout(m, z[i]);
+        });
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const float m[6] = {z[0][l], z[1][l], z[2][l], z[3][l], z[4][l], z[5][l]};
+            float yk[4];
+            xout(m, yk);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k][l] = yk[k];
+        }
+    };
+    auto for_channels = [&](auto&& f) __attribute__((always_inline)) {
+        xfor(std::make_integer_sequence<int, 8>{}, [&](auto c_c) __attribute__((always_inline)) {
+            f(std::integral_constant<int, (decltype(c_c)::value >> 2)>{}, std::integral_constant<int, (decltype(c_c)::value & 3)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    if (epi == 4) {
+        // bias + ReLU + 2x2/2 max pool (floor mode): the tile is four pool windows
+        const int OH = H >> 1, OW = W >> 1, OHW = OH * OW;
+        const long long ytail = (long long)(N - n) * Cout * OHW * 4;
+        const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail));
+        const int oy = py >> 1, ox = px >> 1;
+        unsigned pv2[2], pv1[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const bool rok = tile_ok && oy + a < OH;
+            const unsigned o = (unsigned)(((tsn - n) * Cout + 4 * kq) * OHW + (oy + a) * OW + ox) * 4u;
+            pv2[a] = (rok && ox + 1 < OW) ? o : 0xFFFFFFFFu;
+            pv1[a] = (rok && ox + 1 == OW) ? o : 0xFFFFFFFFu;
+        }
+        for_channels([&](auto ct_c, auto r_c) __attribute__((always_inline)) {
+            constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
+            float o[4][4];
+            inverse(ct_c, r_c, o);
+            const float b = bv[ct][r];
+            const bool cok = 16 * ct + r < cmax;
+            const int soff = (co_w + 16 * ct + r) * OHW * 4;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                f32x2 m;
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+                    m[l] = fmaxf(fmaxf(fmaxf(o[2 * a][2 * l] + b, o[2 * a][2 * l + 1] + b),
+                                       fmaxf(o[2 * a + 1][2 * l] + b, o[2 * a + 1][2 * l + 1] + b)), 0.f);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, m), ry, cok ? (int)pv2[a] : -1, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m[0]), ry, cok ? (int)pv1[a] : -1, soff, 0);
+            }
+        });
+        return;
+    }
+    const long long ytail = (long long)(N - n) * Cout * HW * 4;
+    const unsigned img_bytes = (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail);     // to the end of the tensor, clamped
+    const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * HW, img_bytes);
+    const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(epi == 3 ? mref + (size_t)n * Cout * HW : y, epi == 3 ? img_bytes : 0u);
+    // per-lane byte offsets of the tile's four rows: pv4 = all four columns inside the image (16-byte access), pve[e] = column
+    // e alone (tiles cut by the right edge)
+    unsigned pv4[4];
+    unsigned pve[4][3];
+    bool partial = false;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const bool rok = tile_ok && py + a < H;
+        const unsigned o = (unsigned)(((tsn - n) * Cout + 4 * kq) * HW + (py + a) * W + px) * 4u;
+        pv4[a] = (rok && px + 3 < W) ? o : 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            pve[a][e] = (rok && px + 3 >= W && px + e < W) ? o + 4u * e : 0xFFFFFFFFu;
+            partial |= pve[a][e] != 0xFFFFFFFFu;
+        }
+    }
+    const bool cut = __any(partial);                         // (wave-uniform) some lane's tile is cut by the right edge
+    auto store_rows = [&](auto epi_c) __attribute__((always_inline)) {
+        constexpr int EPI = decltype(epi_c)::value;
+        for_channels([&](auto ct_c, auto r_c) __attribute__((always_inline)) {
+            constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
+            const bool cok = 16 * ct + r < cmax;
+            const int soff = (co_w + 16 * ct + r) * HW * 4;
+            f32x4 mk[4];
+            float ms[4][3];
+            if constexpr (EPI == 3) {                                  // the producer's activations first: their latency hides
+#pragma unroll                                                         // behind the inverse transform
+                for (int a = 0; a < 4; ++a) {
+                    mk[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, cok ? (int)pv4[a] : -1, soff, 0));
+                    if (cut) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                            ms[a][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, cok ? (int)pve[a][e] : -1, soff, 0));
+                    }
+                }
+            }
+            float o[4][4];
+            inverse(ct_c, r_c, o);
+            const float b = bv[ct][r];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 st;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    float v = o[a][l];
+                    if constexpr (EPI <= 1) v += b;
+                    if constexpr (EPI == 1) v = fmaxf(v, 0.f);
+                    if constexpr (EPI == 3) {
+                        float m = mk[a][l];
+                        if (cut && l < 3) m = (pve[a][l] != 0xFFFFFFFFu) ? ms[a][l] : m;
+                        v = (m > 0.f) ? v : 0.f;
+                    }
+                    st[l] = v;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st), ry, cok ? (int)pv4[a] : -1, soff, 0);
+                // a 16-byte store reads its data registers for two more states: hipcc pads that against ITS next VALU, not against
+                // an inline-asm one (found the hard way: output (1, 1) of tile columns 12 .. 15 wrong, only with a bias)
+                asm volatile("s_nop 1" ::: "memory");
+                if (cut) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const float sv = e == 0 ? st[0] : e == 1 ? st[1] : st[2];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv), ry, cok ? (int)pve[a][e] : -1, soff, 0);
+                    }
+                }
+            }
+        });
+    };
+    if (epi == 0) store_rows(std::integral_constant<int, 0>{});
+    else if (epi == 1) store_rows(std::integral_constant<int, 1>{});
+    else if (epi == 2) store_rows(std::integral_constant<int, 2>{});
+    else store_rows(std::integral_constant<int, 3>{});
+}
+
+// U = G g G^T (6x6 per filter) laid out as the kernel's LDS image: [channel tile (64)][chunk (4 ci)][ci][position group 9][co 64]
+// [position in group 4].  mode as ptmi_conv3x3_pack_weights (1: dgrad -- transposed channels, flipped taps).
+__global__ void wino4_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int wCout, int wCin, int mode,
+                                          int coTiles, int nChunks)
+{
+    const int64_t total = (int64_t)coTiles * nChunks * XKC * XBM;
+    const int convCout = mode ? wCin : wCout, convCin = mode ? wCout : wCin;
+    const double G[6][3] = {{64.0 / 81.0, 0.0, 0.0},
+                            {-128.0 / 243.0, -32.0 / 81.0, -8.0 / 27.0},
+                            {-128.0 / 243.0, 32.0 / 81.0, -8.0 / 27.0},
+                            {32.0 / 243.0, 16.0 / 81.0, 8.0 / 27.0},
+                            {32.0 / 243.0, -16.0 / 81.0, 8.0 / 27.0},
+                            {0.0, 0.0, 1.0}};
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = idx;
+        const int col = t % XBM; t /= XBM;
+        const int cil = t % XKC; t /= XKC;
+        const int chunk = t % nChunks;
+        const int cot = t / nChunks;
+        const int co = cot * XBM + col, ci = chunk * XKC + cil;
+        double g[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float v = 0.f;
+                if (co < convCout && ci < convCin)
+                    v = mode == 0 ? w[((size_t)co * wCin + ci) * 9 + ky * 3 + kx]
+                                  : w[((size_t)ci * wCin + co) * 9 + (2 - ky) * 3 + (2 - kx)];
+                g[ky][kx] = (double)v;
+            }
+        }
+        double rr[6][3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) rr[i][kx] = G[i][0] * g[0][kx] + G[i][1] * g[1][kx] + G[i][2] * g[2][kx];
+        }
+        float* dst = wp + ((size_t)(cot * nChunks + chunk) * XKC + cil) * (9 * XBM * 4) + col * 4;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int p = 6 * i + j;
+                dst[(p >> 2) * (XBM * 4) + (p & 3)] = (float)(rr[i][0] * G[j][0] + rr[i][1] * G[j][1] + rr[i][2] * G[j][2]);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ptmi_conv3x3_wino4_packed_floats(int cin, int cout)
+{
+    return (int64_t)cdiv(cout, XBM) * cdiv(cin, XKC) * XUS;
+}
+
+int ptmi_conv3x3_wino4_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(w && wp && w_cout > 0 && w_cin > 0, "conv3x3_wino4_pack_weights: bad args");
+    const int convCout = mode ? w_cin : w_cout, convCin = mode ? w_cout : w_cin;
+    const int coTiles = cdiv(convCout, XBM), nChunks = cdiv(convCin, XKC);
+    const int64_t total = (int64_t)coTiles * nChunks * XKC * XBM;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(wino4_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, wp, w_cout, w_cin, mode,
+                       coTiles, nChunks);
+    PTMI_LAUNCH_CHECK("conv3x3_wino4_pack_weights");
+    return 0;
+}
+
+int ptmi_conv3x3_wino4_fwd_fits(int cin, int cout, int h, int w)
+{
+    if (cin <= 0 || cout <= 0 || h <= 0 || w <= 0 || (cin & 7)) return 0;       // chunks of 4 channels, walked in pairs
+    // a workgroup's 64 flat columns may reach into the strips of later images: per-lane offsets are relative to the first one
+    const int64_t img_span = XTW / ((w + 4) & ~3) + 2;
+    return (img_span * cin + XKC) * h * w * 4 < (1ll << 32) && (img_span * cout + XBM) * h * w * 4 < (1ll << 32);
+}
+
+int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
+                           int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino4_fwd: bad args");
+    PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_wino4_fwd: bad epilogue %d", epilogue);
+    PTMI_CHECK_ARG(!(cin & 7), "conv3x3_wino4_fwd: cin %d is not a multiple of 8 (use ptmi_conv3x3_wino_fwd)", cin);
+    PTMI_CHECK_ARG(ptmi_conv3x3_wino4_fwd_fits(cin, cout, h, w),
+                   "conv3x3_wino4_fwd: image too large for 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d)", n, cin,
+                   cout, h, w);
+    PTMI_CHECK_ARG(epilogue > 1 || bias, "conv3x3_wino4_fwd: bias required for epilogue %d", epilogue);
+    PTMI_CHECK_ARG(epilogue != 4 || bias, "conv3x3_wino4_fwd: bias required for epilogue 4");
+    PTMI_CHECK_ARG(epilogue != 3 || mask_ref, "conv3x3_wino4_fwd: mask_ref required for epilogue 3");
+    const int bands = cdiv(h, XTH), coTiles = cdiv(cout, XBM), nChunks = cin / XKC;
+    const int period = (w + 1 + 3) & ~3;                     // strip length: W + at least one zero column, a multiple of 4
+    const int64_t nPix = cdiv64((int64_t)n * bands * period, XTW);
+    PTMI_CHECK_ARG(nPix * XTW < (1ll << 31), "conv3x3_wino4_fwd: too many tiles");
+    const int colocate = coTiles <= 4;
+    const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;
+    PTMI_CHECK_ARG(nWg < (1ll << 31), "conv3x3_wino4_fwd: too many tiles");
+    hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)nWg), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
+                       cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate);
+    PTMI_LAUNCH_CHECK("conv3x3_wino4_fwd");
+    return 0;
+}
+
+}  // extern "C"

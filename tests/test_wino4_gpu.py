@@ -1,0 +1,127 @@
+"""GPU parity tests (pytest -m gpu) of the fused Winograd F(4x4,3x3) kernel (csrc/wino4.hip, round 5) through the C ABI: every
+epilogue, forward and dgrad packs, against stock torch CPU fp32 conv2d.
+
+Tolerance: 1e-4 relative + 1e-4 absolute on unit-scale outputs -- the SAME bar as the F(2x2,3x3) and direct kernels' tests
+(tests/test_wino_gpu.py); the kernel's interpolation points were chosen so that it passes it with margin (measured ~1e-5)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(a, b, rtol, atol, what=""):
+    a = a.detach().cpu().double().numpy()
+    b = b.detach().cpu().double().numpy()
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    assert (err <= tol).all(), f"{what}: max abs err {err.max():.3e}, max |ref| {np.abs(b).max():.3e}, " \
+                               f"{int((err > tol).sum())} of {err.size} off, first at {np.argwhere(err > tol)[0]}"
+    return float(err.max())
+
+
+def _wino4(x, wt, bias, mask, epilogue, mode=0):
+    """ptmi_conv3x3_wino4_pack_weights + ptmi_conv3x3_wino4_fwd on device tensors"""
+    from probabilisticteacher_amd import _lib, ops
+    call, ptr, stream = _lib.call, ops._ptr, ops._stream
+    co, ci = wt.shape[0], wt.shape[1]
+    conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
+    n, cin, h, w = x.shape
+    assert cin == conv_cin
+    wp = torch.empty(_lib.load().ptmi_conv3x3_wino4_packed_floats(conv_cin, conv_cout), device=DEV)
+    call("ptmi_conv3x3_wino4_pack_weights", ptr(wt), ptr(wp), co, ci, mode, stream())
+    y = torch.full((n, conv_cout, h // 2, w // 2) if epilogue == 4 else (n, conv_cout, h, w), float("nan"), device=DEV)
+    call("ptmi_conv3x3_wino4_fwd", ptr(x), ptr(wp), ptr(bias), ptr(mask), ptr(y), n, conv_cin, conv_cout, h, w, epilogue,
+         stream())
+    return y
+
+
+SHAPES = [
+    (1, 8, 64, 8, 64),        # two chunks, one workgroup, exact tile
+    (1, 16, 64, 8, 64),       # four chunks (stage rotation)
+    (1, 40, 64, 8, 64),       # ten chunks: every residue of the 3 slab stages / 4 patch stages
+    (2, 64, 64, 24, 72),      # several tiles, second tile column 8 wide
+    (2, 64, 128, 19, 35),     # odd H and W: tiles cut by the right edge, rows below the image
+    (1, 128, 256, 13, 33),
+    (1, 256, 512, 9, 83),     # W = 83 as the 1333x800 block-5 map
+    (1, 24, 70, 11, 17),      # output channel count that is not a multiple of the channel tile
+    (1, 32, 128, 5, 166),     # W = 166 / 333: 16-B pieces straddling the right image edge
+    (2, 32, 128, 3, 333),     # H = 3: the lower wave pair of every workgroup is idle
+    (1, 40, 130, 1, 70),      # a single row
+    (3, 32, 64, 4, 3),        # narrower than one 16-B piece
+    (1, 8, 7, 2, 1),          # one column
+    (1, 24, 64, 50, 83),      # the block-5 map itself
+    (3, 16, 48, 7, 21),       # workgroups straddling bands and images
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
+def test_wino4_forward_epilogues(n, cin, cout, h, w):
+    gen = g(n * 1000 + cin + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    b = torch.randn(cout, generator=gen) * 0.1
+    ref = F.conv2d(x, wt, b, padding=1)
+    xd, wd, bd = x.to(DEV), wt.to(DEV), b.to(DEV)
+    close(_wino4(xd, wd, bd, None, 0), ref, 1e-4, 1e-4, "epilogue 0 (bias)")
+    close(_wino4(xd, wd, bd, None, 1), F.relu(ref), 1e-4, 1e-4, "epilogue 1 (bias + relu)")
+    close(_wino4(xd, wd, None, None, 2), ref - b.view(1, -1, 1, 1), 1e-4, 1e-4, "epilogue 2 (none)")
+    if h >= 2 and w >= 2:
+        close(_wino4(xd, wd, bd, None, 4), F.max_pool2d(F.relu(ref), 2, 2), 1e-4, 1e-4, "epilogue 4 (bias + relu + pool)")
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
+def test_wino4_dgrad_with_relu_mask(n, cin, cout, h, w):
+    """dX = conv(dY, W^T flipped) (pack mode 1), plain (epilogue 2) and through the producer's ReLU mask (epilogue 3).
+    (The conv's input channel count is `cout` here: only shapes whose cout is a multiple of 8 are served.)"""
+    if cout % 8:
+        pytest.skip("dgrad contracts over cout: not a multiple of 8")
+    gen = g(7 + n * 1000 + cin + cout + h + w)
+    xr = torch.randn(n, cin, h, w, generator=gen).requires_grad_()
+    wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+    gy = torch.randn(n, cout, h, w, generator=gen)
+    F.conv2d(xr, wt, None, padding=1).backward(gy)
+    mask_src = torch.randn(n, cin, h, w, generator=gen)            # "activation of the producing layer"
+    got = _wino4(gy.to(DEV), wt.to(DEV), None, None, 2, mode=1)
+    close(got, xr.grad, 1e-4, 2e-4, "dgrad")
+    got3 = _wino4(gy.to(DEV), wt.to(DEV), None, mask_src.to(DEV), 3, mode=1)
+    close(got3, xr.grad * (mask_src > 0), 1e-4, 2e-4, "dgrad + relu mask")
+
+
+def test_wino4_rejects_channel_counts_it_does_not_serve():
+    from probabilisticteacher_amd import _lib
+    lib = _lib.load()
+    assert lib.ptmi_conv3x3_wino4_fwd_fits(20, 64, 8, 8) == 0 and lib.ptmi_conv3x3_wino4_fwd_fits(24, 64, 8, 8) == 1
+    x = torch.zeros(1, 20, 8, 8, device=DEV)
+    with pytest.raises(_lib.PtmiError):
+        _wino4(x, torch.zeros(64, 20, 3, 3, device=DEV), None, None, 2)
+
+
+def test_wino4_baseline_layer_shapes():
+    """One image of every distinct layer shape of the 1333x800 stack that the F(4x4,3x3) kernel may serve, against torch CPU on
+    border-including crops, + the measured error (printed: the margin to the 1e-4 bar)."""
+    worst = 0.0
+    for cin, cout, h, w in [(64, 64, 800, 1333), (128, 128, 400, 666), (256, 256, 200, 333), (512, 512, 100, 166),
+                            (512, 512, 50, 83)]:
+        gen = g(cin + h)
+        x = torch.relu(torch.randn(1, cin, h, w, generator=gen))
+        wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
+        b = torch.randn(cout, generator=gen) * 0.1
+        got = _wino4(x.to(DEV), wt.to(DEV), b.to(DEV), None, 1).cpu()
+        assert torch.isfinite(got).all()
+        for ys, xs in [(slice(0, 24), slice(0, 40)), (slice(h - 24, h), slice(w - 40, w)), (slice(h // 2 - 9, h // 2 + 9), slice(w - 45, w))]:
+            y0, y1 = max(ys.start - 1, 0), min(ys.stop + 1, h)
+            x0, x1 = max(xs.start - 1, 0), min(xs.stop + 1, w)
+            ref = F.relu(F.conv2d(x[:, :, y0:y1, x0:x1], wt, b, padding=1))
+            ref = ref[:, :, ys.start - y0: ys.start - y0 + (ys.stop - ys.start), xs.start - x0: xs.start - x0 + (xs.stop - xs.start)]
+            worst = max(worst, close(got[:, :, ys, xs], ref, 1e-4, 1e-4, f"layer {cin}->{cout} {h}x{w} crop {ys} {xs}"))
+    print(f"\n[wino4] worst abs error over the layer-shape crops: {worst:.2e} (bar 1e-4 + 1e-4 |ref|)")

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Time ptmi_conv3x3_wino_fwd (F(2x2,3x3)) against ptmi_conv3x3_wino4_fwd (F(4x4,3x3)) on BASELINE layer shapes (HIP events),
+and report the worst difference of the two outputs and (small n) the error of each against an fp64 convolution.
+    python tools/exp/wino4_bench.py [--n 16] [--layers conv3_2,conv4_2] [--epi 1] [--lib path.so]"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+LAYERS = {"conv1_2": (64, 64, 800, 1333), "conv2_1": (64, 128, 400, 666), "conv2_2": (128, 128, 400, 666),
+          "conv3_1": (128, 256, 200, 333), "conv3_2": (256, 256, 200, 333), "conv4_1": (256, 512, 100, 166),
+          "conv4_2": (512, 512, 100, 166), "conv5_1": (512, 512, 50, 83)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=16)
+    ap.add_argument("--layers", default=",".join(LAYERS))
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--epi", type=int, default=1)
+    ap.add_argument("--lib", default=None)
+    ap.add_argument("--only4", action="store_true")
+    a = ap.parse_args()
+    from probabilisticteacher_amd import _lib
+    lib = ctypes.CDLL(os.path.abspath(a.lib)) if a.lib else _lib.load()
+    vp = ctypes.c_void_p
+    for name in a.layers.split(","):
+        cin, cout, h, w = LAYERS[name]
+        gen = torch.Generator().manual_seed(1)
+        x = torch.relu(torch.randn(a.n, cin, h, w, generator=gen)).to("cuda:0")
+        wt = (torch.randn(cout, cin, 3, 3, generator=gen) * (2.0 / (9 * cin)) ** 0.5).to("cuda:0")
+        b = torch.zeros(cout, device="cuda:0")
+        fl = 2.0 * 9 * cin * cout * h * w * a.n
+        outs = {}
+        line = f"{name:8s} n={a.n:2d}"
+        for kind in (("wino4",) if a.only4 else ("wino", "wino4")):
+            pf = getattr(lib, f"ptmi_conv3x3_{kind}_packed_floats")
+            pf.restype = ctypes.c_int64
+            wp = torch.empty(pf(cin, cout), device="cuda:0")
+            st = vp(torch.cuda.current_stream().cuda_stream)
+            getattr(lib, f"ptmi_conv3x3_{kind}_pack_weights")(vp(wt.data_ptr()), vp(wp.data_ptr()), cout, cin, 0, st)
+            y = torch.empty(a.n, cout, h, w, device="cuda:0")
+            fwd = getattr(lib, f"ptmi_conv3x3_{kind}_fwd")
+
+            def f():
+                rc = fwd(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()), vp(x.data_ptr()), vp(y.data_ptr()), a.n, cin, cout, h, w,
+                         a.epi, st)
+                assert rc == 0, _lib.load().ptmi_last_error()
+            f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            outs[kind] = (y, ms)
+            line += f"  {kind}: {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s direct-eq"
+        if len(outs) == 2:
+            d = (outs["wino"][0] - outs["wino4"][0]).abs().max().item()
+            line += f"  speed-up {outs['wino'][1] / outs['wino4'][1]:.3f}  max |wino - wino4| {d:.2e} (max |y| {outs['wino'][0].abs().max().item():.2f})"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
