@@ -81,8 +81,8 @@ def cpu_baseline(h, w, K, seed=0, student_only=False):
                        f"1 unlabelled {w}x{h} image, {dt:.1f} s")}
 
 
-PMC_PROFILE = "profiles/r04_bench_b16_pmc_by_kernel.json"
-DOMINANT = "conv3x3_wino_kernel"          # the kernel the roofline object describes (its rocprofv3 name contains this)
+PMC_PROFILE = "profiles/r05_bench_b16_pmc_by_kernel.json"
+DOMINANT = "conv3x3_wino4_kernel"         # the kernel the roofline object describes (its rocprofv3 name contains this)
 DOMINANT_AMP = "p8_conv3x3_kernel"        # ... with --amp: the bf16-storage forward / dgrad kernel
 
 
@@ -295,7 +295,7 @@ def main():
         # the dominant kernel: the fused Winograd F(2x2,3x3) kernel (fp32 bench) / the bf16-storage direct kernel (--amp).
         # `achieved` / `frac` price the MFMA FLOPs the kernel ISSUES (never above the peak); the direct-convolution FLOPs the
         # same launches stand for are reported next to it as `effective_direct_tflops`
-        dom = "p8_conv3x3" if args.amp else "conv3x3_wino"
+        dom = "p8_conv3x3" if args.amp else "conv3x3_wino4"
         conv = prof.get(dom, {"ms": 0.0, "flops": 0.0, "issued": 0.0, "bytes": 0.0, "calls": 0})
         ach = conv["issued"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         eff = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
@@ -321,10 +321,12 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["calls"], 1),
                          "kernel": ("p8_conv3x3_kernel<MT> (bf16 storage: all 3x3 conv fwd + dgrad launches)" if args.amp else
-                                    "conv3x3_wino_kernel (fused Winograd F(2x2,3x3): every 3x3 conv fwd + dgrad launch with "
-                                    ">= 32 input channels; the 3-channel stem runs conv3x3_stem_kernel, listed under kernels)"),
-                         "achieved_is": "MFMA FLOPs issued by the kernel (16 multiplies per 2x2 tile and channel pair, tile "
-                                        "padding included) / HIP-event time; equals the direct FLOPs for the bf16 kernels",
+                                    "conv3x3_wino4_kernel (fused Winograd F(4x4,3x3), round 5: every 3x3 conv fwd + dgrad launch with "
+                                    ">= 64 input channels; the 3-channel stem runs conv3x3_stem_kernel, listed under kernels)"),
+                         "achieved_is": "MFMA FLOPs issued by the kernel (36 multiplies per 4x4 tile and channel pair -- a quarter of "
+                                        "the direct algorithm's 144 -- tile padding included) / HIP-event time; equals the direct "
+                                        "FLOPs for the bf16 kernels.  effective_direct_tflops prices the same launches by the direct "
+                                        "convolution's FLOPs (SURVEY 8d's per-image figure)",
                          "effective_direct_tflops": eff,
                          "effective_direct_over_peak": eff / peak,
                          "calls": conv["calls"],

@@ -193,19 +193,22 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
 
 
 # ============================================================================ conv 3x3
-# Forward / dgrad algorithm of the fp32 3x3 layers: "auto" = fused Winograd F(2x2,3x3) (csrc/wino.hip) wherever the
+# Forward / dgrad algorithm of the fp32 3x3 layers: "auto" = fused Winograd F(4x4,3x3) (csrc/wino4.hip, round 5) where the
+# input channel count is a multiple of 8 and >= 64, else fused Winograd F(2x2,3x3) (csrc/wino.hip) wherever the
 # input has enough channels to amortise its per-workgroup prologue, the direct implicit GEMM (csrc/conv.hip) for the
-# 3-channel stem; "direct" = the direct kernel everywhere (comparison runs, tests).  "bf16_emulate" keeps the direct
+# 3-channel stem; "wino2" = as "auto" without the F(4x4,3x3) kernel; "direct" = the direct kernel everywhere (comparison
+# runs, tests).  "bf16_emulate" keeps the direct
 # kernels (its parity statement -- products of rounded operands are exact in fp32 -- does not survive a transform); "bf16"
 # does not come here at all (p8.py).
 _CONV_ALGO = "auto"
 _WINO_MIN_CIN = 32
+_WINO4_MIN_CIN = 64
 _WINO_WGRAD_MIN_C = 64         # the wgrad workgroup owns 64 co x 64 ci
 
 
 def set_conv_algo(mode: str) -> None:
     global _CONV_ALGO
-    if mode not in ("auto", "direct"):
+    if mode not in ("auto", "wino2", "direct"):
         raise ValueError(f"unknown conv algorithm {mode!r}")
     _CONV_ALGO = mode
 
@@ -231,6 +234,26 @@ def wino_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
     return float(waves) * 2 * co_tiles * chunks * 4 * 16 * 4096
 
 
+@functools.lru_cache(maxsize=256)
+def wino4_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
+    """FLOPs of the v_mfma_f32_16x16x4_f32 instructions one ptmi_conv3x3_wino4_fwd launch issues: a wave runs 72 MFMAs
+    (2048 FLOP each: 36 positions x two 16-channel tiles) per 4-channel chunk for its 32 channels x 16 tiles (one tile row of
+    the FLAT tile line, csrc/wino4.hip); waves none of whose tiles lies inside an image issue none."""
+    import numpy as np
+    co_tiles, chunks, bands = -(-cout // 64), cin // 4, -(-h // 8)
+    period = (w + 4) & ~3
+    n_strips = n * bands
+    n_pix = -(-(n_strips * period) // 64)
+    tu = (np.arange(n_pix, dtype=np.int64)[:, None] * 64 + 4 * np.arange(16, dtype=np.int64)[None, :])
+    st, px = tu // period, tu % period
+    col_ok = (st < n_strips) & (px < w)
+    band = st % bands
+    waves = 0
+    for wn in (0, 1):
+        waves += int((col_ok & (band * 8 + 4 * wn < h)).any(axis=1).sum())
+    return float(waves) * 2 * co_tiles * chunks * 72 * 2048
+
+
 def wino_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
     """FLOPs of the MFMAs one ptmi_conv3x3_wino_wgrad launch issues: per 64 co x 64 ci pair and chunk (one tile row x KSN
     tile pairs; KSN = 7 or 8, whichever pads a tile row less -- csrc/wino.hip: wino_wgrad_ksn) KSN k-steps x 16 positions x
@@ -245,11 +268,36 @@ def wino_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> floa
 def _use_wino(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tuple[int, int]] = None) -> bool:
     """Winograd routing of a 3x3 layer: fp32, enough input channels, and -- when the caller knows the map size -- a shape
     that fits the kernel's 32-bit buffer offsets (ptmi_conv3x3_wino_fwd_fits; larger maps run the direct kernel)."""
-    if not (_CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and conv_cin >= _WINO_MIN_CIN):
+    if not (_CONV_ALGO in ("auto", "wino2") and _OPERAND_ROUNDING is None and conv_cin >= _WINO_MIN_CIN):
         return False
     if hw is None or conv_cout is None:
         return True
     return bool(_lib.load().ptmi_conv3x3_wino_fwd_fits(conv_cin, conv_cout, int(hw[0]), int(hw[1])))
+
+
+def _use_wino4(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tuple[int, int]] = None) -> bool:
+    """F(4x4,3x3) routing of a 3x3 layer (checked BEFORE _use_wino): fp32, input channels a multiple of 8 and >= 64, and -- when
+    the caller knows the map size -- a shape that fits the kernel's 32-bit buffer offsets (ptmi_conv3x3_wino4_fwd_fits)."""
+    if not (_CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and conv_cin >= _WINO4_MIN_CIN and conv_cin % 8 == 0):
+        return False
+    if hw is None or conv_cout is None:
+        return True
+    return bool(_lib.load().ptmi_conv3x3_wino4_fwd_fits(conv_cin, conv_cout, int(hw[0]), int(hw[1])))
+
+
+def _conv_kind(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tuple[int, int]] = None) -> str:
+    """'wino4' | 'wino' | 'mfma' (the direct kernel): the kernel family a forward / dgrad launch of this shape is routed to"""
+    if _use_wino4(conv_cin, conv_cout, hw):
+        return "wino4"
+    return "wino" if _use_wino(conv_cin, conv_cout, hw) else "mfma"
+
+
+_CONV_ABI = {"wino4": "ptmi_conv3x3_wino4", "wino": "ptmi_conv3x3_wino", "mfma": "ptmi_conv3x3"}
+
+
+def _conv_issued(kind: str, n: int, cin: int, cout: int, h: int, w: int):
+    return (wino4_issued_flops(n, cin, cout, h, w) if kind == "wino4" else
+            wino_issued_flops(n, cin, cout, h, w) if kind == "wino" else None)
 
 
 def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int, hw: Optional[Tuple[int, int]] = None) -> torch.Tensor:
@@ -260,14 +308,10 @@ def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int, hw: Optional[Tuple[i
     _chk(w, name="conv weight")
     co, ci = w.shape[0], w.shape[1]
     conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
-    if _use_wino(conv_cin, conv_cout, hw):
-        n = _lib.load().ptmi_conv3x3_wino_packed_floats(conv_cin, conv_cout)
-        wp = torch.empty(n, dtype=F32, device=w.device)
-        _lib.call("ptmi_conv3x3_wino_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
-        return wp
-    n = _lib.load().ptmi_conv3x3_packed_floats(conv_cin, conv_cout)
+    abi = _CONV_ABI[_conv_kind(conv_cin, conv_cout, hw)]
+    n = getattr(_lib.load(), abi + "_packed_floats")(conv_cin, conv_cout)
     wp = torch.empty(n, dtype=F32, device=w.device)
-    _lib.call("ptmi_conv3x3_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
+    _lib.call(abi + "_pack_weights", _ptr(w), _ptr(wp), co, ci, mode, _stream())
     return wp
 
 
@@ -278,18 +322,14 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
     n, cin, h, w = x.shape
     y = torch.empty((n, cout, h, w), dtype=F32, device=x.device)
     nbytes = 4.0 * (n * h * w * (cin + cout * (2 if epilogue == 3 else 1)) + 9 * cin * cout)
-    wino = _use_wino(cin, cout, (h, w))
-    want = (_lib.load().ptmi_conv3x3_wino_packed_floats if wino else _lib.load().ptmi_conv3x3_packed_floats)(cin, cout)
+    kind = _conv_kind(cin, cout, (h, w))
+    abi = _CONV_ABI[kind]
+    want = getattr(_lib.load(), abi + "_packed_floats")(cin, cout)
     if wp.numel() != want:
-        raise _lib.PtmiError(f"conv3x3_raw: packed weights have {wp.numel()} floats, the {'Winograd' if wino else 'direct'} "
-                             f"kernel this {h}x{w} map is routed to takes {want} (pass hw=(H, W) to conv3x3_pack)")
-    if wino:
-        with _prof("conv3x3_wino", 2.0 * 9 * cin * cout * h * w * n, nbytes, wino_issued_flops(n, cin, cout, h, w)):
-            _lib.call("ptmi_conv3x3_wino_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
-                      epilogue, _stream())
-        return y
-    with _prof("conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n, nbytes):
-        _lib.call("ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w, epilogue, _stream())
+        raise _lib.PtmiError(f"conv3x3_raw: packed weights have {wp.numel()} floats, the {kind} kernel this {h}x{w} map is "
+                             f"routed to takes {want} (pass hw=(H, W) to conv3x3_pack)")
+    with _prof("conv3x3_" + kind, 2.0 * 9 * cin * cout * h * w * n, nbytes, _conv_issued(kind, n, cin, cout, h, w)):
+        _lib.call(abi + "_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w, epilogue, _stream())
     return y
 
 
@@ -303,11 +343,10 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     cout = weight.shape[0]
     wp = conv3x3_pack(_chk(_rnd(weight).contiguous()), 0, 4, (h, w))
     y = torch.empty((n, cout, h // 2, w // 2), dtype=F32, device=x.device)
-    wino = _use_wino(cin, cout, (h, w))
-    with _prof("conv3x3_wino" if wino else "conv3x3_mfma", 2.0 * 9 * cin * cout * h * w * n,
-               4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout),
-               wino_issued_flops(n, cin, cout, h, w) if wino else None):
-        _lib.call("ptmi_conv3x3_wino_fwd" if wino else "ptmi_conv3x3_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None,
+    kind = _conv_kind(cin, cout, (h, w))
+    with _prof("conv3x3_" + kind, 2.0 * 9 * cin * cout * h * w * n, 4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout),
+               _conv_issued(kind, n, cin, cout, h, w)):
+        _lib.call(_CONV_ABI[kind] + "_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None,
                   _ptr(y), n, cin, cout, h, w, 4, _stream())
     return _rnd_stored(y)
 

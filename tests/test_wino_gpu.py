@@ -110,7 +110,9 @@ def test_wino_ragged_channels_do_not_read_the_next_image():
 
 
 def test_wino_equals_direct_kernel_closely():
-    """Same inputs through both algorithms (ops.set_conv_algo): forward, dgrad and the fused block agree to fp32 rounding."""
+    """Same inputs through the algorithms (ops.set_conv_algo): forward and dgrad of F(2x2,3x3) ("wino2") agree with the direct
+    kernel to fp32 rounding (1e-5); F(4x4,3x3) ("auto" since round 5 for this channel count) agrees at the parity bar of every
+    conv test, 1e-4 (its transforms multiply by constants up to 3.4: measured 1-3e-5, tests/test_wino4_gpu.py)."""
     from probabilisticteacher_amd import ops
     gen = g(3)
     x = torch.randn(2, 64, 45, 70, generator=gen).to(DEV)
@@ -119,7 +121,7 @@ def test_wino_equals_direct_kernel_closely():
     gy = torch.randn(2, 128, 45, 70, generator=gen).to(DEV)
     outs = {}
     try:
-        for algo in ("auto", "direct"):
+        for algo in ("auto", "wino2", "direct"):
             ops.set_conv_algo(algo)
             xd = x.clone().requires_grad_()
             y = ops.conv3x3(xd, wt, b, True)
@@ -127,8 +129,10 @@ def test_wino_equals_direct_kernel_closely():
             outs[algo] = (y.detach(), xd.grad)
     finally:
         ops.set_conv_algo("auto")
-    close(outs["auto"][0], outs["direct"][0], 1e-5, 2e-5, "forward wino vs direct")
-    close(outs["auto"][1], outs["direct"][1], 1e-5, 2e-5, "dgrad wino vs direct")
+    close(outs["wino2"][0], outs["direct"][0], 1e-5, 2e-5, "forward wino vs direct")
+    close(outs["wino2"][1], outs["direct"][1], 1e-5, 2e-5, "dgrad wino vs direct")
+    close(outs["auto"][0], outs["direct"][0], 1e-4, 1e-4, "forward wino4 vs direct")
+    close(outs["auto"][1], outs["direct"][1], 1e-4, 1e-4, "dgrad wino4 vs direct")
 
 
 def test_wino_baseline_layer_shapes():
@@ -215,8 +219,18 @@ def test_wino_wgrad_layer_shape_vs_direct_kernel():
 
 def test_training_step_runs_on_the_winograd_kernels():
     """Routing guard: one fp32 VGG block forward + backward through the production autograd nodes launches the Winograd forward /
-    dgrad and weight-gradient kernels (and no direct conv kernel), and their issued-FLOP models are the ones the bench reports."""
+    dgrad and weight-gradient kernels (and no direct conv kernel), and their issued-FLOP models are the ones the bench reports.
+    Round 5: "auto" routes forward / dgrad of these channel counts to the F(4x4,3x3) kernel, "wino2" to F(2x2,3x3)."""
     from probabilisticteacher_amd import ops
+    for algo, key, issued in (("auto", "conv3x3_wino4", ops.wino4_issued_flops), ("wino2", "conv3x3_wino", ops.wino_issued_flops)):
+        ops.set_conv_algo(algo)
+        try:
+            _routing_guard(ops, key, issued)
+        finally:
+            ops.set_conv_algo("auto")
+
+
+def _routing_guard(ops, key, issued_flops):
     gen = g(21)
     x = torch.randn(2, 64, 40, 83, generator=gen).to(DEV).requires_grad_()
     w1 = (torch.randn(128, 64, 3, 3, generator=gen) * 0.05).to(DEV).requires_grad_()
@@ -227,9 +241,9 @@ def test_training_step_runs_on_the_winograd_kernels():
     y = ops.conv3x3(ops.conv3x3(x, w1, b1, True), w2, b2, True)
     y.sum().backward()
     prof = ops.profile_stop()
-    assert prof["conv3x3_wino"]["calls"] == 4 and prof["conv3x3_wino_wgrad"]["calls"] == 2, prof.keys()
+    assert prof[key]["calls"] == 4 and prof["conv3x3_wino_wgrad"]["calls"] == 2, prof.keys()
     assert "conv3x3_mfma" not in prof and "conv3x3_wgrad" not in prof
-    assert prof["conv3x3_wino"]["issued"] == 2 * ops.wino_issued_flops(2, 64, 128, 40, 83) + 2 * ops.wino_issued_flops(2, 128, 128, 40, 83)
+    assert prof[key]["issued"] == 2 * issued_flops(2, 64, 128, 40, 83) + 2 * issued_flops(2, 128, 128, 40, 83)
     assert prof["conv3x3_wino_wgrad"]["issued"] == ops.wino_wgrad_issued_flops(2, 64, 128, 40, 83) + ops.wino_wgrad_issued_flops(2, 128, 128, 40, 83)
     ref = F.relu(F.conv2d(F.relu(F.conv2d(x.detach().cpu(), w1.detach().cpu(), None, padding=1)), w2.detach().cpu(), None, padding=1))
     close(y, ref, 1e-4, 1e-4, "two-layer block")
