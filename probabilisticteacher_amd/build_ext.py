@@ -20,8 +20,9 @@ SOURCES = ["abi.cpp", "conv.hip", "wino.hip", "wino4.hip", "p8.hip", "p8gemm.hip
 # CPU reference does.  -munsafe-fp-atomics: hardware fp32 atomic add for the ROIAlign backward scatter.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
-# per-file extra flags (none at present)
-FILE_FLAGS = {}
+# per-file extra flags.  wino4.hip: its transforms are scalar FMA sequences the SLP vectoriser would turn into v_pk_fma_f32 +
+# register shuffles (slower next to MFMAs)
+FILE_FLAGS = {"wino4.hip": ["-fno-slp-vectorize"]}
 
 
 def _deps_mtime():

@@ -69,29 +69,31 @@ constexpr int XLDS = XNU * XUS + XNP * XPSP;   // 39936 floats = 159744 B
 constexpr float XA = 0.75f, XB = 1.5f, XA2 = 0.5625f, XB2 = 2.25f, XA3 = 0.421875f, XB3 = 3.375f;
 constexpr float XA2B2 = 1.265625f, XS2 = 2.8125f;      // a^2 b^2, a^2 + b^2
 
-// r = c * x + y / r = -c * x + y with the constant in an SGPR: one VOP3 each, opaque to the SLP vectoriser (which otherwise
-// builds v_pk_fma_f32 out of register shuffles -- slower than two scalar FMAs next to MFMAs on this part)
-__device__ __forceinline__ float xfma(float c, float x, float y) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(c), "v"(x), "v"(y)); return r; }
-__device__ __forceinline__ float xfnma(float c, float x, float y) { float r; asm volatile("v_fma_f32 %0, -%1, %2, %3" : "=v"(r) : "s"(c), "v"(x), "v"(y)); return r; }
-__device__ __forceinline__ float xadd(float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
-__device__ __forceinline__ float xsub(float x, float y) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; }
-__device__ __forceinline__ float xmul(float c, float x) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "s"(c), "v"(x)); return r; }
+// r = c * x + y / r = -c * x + y: explicit FMAs (the file is built with -fno-slp-vectorize: the SLP vectoriser otherwise builds
+// v_pk_fma_f32 out of register shuffles -- slower than two scalar FMAs next to MFMAs on this part; inline-asm FMAs cost a
+// compiler-inserted s_nop after every dependent pair)
+__device__ __forceinline__ float xfma(float c, float x, float y) { return __builtin_fmaf(c, x, y); }
+__device__ __forceinline__ float xfnma(float c, float x, float y) { return __builtin_fmaf(-c, x, y); }
+__device__ __forceinline__ float xadd(float x, float y) { return x + y; }
+__device__ __forceinline__ float xsub(float x, float y) { return x - y; }
+__device__ __forceinline__ float xmul(float c, float x) { return c * x; }
 
 // 1-D input transform t = B^T d: operation k of 12 (so that a slot can carry any sub-range of them).  E[] are the four
 // intermediates (even / odd parts at +-a and +-b).
+// operations 0 .. 5 are independent of each other, 6 .. 11 depend only on 0 .. 5: no back-to-back dependent FMAs
 template <int K>
 __device__ __forceinline__ void xin_op(const float (&d)[6], float (&t)[6], float (&E)[4])
 {
     if constexpr (K == 0) t[0] = xfnma(XS2, d[2], d[4]);
-    if constexpr (K == 1) t[0] = xfma(XA2B2, d[0], t[0]);
-    if constexpr (K == 2) t[5] = xfnma(XS2, d[3], d[5]);
-    if constexpr (K == 3) t[5] = xfma(XA2B2, d[1], t[5]);
-    if constexpr (K == 4) E[0] = xfnma(XB2, d[2], d[4]);        // even part at +-a
-    if constexpr (K == 5) E[1] = xfnma(XB2, d[1], d[3]);        // odd part at +-a (before the factor a)
-    if constexpr (K == 6) t[1] = xfma(XA, E[1], E[0]);
-    if constexpr (K == 7) t[2] = xfnma(XA, E[1], E[0]);
-    if constexpr (K == 8) E[2] = xfnma(XA2, d[2], d[4]);
-    if constexpr (K == 9) E[3] = xfnma(XA2, d[1], d[3]);
+    if constexpr (K == 1) t[5] = xfnma(XS2, d[3], d[5]);
+    if constexpr (K == 2) E[0] = xfnma(XB2, d[2], d[4]);        // even part at +-a
+    if constexpr (K == 3) E[1] = xfnma(XB2, d[1], d[3]);        // odd part at +-a (before the factor a)
+    if constexpr (K == 4) E[2] = xfnma(XA2, d[2], d[4]);
+    if constexpr (K == 5) E[3] = xfnma(XA2, d[1], d[3]);
+    if constexpr (K == 6) t[0] = xfma(XA2B2, d[0], t[0]);
+    if constexpr (K == 7) t[5] = xfma(XA2B2, d[1], t[5]);
+    if constexpr (K == 8) t[1] = xfma(XA, E[1], E[0]);
+    if constexpr (K == 9) t[2] = xfnma(XA, E[1], E[0]);
     if constexpr (K == 10) t[3] = xfma(XB, E[3], E[2]);
     if constexpr (K == 11) t[4] = xfnma(XB, E[3], E[2]);
 }
@@ -211,14 +213,14 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
 
     float* const ldsU = lds;
     float* const ldsP = lds + XNU * XUS;
-    auto dma_patch = [&](int i, int stage) __attribute__((always_inline)) {
+    auto dma_patch = [&](int i, int stage /* float offset of the stage */) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
             ptmi_uniform_ptr(xc), 0, __builtin_amdgcn_readfirstlane((int)xleft), 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (xlds_void_t*)(ldsP + stage * XPSP + wave * 256 + i * XNT * 4), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (xlds_void_t*)(ldsP + stage + wave * 256 + i * XNT * 4), 16,
                                                  (int)pvoff[i], 0, 0, 0);
     };
     auto dma_u = [&](int i, int stage) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (xlds_void_t*)(ldsU + stage * XUS + wave * 256 + i * XNT * 4), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (xlds_void_t*)(ldsU + stage + wave * 256 + i * XNT * 4), 16,
                                                  (int)wv, i * XNT * 16, 0, 0);
     };
     auto advance_patch = [&]() __attribute__((always_inline)) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     auto advance_u = [&]() __attribute__((always_inline)) { wv += XUS * 4; };
     auto fixup = [&](int stage) __attribute__((always_inline)) {
         if (edge && fix) {
-            float* pw = ldsP + stage * XPSP + tid * 4;
+            float* pw = ldsP + stage + tid * 4;
 #pragma unroll
             for (int i = 0; i < XPI; ++i) {
 #pragma unroll
@@ -286,9 +288,9 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     };
     issue_patch(0);
     issue_u(0);
-    issue_patch(1);
-    issue_u(1);
-    issue_patch(2);
+    issue_patch(XPSP);
+    issue_u(XUS);
+    issue_patch(2 * XPSP);
     // the accumulators, zeroed while the first pieces are in flight (the wave would sit in the wait below anyway)
     f32x4 accA[64];                        // positions 0 .. 31 (x 2 channel tiles): AGPRs
     f32x4 accV[8];                         // positions 32 .. 35: VGPRs
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     });
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
     fixup(0);
-    fixup(1);
+    fixup(XPSP);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     if (active) {
@@ -350,15 +352,22 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         f32x4 A[3];
         A[0] = *(const volatile xlds_f32x4_t*)(ldsU + a_off);
         A[1] = *(const volatile xlds_f32x4_t*)(ldsU + a_off + 64);
-        auto chunk = [&](auto par_c, int c) __attribute__((always_inline)) {
+        // float offsets of the slab stage of chunk c / c + 1 / c + 2 and of the patch stage of chunk c + 1 / c + 2 / c + 3, rotated
+        // by compare-and-select (a modulo costs a dozen scalar instructions each)
+        int uo0 = 0, uo1 = XUS, uo2 = 2 * XUS, po1 = XPSP, po2 = 2 * XPSP, po3 = 3 * XPSP;
+        auto chunk = [&](auto par_c) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_c)::value;
             float(&Vc)[36] = PAR ? V1 : V0;
             float(&Vn)[36] = PAR ? V0 : V1;
-            const int uc = c % XNU, un = (c + 1) % XNU, ud = (c + 2) % XNU;
-            const int pr = (c + 1) % XNP, pf = (c + 2) % XNP, pd = (c + 3) % XNP;
-            const float* ap = ldsU + uc * XUS + a_off;
-            const float* apn = ldsU + un * XUS + a_off;
-            const float* pb = ldsP + pr * XPSP + b_off;
+            const float* ap = ldsU + uo0 + a_off;
+            const float* apn = ldsU + uo1 + a_off;
+            const float* pb = ldsP + po1 + b_off;
+            const int ud = uo2, pf = po2, pd = po3;
+            {
+                const int t = uo0; uo0 = uo1; uo1 = uo2; uo2 = t;
+                const int q = po3 + XPSP == XNP * XPSP ? 0 : po3 + XPSP;
+                po1 = po2; po2 = po3; po3 = q;
+            }
             {   // one address register each for the chunk's A reads and window reads (immediate offsets)
                 unsigned va = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)ap;
                 unsigned vn = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)apn;
@@ -372,51 +381,51 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
                 constexpr int S = decltype(s_c)::value;
                 constexpr int hg = S >> 2, g = S >> 3, ct = hg & 1, q = S & 3, p = 4 * g + q;
                 const float av = A[hg % 3][q], bvv = Vc[p];
-                if constexpr (p < 32) xmfma_a(accA[2 * p + ct], av, bvv);
-                else xmfma_v(accV[2 * (p - 32) + ct], av, bvv);
+                if constexpr (p < 32) xmfma_a(accA[2 * p + ct], av, bvv);   // [x4:mf]
+                else xmfma_v(accV[2 * (p - 32) + ct], av, bvv);   // [x4:mf]
                 if constexpr (q == 1) {                      // half-group hg + 2 (of this chunk, or 0 / 1 of the next one)
                     constexpr int h2 = hg + 2;
-                    if constexpr (h2 < 18) A[h2 % 3] = *(const volatile xlds_f32x4_t*)(ap + (h2 >> 1) * 256 + (h2 & 1) * 64);
-                    else A[h2 % 3] = *(const volatile xlds_f32x4_t*)(apn + (h2 & 1) * 64);
+                    if constexpr (h2 < 18) A[h2 % 3] = *(const volatile xlds_f32x4_t*)(ap + (h2 >> 1) * 256 + (h2 & 1) * 64);   // [x4:ar]
+                    else A[h2 % 3] = *(const volatile xlds_f32x4_t*)(apn + (h2 & 1) * 64);   // [x4:ar]
                 }
                 if constexpr (S == XHAND) {
                     // everything but the 12 newest DMA instructions (this chunk's) has landed: slab c + 1, patch c + 2
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
-                    fixup(pf);
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");   // [x4:ho]
+                    fixup(pf);   // [x4:ho]
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // [x4:ho]
                 }
                 constexpr int wr = x_wread_at(S);
-                if constexpr (wr >= 0) wread(std::integral_constant<int, (wr >= 0 ? wr : 0)>{}, pb);
+                if constexpr (wr >= 0) wread(std::integral_constant<int, (wr >= 0 ? wr : 0)>{}, pb);   // [x4:wr]
                 constexpr int di = x_dma_at(S);
                 if constexpr (di >= 0) {
-                    if constexpr (di < XUI) dma_u(di, ud);
-                    else dma_patch(di - XUI, pd);
+                    if constexpr (di < XUI) dma_u(di, ud);   // [x4:dma]
+                    else dma_patch(di - XUI, pd);   // [x4:dma]
                     if constexpr (di == XUI - 1) advance_u();
                     if constexpr (di == XDI - 1) advance_patch();
                 }
                 constexpr int h0 = x_hop_lo(S), h1 = x_hop_lo(S + 1);
-                xfor(std::make_integer_sequence<int, h1 - h0>{}, [&](auto k_c) __attribute__((always_inline)) { hop(std::integral_constant<int, h0 + decltype(k_c)::value>{}); });
+                xfor(std::make_integer_sequence<int, h1 - h0>{}, [&](auto k_c) __attribute__((always_inline)) { hop(std::integral_constant<int, h0 + decltype(k_c)::value>{}); });   // [x4:xf]
                 constexpr int v0 = x_vop_lo(S), v1 = x_vop_lo(S + 1);
-                xfor(std::make_integer_sequence<int, v1 - v0>{}, [&](auto k_c) __attribute__((always_inline)) { vop(std::integral_constant<int, v0 + decltype(k_c)::value>{}, Vn); });
+                xfor(std::make_integer_sequence<int, v1 - v0>{}, [&](auto k_c) __attribute__((always_inline)) { vop(std::integral_constant<int, v0 + decltype(k_c)::value>{}, Vn); });   // [x4:xf]
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
         for (int c = 0; c < nChunks; c += 2) {              // nChunks is even (launcher: Cin % 8 == 0)
-            chunk(std::integral_constant<int, 0>{}, c);
-            chunk(std::integral_constant<int, 1>{}, c + 1);
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filled pieces of the chunks that do not exist
     } else {
         // a wave whose rows all lie below the image: the same DMA issue / wait / barrier sequence, no MFMAs
         for (int c = 0; c < nChunks; ++c) {
 #pragma unroll
-            for (int i = 0; i < XUI; ++i) dma_u(i, (c + 2) % XNU);
+            for (int i = 0; i < XUI; ++i) dma_u(i, ((c + 2) % XNU) * XUS);
             advance_u();
 #pragma unroll
-            for (int i = 0; i < XPI; ++i) dma_patch(i, (c + 3) % XNP);
+            for (int i = 0; i < XPI; ++i) dma_patch(i, ((c + 3) % XNP) * XPSP);
             advance_patch();
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
-            fixup((c + 2) % XNP);
+            fixup(((c + 2) % XNP) * XPSP);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Timing variants of the F(4x4,3x3) kernel (results WRONG by design): copies of csrc/wino4.hip with the lines tagged
+`// [x4:<part>]` removed, built into tools/exp/_bin/libptmi355_w4_<name>.so (the other objects are the product's).
+
+    python tools/exp/make_wino4_variant.py base none   noxf xf   nowr wr   noar ar   nodma dma   noho ho   nomf mf   mfonly xf,wr,ar,dma,ho
+    (on the GPU box)  python tools/exp/wino4_bench.py --only4 --lib tools/exp/_bin/libptmi355_w4_noxf.so --layers conv3_2
+
+parts: mf = the MFMAs, xf = the input transforms' FMAs, wr = window reads, ar = A-operand reads, dma = the LDS-DMA instructions,
+ho = the hand-over (counted vmcnt, fix-ups, barrier).  The `else` of a removed `if constexpr` pair goes with it."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SRC = os.path.join(ROOT, "probabilisticteacher_amd", "csrc", "wino4.hip")
+BIN = os.path.join(ROOT, "tools", "exp", "_bin")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wno-unused-result",
+         "-Wno-uninitialized", "-Wno-sometimes-uninitialized"]
+
+
+def main():
+    os.makedirs(BIN, exist_ok=True)
+    subprocess.check_call([sys.executable, "-m", "probabilisticteacher_amd.build_ext"], cwd=ROOT, stdout=subprocess.DEVNULL)
+    objs = [os.path.join(ROOT, "probabilisticteacher_amd", "_build", f)
+            for f in os.listdir(os.path.join(ROOT, "probabilisticteacher_amd", "_build")) if f.endswith(".o") and f != "wino4.o"]
+    args = sys.argv[1:]
+    extra = []
+    while args and args[0].startswith("-"):
+        extra.append(args.pop(0))
+    src = open(os.environ.get("W4SRC", SRC)).read().splitlines()
+    for name, parts in zip(args[0::2], args[1::2]):
+        drop = set() if parts == "none" else set(parts.split(","))
+        out = [ln for ln in src if not any(f"[x4:{p}]" in ln for p in drop)]
+        tmp = os.path.join(ROOT, "probabilisticteacher_amd", "csrc", f"_w4_{name}.hip")
+        open(tmp, "w").write("\n".join(out) + "\n")
+        try:
+            obj = os.path.join(BIN, f"w4_{name}.o")
+            subprocess.check_call(["hipcc"] + FLAGS + extra + ["-c", tmp, "-o", obj])
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                                   os.path.join(BIN, f"libptmi355_w4_{name}.so")] + objs + [obj])
+        finally:
+            os.remove(tmp)
+        print("built", name, "without", sorted(drop))
+
+
+if __name__ == "__main__":
+    main()
