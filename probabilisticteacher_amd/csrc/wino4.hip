@@ -118,32 +118,37 @@ __device__ __forceinline__ void xfor(std::integer_sequence<int, I...>, F&& f) { 
 // ---- the chunk schedule (compile-time tables; slot S = 8 g + 4 ct + q runs the MFMA of position 4 g + q, channel tile ct)
 constexpr int XHAND = 60;                                   // hand-over slot
 __host__ __device__ constexpr bool x_is_aread(int s) { return (s & 3) == 1; }
+__host__ __device__ constexpr bool x_is_dma(int s);
 // the k-th slot (k = 0 ..) that carries neither an A read nor the hand-over, from slot 2 on
 __host__ __device__ constexpr int x_free_slot(int k)
 {
     int s = 2;
     for (;; ++s) {
-        if (x_is_aread(s) || s == XHAND) continue;
+        if (x_is_aread(s) || x_is_dma(s) || s == XHAND) continue;
         if (k-- == 0) return s;
     }
 }
-// window read r (0 .. 17: row r / 3, part r % 3) sits in the r-th free slot; DMA instruction i in slot 26 + 2 i
+// window read r (0 .. 17: row r / 3, part r % 3) sits in the r-th free slot.  DMA instruction i in slot 5 + 6 i: the twelve
+// pieces of a chunk spread EVENLY over its 72 slots -- the L2 -> LDS path moves a chunk's 48 KB in ~1570 cycles (DMA-only
+// variant of tools/exp/make_wino4_variant.py: 30 B/clk/CU), two thirds of the chunk's MFMA time, and a burst (round 5's first
+// version: 12 instructions in 24 slots) stalls the issuing wave behind its own queue
+__host__ __device__ constexpr bool x_is_dma(int s) { return s % 6 == 5; }
+__host__ __device__ constexpr int x_dma_at(int s) { return x_is_dma(s) ? s / 6 : -1; }
+__host__ __device__ constexpr int x_dma_before(int s) { return (s + 0) / 6; }   // DMA instructions of this chunk issued before slot s
 __host__ __device__ constexpr int x_wread_at(int s)
 {
     for (int r = 0; r < 18; ++r)
         if (x_free_slot(r) == s) return r;
     return -1;
 }
-__host__ __device__ constexpr int x_dma_at(int s) { return (s >= 26 && s < 26 + 2 * XDI && !(s & 1)) ? (s - 26) / 2 : -1; }
-// horizontal-transform operation h (0 .. 71: window row h / 12, operation h % 12) in slot 9 + h / 2; vertical operation v
-// (0 .. 71: column v / 12) in slot 45 + 3 v / 8
-__host__ __device__ constexpr int x_hop_lo(int s) { return s < 9 ? 0 : (s - 9) * 2 > 72 ? 72 : (s - 9) * 2; }
-__host__ __device__ constexpr int x_vop_lo(int s)
+// the 144 transform FMAs (0 .. 71 horizontal: window row k / 12; 72 .. 143 vertical: column (k - 72) / 12), three per slot in the
+// slots from 9 on that carry neither a DMA instruction nor the hand-over
+__host__ __device__ constexpr int x_valu_before(int s)
 {
-    if (s < 45) return 0;
-    int v = 0;
-    while (v < 72 && 45 + 3 * v / 8 < s) ++v;
-    return v;
+    int n = 0;
+    for (int t = 9; t < s && t < 72; ++t)
+        if (!x_is_dma(t) && t != XHAND) n += 3;
+    return n > 144 ? 144 : n;
 }
 
 template <bool RAGGED_UNUSED>
@@ -389,8 +394,8 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
                     else A[h2 % 3] = *(const volatile xlds_f32x4_t*)(apn + (h2 & 1) * 64);   // [x4:ar]
                 }
                 if constexpr (S == XHAND) {
-                    // everything but the 12 newest DMA instructions (this chunk's) has landed: slab c + 1, patch c + 2
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");   // [x4:ho]
+                    // everything but this chunk's DMA instructions so far (10 of its 12) has landed: slab c + 1, patch c + 2
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(x_dma_before(XHAND)) : "memory");   // [x4:ho]
                     fixup(pf);   // [x4:ho]
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // [x4:ho]
                 }
@@ -403,10 +408,12 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
                     if constexpr (di == XUI - 1) advance_u();
                     if constexpr (di == XDI - 1) advance_patch();
                 }
-                constexpr int h0 = x_hop_lo(S), h1 = x_hop_lo(S + 1);
-                xfor(std::make_integer_sequence<int, h1 - h0>{}, [&](auto k_c) __attribute__((always_inline)) { hop(std::integral_constant<int, h0 + decltype(k_c)::value>{}); });   // [x4:xf]
-                constexpr int v0 = x_vop_lo(S), v1 = x_vop_lo(S + 1);
-                xfor(std::make_integer_sequence<int, v1 - v0>{}, [&](auto k_c) __attribute__((always_inline)) { vop(std::integral_constant<int, v0 + decltype(k_c)::value>{}, Vn); });   // [x4:xf]
+                constexpr int k0 = x_valu_before(S), k1 = x_valu_before(S + 1);
+                xfor(std::make_integer_sequence<int, k1 - k0>{}, [&](auto k_c) __attribute__((always_inline)) {
+                    constexpr int k = k0 + decltype(k_c)::value;
+                    if constexpr (k < 72) hop(std::integral_constant<int, (k < 72 ? k : 0)>{});   // [x4:xf]
+                    else vop(std::integral_constant<int, (k >= 72 ? k - 72 : 0)>{}, Vn);   // [x4:xf]
+                });
                 __builtin_amdgcn_sched_barrier(0);
             });
         };

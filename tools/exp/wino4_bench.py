@@ -23,11 +23,16 @@ def main():
     ap.add_argument("--epi", type=int, default=1)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--only4", action="store_true")
+    ap.add_argument("--custom", action="append", default=[], help="name=cin,cout,h,w (repeatable)")
+    ap.add_argument("--reps", type=int, default=3, help="timed repetitions; the minimum is reported")
     a = ap.parse_args()
     from probabilisticteacher_amd import _lib
     lib = ctypes.CDLL(os.path.abspath(a.lib)) if a.lib else _lib.load()
     vp = ctypes.c_void_p
-    for name in a.layers.split(","):
+    for c in a.custom:
+        nm, v = c.split("=")
+        LAYERS[nm] = tuple(int(t) for t in v.split(","))
+    for name in ([c.split("=")[0] for c in a.custom] if a.custom else a.layers.split(",")):
         cin, cout, h, w = LAYERS[name]
         gen = torch.Generator().manual_seed(1)
         x = torch.relu(torch.randn(a.n, cin, h, w, generator=gen)).to("cuda:0")
@@ -51,13 +56,15 @@ def main():
                 assert rc == 0, _lib.load().ptmi_last_error()
             f()
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(a.iters):
-                f()
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / a.iters
+            ms = 1e9
+            for _ in range(a.reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = min(ms, e0.elapsed_time(e1) / a.iters)
             outs[kind] = (y, ms)
             line += f"  {kind}: {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s direct-eq"
         if len(outs) == 2:
