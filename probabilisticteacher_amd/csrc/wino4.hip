@@ -116,7 +116,8 @@ template <int... I, class F>
 __device__ __forceinline__ void xfor(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 // ---- the chunk schedule (compile-time tables; slot S = 8 g + 4 ct + q runs the MFMA of position 4 g + q, channel tile ct)
-constexpr int XHAND = 60;                                   // hand-over slot
+constexpr int XHAND = 64;                                   // hand-over slot: after the chunk's last A read (slot 61; three slots: it has
+                                                             // landed when the hand-over drains lgkmcnt), before the next chunk's first (65)
 __host__ __device__ constexpr bool x_is_aread(int s) { return (s & 3) == 1; }
 __host__ __device__ constexpr bool x_is_dma(int s);
 // the k-th slot (k = 0 ..) that carries neither an A read nor the hand-over, from slot 2 on
@@ -151,70 +152,113 @@ __host__ __device__ constexpr int x_valu_before(int s)
     return n > 144 ? 144 : n;
 }
 
-template <bool RAGGED_UNUSED>
 __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi,
-    int coTiles, int bands, int period, int nPix, int colocate)
+    int coTiles, int bands, int period, int nPix, int colocate, int nTiles)
 {
     __shared__ __attribute__((aligned(16))) float lds[XLDS];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup -> (channel tile, pixel tile): as wino.hip (colocate: the channel tiles of a pixel tile back to back on one XCD)
-    int cot, pix;
-    if (colocate) {
-        const int slot = blockIdx.x >> 3;
-        cot = slot % coTiles;
-        pix = (slot / coTiles) * 8 + (blockIdx.x & 7);
-        if (pix >= nPix) return;
-    } else {
-        cot = blockIdx.x % coTiles;
-        pix = blockIdx.x / coTiles;
-    }
     const int HW = H * W;
     const int nStrips = N * bands;
-    const int u0 = pix * XTW;                                // flat column of the workgroup's first output column
-    const int s_first = u0 / period;
-    const int n = s_first / bands;                           // image of the first tile column: the address base
-    const int s0 = (u0 > 4 ? u0 - 4 : 0) / period;           // strip / image / band of the patch's first column
-    const int n0 = s0 / bands, b0 = s0 - n0 * bands;
-
-    // ---- DMA descriptors: this lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first plane
-    // of image n.  Periods are multiples of 4, so a piece lies in ONE strip.
-    unsigned pvoff[XPI];
-    int fix = 0;                                             // words 1..3 of piece i (bits 4i+1 .. 4i+3) beyond the image edge
-#pragma unroll
-    for (int i = 0; i < XPI; ++i) {
-        const int pidx = tid + i * XNT;
-        const int ci = pidx / (XPR * 18), rem = pidx - ci * (XPR * 18);
-        const int r = rem / 18, q = rem - r * 18;
-        int gx = u0 - 4 + 4 * q - s0 * period, band = b0, sn = n0;       // gx < 0 only in the very first patch (u0 = 0, q = 0)
-        while (gx >= period) { gx -= period; ++band; }
-        while (band >= bands) { band -= bands; ++sn; }
-        const int gy = band * XTH - 1 + r;
-        pvoff[i] = 0xFFFFFFFFu;
-        if (pidx < XPS / 4 && gx >= 0 && sn < N && gy >= 0 && gy < H && gx < W) {
-            pvoff[i] = (unsigned)(((sn - n) * Cin + ci) * HW + gy * W + gx) * 4u;
-#pragma unroll
-            for (int e = 1; e < 4; ++e) fix |= (gx + e >= W) ? (1 << (4 * i + e)) : 0;
+    const int grid = gridDim.x;
+    // PERSISTENT workgroups (one per CU: the LDS admits no second): workgroup b walks the tile ids b, b + grid, ...; the chunk
+    // stream does not stop at a tile boundary -- "the next chunk" of a tile's last chunk is the first chunk of the workgroup's
+    // next tile (its DMA, hand-over, window reads, transform, first A reads), so only the epilogue separates the MFMA streams of
+    // two tiles, and its stores drain while the next tile computes.  (One tile per workgroup: 32 k cycles per tile outside the
+    // chunk loop -- launch, 27 DMA issues + their latency, the first transform, the store burst of all CUs in lock step; 13 % of
+    // conv3_2, 35 % of conv1_2 -- tools/exp/wino4_bench.py --custom, intercept of time over chunk count.)
+    // tile id -> (channel tile, pixel tile): as wino.hip (colocate: the channel tiles of a pixel tile back to back on one XCD --
+    // grid is a multiple of 8, so id mod 8 = the workgroup's XCD for all of its tiles); ids beyond the last pixel tile: the end
+    auto decode = [&](int vid, int& cot, int& pix) __attribute__((always_inline)) {
+        cot = 0; pix = 0;
+        if (vid >= nTiles) return false;
+        if (colocate) {
+            const int slot = vid >> 3;
+            cot = slot % coTiles;
+            pix = (slot / coTiles) * 8 + (vid & 7);
+            return pix < nPix;
         }
-    }
-    unsigned wv = (unsigned)tid * 16u;                      // byte offset of the lane's piece of the NEXT slab chunk to fetch (the range
-                                                             // check covers voffset only: beyond the slab = zero fill)
-    bool edge = false;                                       // some loaded piece may straddle the right edge of an image row
-    if (W & 3) {
-        const int e0 = W & ~3;
-        for (int st = s0; st < nStrips && st * period + e0 < u0 + XPP - 4; ++st)
-            edge |= st * period + e0 >= u0 - 4;
-    }
+        cot = vid % coTiles;
+        pix = vid / coTiles;
+        return true;
+    };
 
-    const char* xc = (const char*)(x + (size_t)n * Cin * HW);
-    // bytes from xc to the end of the tensor, clamped (offsets reach into the next image: (span Cin + 4) HW 4 < 2^32, launcher)
-    const long long xtail = (long long)(N - n) * Cin * HW * 4;
-    unsigned xleft = (unsigned)(xtail > 0xFFFFFFFEll ? 0xFFFFFFFEll : xtail);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        ptmi_uniform_ptr(wp + (size_t)cot * nChunks * XUS), 0, __builtin_amdgcn_readfirstlane(nChunks * XUS * 4), 0x00020000);
+    // ---- DMA-side state of a tile: the lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first
+    // plane of the tile's first image; periods are multiples of 4, so a piece lies in ONE strip
+    unsigned n_pvoff[XPI];                                   // the NEXT tile's (the DMA cursors switch to it when they wrap)
+    int n_fix;
+    bool n_edge;
+    const char* n_xc;
+    unsigned n_xleft;
+    const float* n_slab;
+    int n_urange;
+    int n_vid;
+    auto make_next = [&](int vid) __attribute__((always_inline)) {
+        int cot, pix;
+        const bool valid = decode(vid, cot, pix);
+        n_vid = vid;
+        const int u0 = pix * XTW;                            // flat column of the tile's first output column
+        const int n = (u0 / period) / bands;                 // image of the first tile column: the address base
+        const int s0 = (u0 > 4 ? u0 - 4 : 0) / period;       // strip / image / band of the patch's first column
+        const int n0 = s0 / bands, b0 = s0 - n0 * bands;
+        n_fix = 0;                                           // words 1..3 of piece i (bits 4i+1 .. 4i+3) beyond the image edge
+#pragma unroll
+        for (int i = 0; i < XPI; ++i) {
+            const int pidx = tid + i * XNT;
+            const int ci = pidx / (XPR * 18), rem = pidx - ci * (XPR * 18);
+            const int r = rem / 18, q = rem - r * 18;
+            int gx = u0 - 4 + 4 * q - s0 * period, band = b0, sn = n0;   // gx < 0 only in the very first patch (u0 = 0, q = 0)
+            while (gx >= period) { gx -= period; ++band; }
+            while (band >= bands) { band -= bands; ++sn; }
+            const int gy = band * XTH - 1 + r;
+            n_pvoff[i] = 0xFFFFFFFFu;
+            if (valid && pidx < XPS / 4 && gx >= 0 && sn < N && gy >= 0 && gy < H && gx < W) {
+                n_pvoff[i] = (unsigned)(((sn - n) * Cin + ci) * HW + gy * W + gx) * 4u;
+#pragma unroll
+                for (int e = 1; e < 4; ++e) n_fix |= (gx + e >= W) ? (1 << (4 * i + e)) : 0;
+            }
+        }
+        n_edge = false;                                      // some loaded piece may straddle the right edge of an image row
+        if (valid && (W & 3)) {
+            const int e0 = W & ~3;
+            for (int st = s0; st < nStrips && st * period + e0 < u0 + XPP - 4; ++st)
+                n_edge |= st * period + e0 >= u0 - 4;
+        }
+        n_xc = (const char*)(x + (size_t)(valid ? n : 0) * Cin * HW);
+        // bytes from xc to the end of the tensor, clamped (offsets reach into the next image: (span Cin + 4) HW 4 < 2^32, launcher)
+        const long long xtail = valid ? (long long)(N - n) * Cin * HW * 4 : 0ll;
+        n_xleft = (unsigned)(xtail > 0xFFFFFFFEll ? 0xFFFFFFFEll : xtail);
+        n_slab = wp + (size_t)cot * nChunks * XUS;
+        n_urange = valid ? nChunks * XUS * 4 : 0;            // no tile: every piece is zero fill
+    };
+    // the cursors: patch pieces of chunk pcur / slab pieces of chunk ucur of the tile they are in
+    unsigned pvoff[XPI];
+    int fix;
+    bool edge;
+    const char* xc;
+    unsigned xleft;
+    const float* slab;
+    int urange;
+    unsigned wv;                                             // byte offset of the lane's piece of slab chunk ucur (the range check covers
+    int pcur, ucur;                                          // voffset only: beyond the slab = zero fill)
+    auto patch_wrap = [&]() __attribute__((always_inline)) {
+        if (pcur == nChunks) {
+#pragma unroll
+            for (int i = 0; i < XPI; ++i) pvoff[i] = n_pvoff[i];
+            fix = n_fix; edge = n_edge; xc = n_xc; xleft = n_xleft;
+            pcur = 0;
+        }
+    };
+    auto slab_wrap = [&]() __attribute__((always_inline)) {   // (always one chunk after the patch cursor wrapped: then the NEXT state is free)
+        if (ucur == nChunks) {
+            slab = n_slab; urange = n_urange; wv = (unsigned)tid * 16u;
+            ucur = 0;
+            make_next(n_vid + grid);
+        }
+    };
 
     float* const ldsU = lds;
     float* const ldsP = lds + XNU * XUS;
@@ -225,27 +269,32 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
                                                  (int)pvoff[i], 0, 0, 0);
     };
     auto dma_u = [&](int i, int stage) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            ptmi_uniform_ptr(slab), 0, __builtin_amdgcn_readfirstlane(urange), 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (xlds_void_t*)(ldsU + stage + wave * 256 + i * XNT * 4), 16,
                                                  (int)wv, i * XNT * 16, 0, 0);
     };
     auto advance_patch = [&]() __attribute__((always_inline)) {
         xc += (size_t)XKC * HW * 4;
         xleft = xleft == 0xFFFFFFFEu ? xleft : (xleft > (unsigned)XKC * (unsigned)HW * 4u ? xleft - (unsigned)XKC * (unsigned)HW * 4u : 0u);
+        ++pcur;
     };
-    auto advance_u = [&]() __attribute__((always_inline)) { wv += XUS * 4; };
-    auto fixup = [&](int stage) __attribute__((always_inline)) {
-        if (edge && fix) {
+    auto advance_u = [&]() __attribute__((always_inline)) { wv += XUS * 4; ++ucur; };
+    int fix_ho;                                              // fix-up mask / edge flag of the patch the NEXT hand-over completes (the
+    bool edge_ho;                                            // one issued during the previous chunk)
+    auto fixup = [&](int stage, int fx, bool ed) __attribute__((always_inline)) {
+        if (ed && fx) {
             float* pw = ldsP + stage + tid * 4;
 #pragma unroll
             for (int i = 0; i < XPI; ++i) {
 #pragma unroll
                 for (int e = 1; e < 4; ++e)
-                    if (fix & (1 << (4 * i + e))) pw[i * XNT * 4 + e] = 0.f;
+                    if (fx & (1 << (4 * i + e))) pw[i * XNT * 4 + e] = 0.f;
             }
         }
     };
 
-    // ---- the lane's role in the MFMAs
+    // ---- the lane's role in the MFMAs (the same for every tile)
     const int wm = wave >> 1, wn = wave & 1;                 // channel half (32) / tile row (4 image rows) of the workgroup's tile
     const int ttx = lane & 15, kq = lane >> 4;               // tile column / input channel of the chunk
     auto tile_geometry = [&](int u0v, int& tsn_o, int& py_o, int& px_o) __attribute__((always_inline)) {
@@ -258,335 +307,358 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         px_o = px_t;
         return sn < N && px_o < W && py_o < H;
     };
-    bool active;
-    {
-        int a0, a1, a2;
-        active = __any(tile_geometry(u0, a0, a1, a2));        // (wave-uniform) some tile of the wave lies inside an image
-    }
     // LDS float offsets of the lane: A = U[kq][group][co = wm 32 + ct 16 + ttx][4], window = patch[kq][4 wn + row][4 ttx + 3 ..]
     const int a_off = (kq * 9 * XBM + wm * 32 + ttx) * 4;                                  // + g * 256 + ct * 64
     const int b_off = kq * XPL + (wn * 4) * XPP + 4 * ttx + 3;                             // + row * 72 + {0, 1 (b128), 5}
 
-    // the lane's 8 biases (channels co_w + 16 ct + 4 kq + r), fetched BEFORE the first DMA
-    const int co_w = cot * XBM + wm * 32;
-    f32x4 bv[2];
+    int vid = blockIdx.x;
     {
-        const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
+        int c0, p0;
+        if (!decode(vid, c0, p0)) return;                    // (workgroup-uniform)
+    }
+    // the lane's 8 biases of a tile (channels co_w + 16 ct + 4 kq + r), fetched at the head of the tile
+    f32x4 bv[2];
+    const __amdgpu_buffer_rsrc_t rbias = ptmi_rsrc(bias ? bias : y, bias ? (unsigned)Cout * 4u : 0u);
+    auto load_bias = [&](int v) __attribute__((always_inline)) {
+        int cot, pix;
+        decode(v, cot, pix);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
             bv[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (epi <= 1 || epi == 4)
-                bv[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (co_w + ct * 16 + 4 * kq) * 4, 0, 0));
+                bv[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, (cot * XBM + wm * 32 + ct * 16 + 4 * kq) * 4, 0, 0));
         }
-    }
+    };
+    load_bias(vid);
 
-    // prologue DMA, in the order the counted waits assume: patch 0, U 0, patch 1 | U 1, patch 2
+    // prologue DMA of the workgroup's first tile, in the order the counted waits assume: patch 0, U 0, patch 1 | U 1, patch 2
+    make_next(vid);
+    pcur = ucur = nChunks;                                   // "wrapped": the first issue of either kind switches to the state just made
+    patch_wrap();
+    slab_wrap();                                             // (also makes the state of tile vid + grid)
     auto issue_patch = [&](int stage) __attribute__((always_inline)) {
+        patch_wrap();
 #pragma unroll
         for (int i = 0; i < XPI; ++i) dma_patch(i, stage);
         advance_patch();
     };
     auto issue_u = [&](int stage) __attribute__((always_inline)) {
+        slab_wrap();
 #pragma unroll
         for (int i = 0; i < XUI; ++i) dma_u(i, stage);
         advance_u();
     };
     issue_patch(0);
+    const int fix_p0 = fix; const bool edge_p0 = edge;
     issue_u(0);
     issue_patch(XPSP);
+    const int fix_p1 = fix; const bool edge_p1 = edge;
     issue_u(XUS);
     issue_patch(2 * XPSP);
-    // the accumulators, zeroed while the first pieces are in flight (the wave would sit in the wait below anyway)
+    fix_ho = fix; edge_ho = edge;
+
     f32x4 accA[64];                        // positions 0 .. 31 (x 2 channel tiles): AGPRs
     f32x4 accV[8];                         // positions 32 .. 35: VGPRs
-    xfor(std::make_integer_sequence<int, 64>{}, [&](auto i_c) __attribute__((always_inline)) {
-        accA[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        asm volatile("" : "+a"(accA[decltype(i_c)::value]));
-    });
-    xfor(std::make_integer_sequence<int, 8>{}, [&](auto i_c) __attribute__((always_inline)) {
-        accV[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        asm volatile("" : "+v"(accV[decltype(i_c)::value]));
-    });
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
-    fixup(0);
-    fixup(XPSP);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float V0[36], V1[36];                  // B operands of the current / next chunk
+    float Hh[6][6];                        // horizontally transformed window of the next chunk: Hh[row][j]
+    float D[6][6];                         // raw window rows
+    float E[4];
+    f32x4 A[3];                            // A operands: eighteen half-groups (four positions of one channel tile) per chunk rotate
+                                           // through THREE register quads -- 18 = 0 mod 3, so the rotation carries across chunks
+                                           // and tiles; half-group h + 2 is read during half-group h
 
-    if (active) {
-        float V0[36], V1[36];              // B operands of the current / next chunk
-        float Hh[6][6];                    // horizontally transformed window of the next chunk: Hh[row][j]
-        float D[6][6];                     // raw window rows
-        float E[4];
+    auto wread = [&](auto r_c, const float* pb) __attribute__((always_inline)) {         // window read r: row r / 3, part r % 3
+        constexpr int a = decltype(r_c)::value / 3, part = decltype(r_c)::value % 3;
+        const float* p = pb + a * XPP;
+        if constexpr (part == 0) D[a][0] = *(const volatile xlds_f32_t*)p;
+        if constexpr (part == 1) {
+            const f32x4 v = *(const volatile xlds_f32x4_t*)(p + 1);
+            D[a][1] = v[0]; D[a][2] = v[1]; D[a][3] = v[2]; D[a][4] = v[3];
+        }
+        if constexpr (part == 2) D[a][5] = *(const volatile xlds_f32_t*)(p + 5);
+    };
+    auto hop = [&](auto h_c) __attribute__((always_inline)) {                           // horizontal operation h: row h / 12 -> Hh[row][0..5]
+        constexpr int h = decltype(h_c)::value;
+        xin_op<h % 12>(D[h / 12], Hh[h / 12], E);
+    };
+    auto vop = [&](auto v_c, float (&Vn)[36]) __attribute__((always_inline)) {          // vertical operation v: column j = v / 12 -> Vn[6 i + j]
+        constexpr int v = decltype(v_c)::value;
+        constexpr int j = v / 12;
+        const float d[6] = {Hh[0][j], Hh[1][j], Hh[2][j], Hh[3][j], Hh[4][j], Hh[5][j]};
+        float t[6] = {Vn[j], Vn[6 + j], Vn[12 + j], Vn[18 + j], Vn[24 + j], Vn[30 + j]};
+        xin_op<v % 12>(d, t, E);
+        Vn[j] = t[0]; Vn[6 + j] = t[1]; Vn[12 + j] = t[2]; Vn[18 + j] = t[3]; Vn[24 + j] = t[4]; Vn[30 + j] = t[5];
+    };
 
-        auto wread = [&](auto r_c, const float* pb) __attribute__((always_inline)) {         // window read r: row r / 3, part r % 3
-            constexpr int a = decltype(r_c)::value / 3, part = decltype(r_c)::value % 3;
-            const float* p = pb + a * XPP;
-            if constexpr (part == 0) D[a][0] = *(const volatile xlds_f32_t*)p;
-            if constexpr (part == 1) {
-                const f32x4 v = *(const volatile xlds_f32x4_t*)(p + 1);
-                D[a][1] = v[0]; D[a][2] = v[1]; D[a][3] = v[2]; D[a][4] = v[3];
+    // float offsets of the slab stage of chunk c / c + 1 / c + 2 and of the patch stage of chunk c + 1 / c + 2 / c + 3 of the chunk
+    // STREAM (it runs on across tiles), rotated by compare-and-select (a modulo costs a dozen scalar instructions each)
+    int uo0 = 0, uo1 = XUS, uo2 = 2 * XUS, po1 = XPSP, po2 = 2 * XPSP, po3 = 3 * XPSP;
+    bool first = true;                                       // the workgroup's first tile: its operands do not come out of a previous tile's last chunk
+    bool skipwait = false;                                   // a tile's first hand-over: nothing older than the previous tile's vmcnt(0) is needed,
+                                                             // and the epilogue's stores must not be waited for
+    // One chunk = 72 slots; EVERY chunk runs the same body (no joins of differently specialised copies: at every join the register
+    // allocator moved accumulator tiles around).  PAR: parity of the chunk (which of V0 / V1 is current).
+    auto chunk = [&](auto par_c) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        float(&Vc)[36] = PAR ? V1 : V0;
+        float(&Vn)[36] = PAR ? V0 : V1;
+        const float* ap = ldsU + uo0 + a_off;
+        const float* apn = ldsU + uo1 + a_off;
+        const float* pb = ldsP + po1 + b_off;
+        const int ud = uo2, pf = po2, pd = po3;
+        {
+            const int t = uo0; uo0 = uo1; uo1 = uo2; uo2 = t;
+            const int q = po3 + XPSP == XNP * XPSP ? 0 : po3 + XPSP;
+            po1 = po2; po2 = po3; po3 = q;
+        }
+        slab_wrap();                                         // this chunk's DMA: slab chunk ucur, patch chunk pcur -- of this tile or the next
+        patch_wrap();
+        {   // one address register each for the chunk's A reads and window reads (immediate offsets)
+            unsigned va = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)ap;
+            unsigned vn = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)apn;
+            unsigned vb = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)pb;
+            asm volatile("" : "+v"(va), "+v"(vn), "+v"(vb));
+            ap = (const float*)(const __attribute__((address_space(3))) float*)(size_t)va;
+            apn = (const float*)(const __attribute__((address_space(3))) float*)(size_t)vn;
+            pb = (const float*)(const __attribute__((address_space(3))) float*)(size_t)vb;
+        }
+        xfor(std::make_integer_sequence<int, 72>{}, [&](auto s_c) __attribute__((always_inline)) {
+            constexpr int S = decltype(s_c)::value;
+            constexpr int hg = S >> 2, g = S >> 3, ct = hg & 1, q = S & 3, p = 4 * g + q;
+            const float av = A[hg % 3][q], bvv = Vc[p];
+            if constexpr (p < 32) xmfma_a(accA[2 * p + ct], av, bvv);   // [x4:mf]
+            else xmfma_v(accV[2 * (p - 32) + ct], av, bvv);   // [x4:mf]
+            if constexpr (q == 1) {                          // half-group hg + 2 (of this chunk, or 0 / 1 of the next one)
+                constexpr int h2 = hg + 2;
+                if constexpr (h2 < 18) A[h2 % 3] = *(const volatile xlds_f32x4_t*)(ap + (h2 >> 1) * 256 + (h2 & 1) * 64);   // [x4:ar]
+                else A[h2 % 3] = *(const volatile xlds_f32x4_t*)(apn + (h2 & 1) * 64);   // [x4:ar]
             }
-            if constexpr (part == 2) D[a][5] = *(const volatile xlds_f32_t*)(p + 5);
-        };
-        auto hop = [&](auto h_c) __attribute__((always_inline)) {                           // horizontal operation h: row h / 12 -> Hh[row][0..5]
-            constexpr int h = decltype(h_c)::value;
-            xin_op<h % 12>(D[h / 12], Hh[h / 12], E);
-        };
-        auto vop = [&](auto v_c, float (&Vn)[36]) __attribute__((always_inline)) {          // vertical operation v: column j = v / 12 -> Vn[6 i + j]
-            constexpr int v = decltype(v_c)::value;
-            constexpr int j = v / 12;
-            const float d[6] = {Hh[0][j], Hh[1][j], Hh[2][j], Hh[3][j], Hh[4][j], Hh[5][j]};
-            float t[6] = {Vn[j], Vn[6 + j], Vn[12 + j], Vn[18 + j], Vn[24 + j], Vn[30 + j]};
-            xin_op<v % 12>(d, t, E);
-            Vn[j] = t[0]; Vn[6 + j] = t[1]; Vn[12 + j] = t[2]; Vn[18 + j] = t[3]; Vn[24 + j] = t[4]; Vn[30 + j] = t[5];
-        };
+            if constexpr (S == XHAND) {
+                // everything but this chunk's DMA instructions so far (10 of its 12) has landed: slab c + 1, patch c + 2
+                if (!skipwait) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(x_dma_before(XHAND)) : "memory");   // [x4:ho]
+                skipwait = false;
+                fixup(pf, fix_ho, edge_ho);   // [x4:ho]
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // [x4:ho]
+            }
+            constexpr int wr = x_wread_at(S);
+            if constexpr (wr >= 0) wread(std::integral_constant<int, (wr >= 0 ? wr : 0)>{}, pb);   // [x4:wr]
+            constexpr int di = x_dma_at(S);
+            if constexpr (di >= 0) {
+                if constexpr (di < XUI) dma_u(di, ud);   // [x4:dma]
+                else dma_patch(di - XUI, pd);   // [x4:dma]
+                if constexpr (di == XUI - 1) advance_u();
+                if constexpr (di == XDI - 1) advance_patch();
+            }
+            constexpr int k0 = x_valu_before(S), k1 = x_valu_before(S + 1);
+            xfor(std::make_integer_sequence<int, k1 - k0>{}, [&](auto k_c) __attribute__((always_inline)) {
+                constexpr int k = k0 + decltype(k_c)::value;
+                if constexpr (k < 72) hop(std::integral_constant<int, (k < 72 ? k : 0)>{});   // [x4:xf]
+                else vop(std::integral_constant<int, (k >= 72 ? k - 72 : 0)>{}, Vn);   // [x4:xf]
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        fix_ho = fix; edge_ho = edge;                        // (of the patch this chunk issued: the next hand-over completes it)
+    };
 
-        {   // B operands of chunk 0: window from patch stage 0
+    auto epilogue = [&](int tvid) __attribute__((always_inline)) {
+        int cot, pix;
+        decode(tvid, cot, pix);
+        const int u0 = pix * XTW;
+        const int n = (u0 / period) / bands;
+        const int co_w = cot * XBM + wm * 32;
+        // ---- epilogue: Y = A^T M A per (channel, tile) in registers, then bias / ReLU / mask / pool and buffer stores.
+        // Accumulator element r of tile (p, ct): channel co_w + 16 ct + 4 kq + r, tile ttx, position p.
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs' results (inline asm: the compiler pads nothing)
+        int tsn, py, px;
+        const bool tile_ok = tile_geometry(u0, tsn, py, px);
+        const int cmax = Cout - co_w - 4 * kq;                   // channel 16 ct + r of this lane exists iff 16 ct + r < cmax
+        auto rd = [](float a) __attribute__((always_inline)) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; };
+        // the 4x4 outputs of channel (ct, r): o[k][l], k = output row, l = output column
+        auto inverse = [&](auto ct_c, auto r_c, float (&o)[4][4]) __attribute__((always_inline)) {
+            constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
+            float z[6][4];
+            xfor(std::make_integer_sequence<int, 6>{}, [&](auto i_c) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_c)::value;
+                float m[6];
+                xfor(std::make_integer_sequence<int, 6>{}, [&](auto j_c) __attribute__((always_inline)) {
+                    constexpr int p = 6 * i + decltype(j_c)::value;
+                    if constexpr (p < 32) m[decltype(j_c)::value] = rd(accA[2 * p + ct][r]);
+                    else m[decltype(j_c)::value] = accV[2 * (p - 32) + ct][r];
+                });
+                xout(m, z[i]);
+            });
+    #pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const float m[6] = {z[0][l], z[1][l], z[2][l], z[3][l], z[4][l], z[5][l]};
+                float yk[4];
+                xout(m, yk);
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) o[k][l] = yk[k];
+            }
+        };
+        auto for_channels = [&](auto&& f) __attribute__((always_inline)) {
+            xfor(std::make_integer_sequence<int, 8>{}, [&](auto c_c) __attribute__((always_inline)) {
+                f(std::integral_constant<int, (decltype(c_c)::value >> 2)>{}, std::integral_constant<int, (decltype(c_c)::value & 3)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        if (epi == 4) {
+            // bias + ReLU + 2x2/2 max pool (floor mode): the tile is four pool windows
+            const int OH = H >> 1, OW = W >> 1, OHW = OH * OW;
+            const long long ytail = (long long)(N - n) * Cout * OHW * 4;
+            const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail));
+            const int oy = py >> 1, ox = px >> 1;
+            unsigned pv2[2], pv1[2];
+    #pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bool rok = tile_ok && oy + a < OH;
+                const unsigned o = (unsigned)(((tsn - n) * Cout + 4 * kq) * OHW + (oy + a) * OW + ox) * 4u;
+                pv2[a] = (rok && ox + 1 < OW) ? o : 0xFFFFFFFFu;
+                pv1[a] = (rok && ox + 1 == OW) ? o : 0xFFFFFFFFu;
+            }
+            for_channels([&](auto ct_c, auto r_c) __attribute__((always_inline)) {
+                constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
+                float o[4][4];
+                inverse(ct_c, r_c, o);
+                const float b = bv[ct][r];
+                const bool cok = 16 * ct + r < cmax;
+                const int soff = (co_w + 16 * ct + r) * OHW * 4;
+    #pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    f32x2 m;
+    #pragma unroll
+                    for (int l = 0; l < 2; ++l)
+                        m[l] = fmaxf(fmaxf(fmaxf(o[2 * a][2 * l] + b, o[2 * a][2 * l + 1] + b),
+                                           fmaxf(o[2 * a + 1][2 * l] + b, o[2 * a + 1][2 * l + 1] + b)), 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, m), ry, cok ? (int)pv2[a] : -1, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m[0]), ry, cok ? (int)pv1[a] : -1, soff, 0);
+                }
+            });
+            return;
+        }
+        const long long ytail = (long long)(N - n) * Cout * HW * 4;
+        const unsigned img_bytes = (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail);     // to the end of the tensor, clamped
+        const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * HW, img_bytes);
+        const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(epi == 3 ? mref + (size_t)n * Cout * HW : y, epi == 3 ? img_bytes : 0u);
+        // per-lane byte offsets of the tile's four rows: pv4 = all four columns inside the image (16-byte access), pve[e] = column
+        // e alone (tiles cut by the right edge)
+        unsigned pv4[4];
+        unsigned pve[4][3];
+        bool partial = false;
+    #pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const bool rok = tile_ok && py + a < H;
+            const unsigned o = (unsigned)(((tsn - n) * Cout + 4 * kq) * HW + (py + a) * W + px) * 4u;
+            pv4[a] = (rok && px + 3 < W) ? o : 0xFFFFFFFFu;
+    #pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                pve[a][e] = (rok && px + 3 >= W && px + e < W) ? o + 4u * e : 0xFFFFFFFFu;
+                partial |= pve[a][e] != 0xFFFFFFFFu;
+            }
+        }
+        const bool cut = __any(partial);                         // (wave-uniform) some lane's tile is cut by the right edge
+        auto store_rows = [&](auto epi_c) __attribute__((always_inline)) {
+            constexpr int EPI = decltype(epi_c)::value;
+            for_channels([&](auto ct_c, auto r_c) __attribute__((always_inline)) {
+                constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
+                const bool cok = 16 * ct + r < cmax;
+                const int soff = (co_w + 16 * ct + r) * HW * 4;
+                f32x4 mk[4];
+                float ms[4][3];
+                if constexpr (EPI == 3) {                                  // the producer's activations first: their latency hides
+    #pragma unroll                                                         // behind the inverse transform
+                    for (int a = 0; a < 4; ++a) {
+                        mk[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, cok ? (int)pv4[a] : -1, soff, 0));
+                        if (cut) {
+    #pragma unroll
+                            for (int e = 0; e < 3; ++e)
+                                ms[a][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, cok ? (int)pve[a][e] : -1, soff, 0));
+                        }
+                    }
+                }
+                float o[4][4];
+                inverse(ct_c, r_c, o);
+                const float b = bv[ct][r];
+    #pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f32x4 st;
+    #pragma unroll
+                    for (int l = 0; l < 4; ++l) {
+                        float v = o[a][l];
+                        if constexpr (EPI <= 1) v += b;
+                        if constexpr (EPI == 1) v = fmaxf(v, 0.f);
+                        if constexpr (EPI == 3) {
+                            float m = mk[a][l];
+                            if (cut && l < 3) m = (pve[a][l] != 0xFFFFFFFFu) ? ms[a][l] : m;
+                            v = (m > 0.f) ? v : 0.f;
+                        }
+                        st[l] = v;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st), ry, cok ? (int)pv4[a] : -1, soff, 0);
+                    // a 16-byte store reads its data registers for two more states: hipcc pads that against ITS next VALU, not against
+                    // an inline-asm one (found the hard way: output (1, 1) of tile columns 12 .. 15 wrong, only with a bias)
+                    asm volatile("s_nop 1" ::: "memory");
+                    if (cut) {
+    #pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            const float sv = e == 0 ? st[0] : e == 1 ? st[1] : st[2];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv), ry, cok ? (int)pve[a][e] : -1, soff, 0);
+                        }
+                    }
+                }
+            });
+        };
+        if (epi == 0) store_rows(std::integral_constant<int, 0>{});
+        else if (epi == 1) store_rows(std::integral_constant<int, 1>{});
+        else if (epi == 2) store_rows(std::integral_constant<int, 2>{});
+        else store_rows(std::integral_constant<int, 3>{});
+    };
+
+    for (;;) {
+        // [x4@t0]
+        // the accumulators: zeroed while the first tile's first pieces are in flight / the previous tile's stores leave
+        xfor(std::make_integer_sequence<int, 64>{}, [&](auto i_c) __attribute__((always_inline)) {
+            accA[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+a"(accA[decltype(i_c)::value]));
+        });
+        xfor(std::make_integer_sequence<int, 8>{}, [&](auto i_c) __attribute__((always_inline)) {
+            accV[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            asm volatile("" : "+v"(accV[decltype(i_c)::value]));
+        });
+        if (first) {
+            first = false;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
+            fixup(0, fix_p0, edge_p0);
+            fixup(XPSP, fix_p1, edge_p1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // B operands of chunk 0: window from patch stage 0; A half-groups 0, 1 from slab stage 0
             const float* pb = ldsP + b_off;
             xfor(std::make_integer_sequence<int, 18>{}, [&](auto r_c) __attribute__((always_inline)) { wread(r_c, pb); });
             xfor(std::make_integer_sequence<int, 72>{}, [&](auto h_c) __attribute__((always_inline)) { hop(h_c); });
             xfor(std::make_integer_sequence<int, 72>{}, [&](auto v_c) __attribute__((always_inline)) { vop(v_c, V0); });
+            A[0] = *(const volatile xlds_f32x4_t*)(ldsU + a_off);
+            A[1] = *(const volatile xlds_f32x4_t*)(ldsU + a_off + 64);
         }
-
-        // One chunk = 72 slots; EVERY chunk runs the same body -- the last one's work for "the next chunk" (window reads,
-        // transforms, zero-filled DMA, hand-over) is wasted, 1 / nChunks of that work, in exchange for a loop without joins: at
-        // every join of differently specialised copies the register allocator moved accumulator tiles around (hundreds of
-        // v_accvgpr copies per tile, scratch spills).  PAR: parity of the chunk (which of V0 / V1 is current).
-        // A operands: eighteen half-groups (four positions of one channel tile) per chunk rotate through THREE registers
-        // quads -- 18 = 0 mod 3, so the rotation carries across chunks; half-group h + 2 is read during half-group h.
-        f32x4 A[3];
-        A[0] = *(const volatile xlds_f32x4_t*)(ldsU + a_off);
-        A[1] = *(const volatile xlds_f32x4_t*)(ldsU + a_off + 64);
-        // float offsets of the slab stage of chunk c / c + 1 / c + 2 and of the patch stage of chunk c + 1 / c + 2 / c + 3, rotated
-        // by compare-and-select (a modulo costs a dozen scalar instructions each)
-        int uo0 = 0, uo1 = XUS, uo2 = 2 * XUS, po1 = XPSP, po2 = 2 * XPSP, po3 = 3 * XPSP;
-        auto chunk = [&](auto par_c) __attribute__((always_inline)) {
-            constexpr int PAR = decltype(par_c)::value;
-            float(&Vc)[36] = PAR ? V1 : V0;
-            float(&Vn)[36] = PAR ? V0 : V1;
-            const float* ap = ldsU + uo0 + a_off;
-            const float* apn = ldsU + uo1 + a_off;
-            const float* pb = ldsP + po1 + b_off;
-            const int ud = uo2, pf = po2, pd = po3;
-            {
-                const int t = uo0; uo0 = uo1; uo1 = uo2; uo2 = t;
-                const int q = po3 + XPSP == XNP * XPSP ? 0 : po3 + XPSP;
-                po1 = po2; po2 = po3; po3 = q;
-            }
-            {   // one address register each for the chunk's A reads and window reads (immediate offsets)
-                unsigned va = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)ap;
-                unsigned vn = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)apn;
-                unsigned vb = (unsigned)(size_t)(const __attribute__((address_space(3))) float*)pb;
-                asm volatile("" : "+v"(va), "+v"(vn), "+v"(vb));
-                ap = (const float*)(const __attribute__((address_space(3))) float*)(size_t)va;
-                apn = (const float*)(const __attribute__((address_space(3))) float*)(size_t)vn;
-                pb = (const float*)(const __attribute__((address_space(3))) float*)(size_t)vb;
-            }
-            xfor(std::make_integer_sequence<int, 72>{}, [&](auto s_c) __attribute__((always_inline)) {
-                constexpr int S = decltype(s_c)::value;
-                constexpr int hg = S >> 2, g = S >> 3, ct = hg & 1, q = S & 3, p = 4 * g + q;
-                const float av = A[hg % 3][q], bvv = Vc[p];
-                if constexpr (p < 32) xmfma_a(accA[2 * p + ct], av, bvv);   // [x4:mf]
-                else xmfma_v(accV[2 * (p - 32) + ct], av, bvv);   // [x4:mf]
-                if constexpr (q == 1) {                      // half-group hg + 2 (of this chunk, or 0 / 1 of the next one)
-                    constexpr int h2 = hg + 2;
-                    if constexpr (h2 < 18) A[h2 % 3] = *(const volatile xlds_f32x4_t*)(ap + (h2 >> 1) * 256 + (h2 & 1) * 64);   // [x4:ar]
-                    else A[h2 % 3] = *(const volatile xlds_f32x4_t*)(apn + (h2 & 1) * 64);   // [x4:ar]
-                }
-                if constexpr (S == XHAND) {
-                    // everything but this chunk's DMA instructions so far (10 of its 12) has landed: slab c + 1, patch c + 2
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(x_dma_before(XHAND)) : "memory");   // [x4:ho]
-                    fixup(pf);   // [x4:ho]
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // [x4:ho]
-                }
-                constexpr int wr = x_wread_at(S);
-                if constexpr (wr >= 0) wread(std::integral_constant<int, (wr >= 0 ? wr : 0)>{}, pb);   // [x4:wr]
-                constexpr int di = x_dma_at(S);
-                if constexpr (di >= 0) {
-                    if constexpr (di < XUI) dma_u(di, ud);   // [x4:dma]
-                    else dma_patch(di - XUI, pd);   // [x4:dma]
-                    if constexpr (di == XUI - 1) advance_u();
-                    if constexpr (di == XDI - 1) advance_patch();
-                }
-                constexpr int k0 = x_valu_before(S), k1 = x_valu_before(S + 1);
-                xfor(std::make_integer_sequence<int, k1 - k0>{}, [&](auto k_c) __attribute__((always_inline)) {
-                    constexpr int k = k0 + decltype(k_c)::value;
-                    if constexpr (k < 72) hop(std::integral_constant<int, (k < 72 ? k : 0)>{});   // [x4:xf]
-                    else vop(std::integral_constant<int, (k >= 72 ? k - 72 : 0)>{}, Vn);   // [x4:xf]
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        };
+        // [x4@t1]
         for (int c = 0; c < nChunks; c += 2) {              // nChunks is even (launcher: Cin % 8 == 0)
             chunk(std::integral_constant<int, 0>{});
             chunk(std::integral_constant<int, 1>{});
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the zero-filled pieces of the chunks that do not exist
-    } else {
-        // a wave whose rows all lie below the image: the same DMA issue / wait / barrier sequence, no MFMAs
-        for (int c = 0; c < nChunks; ++c) {
-#pragma unroll
-            for (int i = 0; i < XUI; ++i) dma_u(i, ((c + 2) % XNU) * XUS);
-            advance_u();
-#pragma unroll
-            for (int i = 0; i < XPI; ++i) dma_patch(i, ((c + 3) % XNP) * XPSP);
-            advance_patch();
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
-            fixup(((c + 2) % XNP) * XPSP);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+        // [x4@t2]
+        // the last chunk's own DMA instructions (the next tile's chunk 1 slab / chunk 2 patch): with them done, nothing the next
+        // tile's counted waits rely on is older than the epilogue's stores
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-
-    // ---- epilogue: Y = A^T M A per (channel, tile) in registers, then bias / ReLU / mask / pool and buffer stores.
-    // Accumulator element r of tile (p, ct): channel co_w + 16 ct + 4 kq + r, tile ttx, position p.
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs' results (inline asm: the compiler pads nothing)
-    int tsn, py, px;
-    int u0e = u0;
-    asm volatile("" : "+s"(u0e));
-    const bool tile_ok = tile_geometry(u0e, tsn, py, px);
-    const int cmax = Cout - co_w - 4 * kq;                   // channel 16 ct + r of this lane exists iff 16 ct + r < cmax
-    auto rd = [](float a) __attribute__((always_inline)) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; };
-    // the 4x4 outputs of channel (ct, r): o[k][l], k = output row, l = output column
-    auto inverse = [&](auto ct_c, auto r_c, float (&o)[4][4]) __attribute__((always_inline)) {
-        constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
-        float z[6][4];
-        xfor(std::make_integer_sequence<int, 6>{}, [&](auto i_c) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_c)::value;
-            float m[6];
-            xfor(std::make_integer_sequence<int, 6>{}, [&](auto j_c) __attribute__((always_inline)) {
-                constexpr int p = 6 * i + decltype(j_c)::value;
-                if constexpr (p < 32) m[decltype(j_c)::value] = rd(accA[2 * p + ct][r]);
-                else m[decltype(j_c)::value] = accV[2 * (p - 32) + ct][r];
-            });
-            xout(m, z[i]);
-        });
-#pragma unroll
-        for (int l = 0; l < 4; ++l) {
-            const float m[6] = {z[0][l], z[1][l], z[2][l], z[3][l], z[4][l], z[5][l]};
-            float yk[4];
-            xout(m, yk);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k][l] = yk[k];
+        // [x4@t3]
+        epilogue(vid);
+        // [x4@t4]
+        vid += grid;
+        {
+            int c0, p0;
+            if (!decode(vid, c0, p0)) break;
         }
-    };
-    auto for_channels = [&](auto&& f) __attribute__((always_inline)) {
-        xfor(std::make_integer_sequence<int, 8>{}, [&](auto c_c) __attribute__((always_inline)) {
-            f(std::integral_constant<int, (decltype(c_c)::value >> 2)>{}, std::integral_constant<int, (decltype(c_c)::value & 3)>{});
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    };
-    if (epi == 4) {
-        // bias + ReLU + 2x2/2 max pool (floor mode): the tile is four pool windows
-        const int OH = H >> 1, OW = W >> 1, OHW = OH * OW;
-        const long long ytail = (long long)(N - n) * Cout * OHW * 4;
-        const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * OHW, (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail));
-        const int oy = py >> 1, ox = px >> 1;
-        unsigned pv2[2], pv1[2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const bool rok = tile_ok && oy + a < OH;
-            const unsigned o = (unsigned)(((tsn - n) * Cout + 4 * kq) * OHW + (oy + a) * OW + ox) * 4u;
-            pv2[a] = (rok && ox + 1 < OW) ? o : 0xFFFFFFFFu;
-            pv1[a] = (rok && ox + 1 == OW) ? o : 0xFFFFFFFFu;
-        }
-        for_channels([&](auto ct_c, auto r_c) __attribute__((always_inline)) {
-            constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
-            float o[4][4];
-            inverse(ct_c, r_c, o);
-            const float b = bv[ct][r];
-            const bool cok = 16 * ct + r < cmax;
-            const int soff = (co_w + 16 * ct + r) * OHW * 4;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                f32x2 m;
-#pragma unroll
-                for (int l = 0; l < 2; ++l)
-                    m[l] = fmaxf(fmaxf(fmaxf(o[2 * a][2 * l] + b, o[2 * a][2 * l + 1] + b),
-                                       fmaxf(o[2 * a + 1][2 * l] + b, o[2 * a + 1][2 * l + 1] + b)), 0.f);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, m), ry, cok ? (int)pv2[a] : -1, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m[0]), ry, cok ? (int)pv1[a] : -1, soff, 0);
-            }
-        });
-        return;
+        load_bias(vid);
+        skipwait = true;
     }
-    const long long ytail = (long long)(N - n) * Cout * HW * 4;
-    const unsigned img_bytes = (unsigned)(ytail > 0xFFFFFFFEll ? 0xFFFFFFFEll : ytail);     // to the end of the tensor, clamped
-    const __amdgpu_buffer_rsrc_t ry = ptmi_rsrc(y + (size_t)n * Cout * HW, img_bytes);
-    const __amdgpu_buffer_rsrc_t rm = ptmi_rsrc(epi == 3 ? mref + (size_t)n * Cout * HW : y, epi == 3 ? img_bytes : 0u);
-    // per-lane byte offsets of the tile's four rows: pv4 = all four columns inside the image (16-byte access), pve[e] = column
-    // e alone (tiles cut by the right edge)
-    unsigned pv4[4];
-    unsigned pve[4][3];
-    bool partial = false;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const bool rok = tile_ok && py + a < H;
-        const unsigned o = (unsigned)(((tsn - n) * Cout + 4 * kq) * HW + (py + a) * W + px) * 4u;
-        pv4[a] = (rok && px + 3 < W) ? o : 0xFFFFFFFFu;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            pve[a][e] = (rok && px + 3 >= W && px + e < W) ? o + 4u * e : 0xFFFFFFFFu;
-            partial |= pve[a][e] != 0xFFFFFFFFu;
-        }
-    }
-    const bool cut = __any(partial);                         // (wave-uniform) some lane's tile is cut by the right edge
-    auto store_rows = [&](auto epi_c) __attribute__((always_inline)) {
-        constexpr int EPI = decltype(epi_c)::value;
-        for_channels([&](auto ct_c, auto r_c) __attribute__((always_inline)) {
-            constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
-            const bool cok = 16 * ct + r < cmax;
-            const int soff = (co_w + 16 * ct + r) * HW * 4;
-            f32x4 mk[4];
-            float ms[4][3];
-            if constexpr (EPI == 3) {                                  // the producer's activations first: their latency hides
-#pragma unroll                                                         // behind the inverse transform
-                for (int a = 0; a < 4; ++a) {
-                    mk[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, cok ? (int)pv4[a] : -1, soff, 0));
-                    if (cut) {
-#pragma unroll
-                        for (int e = 0; e < 3; ++e)
-                            ms[a][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, cok ? (int)pve[a][e] : -1, soff, 0));
-                    }
-                }
-            }
-            float o[4][4];
-            inverse(ct_c, r_c, o);
-            const float b = bv[ct][r];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                f32x4 st;
-#pragma unroll
-                for (int l = 0; l < 4; ++l) {
-                    float v = o[a][l];
-                    if constexpr (EPI <= 1) v += b;
-                    if constexpr (EPI == 1) v = fmaxf(v, 0.f);
-                    if constexpr (EPI == 3) {
-                        float m = mk[a][l];
-                        if (cut && l < 3) m = (pve[a][l] != 0xFFFFFFFFu) ? ms[a][l] : m;
-                        v = (m > 0.f) ? v : 0.f;
-                    }
-                    st[l] = v;
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, st), ry, cok ? (int)pv4[a] : -1, soff, 0);
-                // a 16-byte store reads its data registers for two more states: hipcc pads that against ITS next VALU, not against
-                // an inline-asm one (found the hard way: output (1, 1) of tile columns 12 .. 15 wrong, only with a bias)
-                asm volatile("s_nop 1" ::: "memory");
-                if (cut) {
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) {
-                        const float sv = e == 0 ? st[0] : e == 1 ? st[1] : st[2];   // (bit_cast of a vector ELEMENT lvalue reads element 0)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sv), ry, cok ? (int)pve[a][e] : -1, soff, 0);
-                    }
-                }
-            }
-        });
-    };
-    if (epi == 0) store_rows(std::integral_constant<int, 0>{});
-    else if (epi == 1) store_rows(std::integral_constant<int, 1>{});
-    else if (epi == 2) store_rows(std::integral_constant<int, 2>{});
-    else store_rows(std::integral_constant<int, 3>{});
 }
 
 // U = G g G^T (6x6 per filter) laid out as the kernel's LDS image: [channel tile (64)][chunk (4 ci)][ci][position group 9][co 64]
@@ -686,10 +758,15 @@ int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, c
     const int64_t nPix = cdiv64((int64_t)n * bands * period, XTW);
     PTMI_CHECK_ARG(nPix * XTW < (1ll << 31), "conv3x3_wino4_fwd: too many tiles");
     const int colocate = coTiles <= 4;
-    const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;
-    PTMI_CHECK_ARG(nWg < (1ll << 31), "conv3x3_wino4_fwd: too many tiles");
-    hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)nWg), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
-                       cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate);
+    const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;      // tile ids (colocate: some beyond nPix -- the end)
+    PTMI_CHECK_ARG(nWg < (1ll << 31) - 4096, "conv3x3_wino4_fwd: too many tiles");
+    // persistent workgroups: one per CU (a multiple of 8: a tile stays on the XCD of its id mod 8)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+        cus = 256;
+    const int64_t grid = nWg < (cus / 8) * 8 ? nWg : (cus / 8) * 8;
+    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)grid), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
+                       cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate, (int)nWg);
     PTMI_LAUNCH_CHECK("conv3x3_wino4_fwd");
     return 0;
 }

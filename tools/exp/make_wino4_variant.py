@@ -31,6 +31,19 @@ def main():
     for name, parts in zip(args[0::2], args[1::2]):
         drop = set() if parts == "none" else set(parts.split(","))
         out = [ln for ln in src if not any(f"[x4:{p}]" in ln for p in drop)]
+        if "stamp" in drop:
+            # `// [x4@tK]` markers become s_memtime stamps of wave 0 of workgroup 0: slot 8 * tile + K of the int64 buffer passed as
+            # mask_ref (run with an epilogue other than 3; tools/exp/wino4_bench.py --stamps)
+            def stamp(ln):
+                if "[x4@t" not in ln:
+                    return ln
+                k = int(ln.split("[x4@t")[1].split("]")[0])
+                return (f"        if (blockIdx.x == 0 && tid == 0 && x4_tile < 64) {{ unsigned long long t_; asm volatile(\"s_memtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t_)); "
+                        f"((unsigned long long*)mref)[8 * x4_tile + {k}] = t_; " +
+                        ("asm volatile(\"s_memrealtime %0\\n\\ts_waitcnt lgkmcnt(0)\" : \"=s\"(t_)); ((unsigned long long*)mref)[8 * x4_tile + 5] = t_; " if k == 0 else "") +
+                        "}" + ("  ++x4_tile;" if k == 4 else ""))
+            out = [stamp(ln) for ln in out]
+            out = [ln.replace("    int vid = blockIdx.x;", "    int vid = blockIdx.x; int x4_tile = 0;") for ln in out]
         tmp = os.path.join(ROOT, "probabilisticteacher_amd", "csrc", f"_w4_{name}.hip")
         open(tmp, "w").write("\n".join(out) + "\n")
         try:

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--only4", action="store_true")
     ap.add_argument("--custom", action="append", default=[], help="name=cin,cout,h,w (repeatable)")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions; the minimum is reported")
+    ap.add_argument("--stamps", action="store_true", help="--lib built with the `stamp` part: per-tile phase stamps of wave 0 of workgroup 0")
     a = ap.parse_args()
     from probabilisticteacher_amd import _lib
     lib = ctypes.CDLL(os.path.abspath(a.lib)) if a.lib else _lib.load()
@@ -50,9 +51,11 @@ def main():
             y = torch.empty(a.n, cout, h, w, device="cuda:0")
             fwd = getattr(lib, f"ptmi_conv3x3_{kind}_fwd")
 
+            tr = torch.zeros(8 * 64, dtype=torch.int64, device="cuda:0")
+
             def f():
-                rc = fwd(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()), vp(x.data_ptr()), vp(y.data_ptr()), a.n, cin, cout, h, w,
-                         a.epi, st)
+                rc = fwd(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()), vp(tr.data_ptr() if a.stamps else x.data_ptr()), vp(y.data_ptr()),
+                         a.n, cin, cout, h, w, a.epi, st)
                 assert rc == 0, _lib.load().ptmi_last_error()
             f()
             torch.cuda.synchronize()
@@ -66,6 +69,16 @@ def main():
                 torch.cuda.synchronize()
                 ms = min(ms, e0.elapsed_time(e1) / a.iters)
             outs[kind] = (y, ms)
+            if a.stamps and kind == "wino4":
+                t = tr.cpu().view(64, 8).tolist()
+                last = max(k for k in range(64) if t[k][0])
+                if last > 2:
+                    print(f"   shader clock over tiles 1 .. {last}: {(t[last][0] - t[1][0]) / (t[last][5] - t[1][5]) * 100:.0f} MHz "
+                          f"(s_memtime ticks per 100 MHz s_memrealtime tick)")
+                for k in range(1, 4):
+                    if t[k][4] and t[k + 1][0]:
+                        print(f"   tile {k}: zero-init {t[k][1]-t[k][0]}  chunk loop {t[k][2]-t[k][1]} ({(t[k][2]-t[k][1]) / (cin // 4):.0f} per chunk)  "
+                              f"vmcnt(0) {t[k][3]-t[k][2]}  epilogue {t[k][4]-t[k][3]}  to next tile {t[k+1][0]-t[k][4]}  total {t[k+1][0]-t[k][0]}")
             line += f"  {kind}: {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s direct-eq"
         if len(outs) == 2:
             d = (outs["wino"][0] - outs["wino4"][0]).abs().max().item()
