@@ -7,12 +7,16 @@ import random
 
 import torch
 
+# Round 5 (criterion v4, fixed before any oracle trajectory of this workload existed): 300 burn-in + 200 mutual-learning iterations
+# = BASELINE configs[4]'s 500.  Round 4's 180 + 120 left the teacher's foreground confidence at the 0.5 argmax threshold of the
+# unsupervised box term (fast_rcnn.py:179-263: rows whose teacher argmax is background are dropped), so single trajectories
+# ended burn-in with that term dead; with 300 burn-in iterations every one of 6 fp32 + 6 AMP HIP trajectories has every
+# unsupervised term live in >= 90 % of the mutual-learning iterations (tools/exp/curve_probe.py, profiles/r05_curve_probe.txt).
 SETTINGS = dict(height=192, width=256, batch=2, pool=8, data_seed=2024, ratio_seed=5,
-                burn=180, iters=300, base_lr=0.02, warmup_iters=20, window=30, param_seed=101,
+                burn=300, iters=500, base_lr=0.02, warmup_iters=20, window=30, param_seed=101,
                 obj_min=0.30, obj_max=0.65)      # object extent as a fraction of the image extent (anchors are 128-512 px)
 LOSS_KEYS = ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")
-KEY_SEEDS = (1000, 5000, 9000)     # sampler-key seeds: one trajectory each (iteration `it` of a trajectory uses seed + it)
-AMP_EXTRA_SEEDS = (2000, 3000, 4000)   # HIP-side only: the SOLVER.AMP.ENABLED test runs these three trajectories as well
+KEY_SEEDS = (1000, 5000, 9000, 2000, 3000, 4000)   # sampler-key seeds: one trajectory each, on BOTH sides (iteration `it` uses seed + it)
 
 
 def make_pool(settings, K):

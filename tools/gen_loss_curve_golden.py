@@ -26,12 +26,14 @@ def main():
     ap.add_argument("--set", action="append", default=[])
     ap.add_argument("--dry", action="store_true")
     ap.add_argument("--seeds", default="")
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--out", default="")
     a = ap.parse_args()
     st = dict(cc.SETTINGS)
     for kv in a.set:
         k, v = kv.split("=")
         st[k] = type(st[k])(v)
-    torch.set_num_threads(max(2, min(os.cpu_count() or 2, 32)))
+    torch.set_num_threads(a.threads or max(2, min(os.cpu_count() or 2, 32)))
     from probabilisticteacher_amd.config import setup_cfg
     cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_s2c.yaml"), ["MODEL.VGG.PRETRAIN", ""])
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
@@ -79,7 +81,7 @@ def main():
         for k, v in curve.items():
             out_arrays[f"{k}@{seed0}"] = v
     if not a.dry:
-        out = os.path.join(ROOT, "tests", "golden", "loss_curve_s2c.npz")
+        out = a.out or os.path.join(ROOT, "tests", "golden", "loss_curve_s2c.npz")
         np.savez_compressed(out, settings_keys=np.array(sorted(st)), settings_vals=np.array([float(st[k]) for k in sorted(st)]),
                             seeds=np.array(seeds), **out_arrays)
         print("wrote", out, os.path.getsize(out), "bytes")
