@@ -608,3 +608,20 @@ def test_baseline_config2_step_b4_plus_4_1333x800_vs_oracle(monkeypatch, capsys)
         print(f"\n[configs[2] 1333x800 B=4+4] proposals: {res['log'].check_sets()}; pseudo labels {[len(p) for p in res['tr'].mine]}; "
               f"losses HIP {m} oracle {om}")
     _compare_step(m, om, res["tr"], res["state"], res["params"], SUP + UNSUP, "configs[2] B=4+4")
+
+
+def test_baseline_config3_per_gpu_share_b8_plus_8_1333x800_vs_oracle(monkeypatch, capsys):
+    """configs[3]'s per-GPU share (batch 64 + 64 on 8 GPUs = 8 labelled + 8 unlabelled 1333 x 800 images per rank; VERDICT r4 item
+    3c): the joint 24-image student pass (n = 24 launch shapes of every conv kernel, incl. the F(4x4,3x3) kernel of round 5), an
+    8-image teacher pass, matcher / sampler / NMS batched over 8 / 16 / 24 images with different gt counts, 8 per-image pseudo-label
+    sets -- against the oracle's per-image loops (reference step pt/engine/trainer.py:263-392, RPN terms
+    pt/modeling/proposal_generator/rpn.py:257-361, ROI terms pt/modeling/roi_heads/fast_rcnn.py:179-263).
+    Same bar as the 1 + 1 and 4 + 4 tests: 8 losses 1e-4, gradient norm 1e-3, updated-parameter probes 1e-4."""
+    res = mutual_learning_step_vs_oracle(monkeypatch, "configs/pt/final_c2f.yaml", 800, 1333, n_img=8, seed=83)
+    m, om = res["m"], res["om"]
+    check_teacher_and_pseudo_labels(res)
+    assert set(SUP + UNSUP) <= set(m) and set(SUP + UNSUP) <= set(om)
+    with capsys.disabled():
+        print(f"\n[configs[3] per-GPU share 1333x800 B=8+8] proposals: {res['log'].check_sets()}; pseudo labels "
+              f"{[len(p) for p in res['tr'].mine]}; losses HIP {m} oracle {om}")
+    _compare_step(m, om, res["tr"], res["state"], res["params"], SUP + UNSUP, "configs[3] per-GPU share B=8+8")
