@@ -103,6 +103,16 @@ int ptmi_conv3x3_wino4_fwd_fits(int cin, int cout, int h, int w);
 int64_t ptmi_conv3x3_wino_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n,
                             int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
+/* F(4x4,3x3)-domain weight gradient (round 5, csrc/wino4w.hip; same contract as ptmi_conv3x3_wgrad / ptmi_conv3x3_wino_wgrad;
+ * replaces cuDNN's BWD_FILTER at pt/modeling/backbone/vgg.py:45-53,66-69, pt/modeling/proposal_generator/rpn.py:96):
+ * dU_p[co][ci] = sum over tiles of (A dY A^T)_p V_p for the 36 positions of the 6x6 transform domain on v_mfma_f32_32x32x2_f32
+ * (36 multiplies per 4x4 tile and channel pair instead of 64 / 144), split over contiguous tile ranges whose partials (workspace
+ * [split][36][Cout][Cin] fp32 + bias partials [split][ceil(Cin/32)][Cout], ptmi_conv3x3_wino4_wgrad_ws_floats) are summed in a fixed
+ * order and mapped back by dW = G^T dU G.  Deterministic.  ptmi_conv3x3_wino4_wgrad_fits: the 32-bit buffer offsets suffice. */
+int ptmi_conv3x3_wino4_wgrad_fits(int h, int w);
+int64_t ptmi_conv3x3_wino4_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
+int ptmi_conv3x3_wino4_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n,
+                             int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
 /* ------------------------------------------------------------------ bf16 STORAGE path of the conv stack ("P8", round 4)
  * SOLVER.AMP.ENABLED (reference pt/engine/trainer.py:98; BASELINE configs[4]): under autocast the reference's cuDNN convolutions
  * (pt/modeling/backbone/vgg.py:45-53,66-69, pt/modeling/proposal_generator/rpn.py:96) read and write bf16 activations.  The

@@ -179,7 +179,14 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
     dw = torch.empty(cout, cin, 3, 3, dtype=F32, device=x.device)
     db = torch.empty(cout, dtype=F32, device=x.device)
     lib = _lib.load()
-    if (_use_wino(cin) and cin >= _WINO_WGRAD_MIN_C and cout >= _WINO_WGRAD_MIN_C
+    if (_CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and cin >= _WINO4_WGRAD_MIN_CIN and cout >= _WINO_WGRAD_MIN_C
+            and lib.ptmi_conv3x3_wino4_wgrad_fits(h, w) and _wino4_wgrad_fill(h, w) >= _WINO4_WGRAD_MIN_FILL):
+        # round 5: the F(4x4,3x3)-domain kernel (csrc/wino4w.hip; workgroup = 64 co x 32 ci)
+        ws = _ws("wgrad", lib.ptmi_conv3x3_wino4_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+        with _prof("conv3x3_wino4_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino4_wgrad_issued_flops(n, cin, cout, h, w)):
+            _lib.call("ptmi_conv3x3_wino4_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
+                      _stream())
+    elif (_use_wino(cin) and cin >= _WINO_WGRAD_MIN_C and cout >= _WINO_WGRAD_MIN_C
             and lib.ptmi_conv3x3_wino_wgrad_fits(h, w)):
         ws = _ws("wgrad", lib.ptmi_conv3x3_wino_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
         with _prof("conv3x3_wino_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino_wgrad_issued_flops(n, cin, cout, h, w)):
@@ -204,6 +211,14 @@ _CONV_ALGO = "auto"
 _WINO_MIN_CIN = 32
 _WINO4_MIN_CIN = 64
 _WINO_WGRAD_MIN_C = 64         # the wgrad workgroup owns 64 co x 64 ci
+_WINO4_WGRAD_MIN_CIN = 32      # the F(4x4,3x3) wgrad workgroup owns 64 co x 32 ci
+_WINO4_WGRAD_MIN_FILL = 0.9    # ... and walks the map in chunks of 4 rows x 16 columns: below this share of real pixels per chunk the
+                               # F(2x2,3x3)-domain kernel (7- or 8-k-step chunks, whichever fits the row) is faster (measured: 50 x 83,
+                               # fill 0.83: 0.91x; 100 x 166, fill 0.94: 1.08x; 200 x 333: 1.17x -- tools/exp/wino4w_bench.py)
+
+
+def _wino4_wgrad_fill(h: int, w: int) -> float:
+    return (h * w) / float(-(-h // 4) * 4 * -(-w // 16) * 16)
 
 
 def set_conv_algo(mode: str) -> None:
@@ -252,6 +267,14 @@ def wino4_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
     for wn in (0, 1):
         waves += int((col_ok & (band * 8 + 4 * wn < h)).any(axis=1).sum())
     return float(waves) * 2 * co_tiles * chunks * 72 * 2048
+
+
+def wino4_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
+    """FLOPs of the MFMAs one ptmi_conv3x3_wino4_wgrad launch issues: per 64 co x 32 ci pair and chunk (one tile row x 16
+    columns = 4 tiles = two k-steps) 2 x 18 v_mfma_f32_32x32x2_f32 x 4 waves x 4096 FLOP (csrc/wino4w.hip)"""
+    pairs = -(-cout // 64) * -(-cin // 32)
+    chunks = n * -(-h // 4) * -(-w // 16)
+    return float(pairs) * chunks * 2 * 18 * 4 * 4096
 
 
 def wino_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:

@@ -406,9 +406,27 @@ class _ProposalLog:
             r = self._f_ref(ocfg, dec.unsqueeze(0), lg.unsqueeze(0), [size], sg.unsqueeze(0), pre, post, training)[0]
             rb, rs = r.proposal_boxes.tensor, r.objectness_logits
             assert len(hb) == len(rb), f"proposal count {len(hb)} vs the oracle's stage on the same inputs {len(rb)}"
-            assert torch.equal(hb, rb), ("HIP proposals differ from the oracle's find_top_rpn_proposals run on the SAME inputs: "
-                                         f"first row {int(((hb != rb).any(dim=1)).nonzero()[0])} of {len(rb)}")
-            close(hs, rs, 1e-5, 1e-6, "proposal scores on identical inputs")
+            if not torch.equal(hb, rb):
+                # The kept SET and its order must be the oracle's -- except inside runs of proposals whose sigma-rescored scores
+                # (proposal_utils.py:136-138: logit x (1 - mean sigmoid(sigma logits))) are tied to within 1e-6 relative: the
+                # rescoring goes through a sigmoid whose last ulps differ between torch's CPU kernel and the device's expf, so two
+                # proposals 1 ulp apart may swap (first seen at 8 + 8 images: rows 1599 / 1600 of one image, scores 87.426567 /
+                # 87.426559).  Inside such a run the rows are compared as a set; everything else bit for bit.
+                srt = rs.double()
+                run = torch.zeros(len(rs), dtype=torch.long)
+                run[1:] = torch.cumsum(((srt[:-1] - srt[1:]).abs() > 1e-6 * srt[:-1].abs()).long(), 0)
+                bad = (hb != rb).any(dim=1)
+                for rid in run[bad].unique().tolist():
+                    rows = (run == rid).nonzero()[:, 0]
+                    a = sorted(map(tuple, hb[rows].tolist()))
+                    b = sorted(map(tuple, rb[rows].tolist()))
+                    assert len(rows) > 1 and a == b, ("HIP proposals differ from the oracle's find_top_rpn_proposals run on the SAME "
+                                                      f"inputs beyond a permutation of score-tied rows: rows {rows.tolist()}")
+                hs = hs.clone()
+                hs_sorted, rs_sorted = torch.sort(hs, descending=True)[0], torch.sort(rs, descending=True)[0]
+                close(hs_sorted, rs_sorted, 1e-5, 1e-6, "proposal scores on identical inputs (tied rows permuted)")
+            else:
+                close(hs, rs, 1e-5, 1e-6, "proposal scores on identical inputs")
             a, b = self.hip[k], self.ref[k]
             za, zb = np.zeros(len(a), np.int64), np.zeros(len(b), np.int64)
             frac, _ = match_detections(a, za, b, zb, box_tol=5e-3)

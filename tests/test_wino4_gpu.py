@@ -125,3 +125,71 @@ def test_wino4_baseline_layer_shapes():
             ref = ref[:, :, ys.start - y0: ys.start - y0 + (ys.stop - ys.start), xs.start - x0: xs.start - x0 + (xs.stop - xs.start)]
             worst = max(worst, close(got[:, :, ys, xs], ref, 1e-4, 1e-4, f"layer {cin}->{cout} {h}x{w} crop {ys} {xs}"))
     print(f"\n[wino4] worst abs error over the layer-shape crops: {worst:.2e} (bar 1e-4 + 1e-4 |ref|)")
+
+
+# ------------------------------------------------------------------------------------------------ weight gradient (csrc/wino4w.hip)
+def _wino4_wgrad(x, gy, cout, accumulate_into=None):
+    from probabilisticteacher_amd import _lib, ops
+    n, cin, h, w = x.shape
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV) if accumulate_into is None else accumulate_into[0]
+    db = torch.full((cout,), float("nan"), device=DEV) if accumulate_into is None else accumulate_into[1]
+    ws = torch.empty(_lib.load().ptmi_conv3x3_wino4_wgrad_ws_floats(n, cin, cout, h, w), device=DEV)
+    _lib.call("ptmi_conv3x3_wino4_wgrad", ops._ptr(x), ops._ptr(gy), ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w,
+              0 if accumulate_into is None else 1, ops._stream())
+    return dw, db
+
+
+WG_SHAPES = [
+    (1, 32, 64, 4, 16),       # one chunk, one workgroup
+    (1, 32, 64, 8, 32),       # four chunks: stage rotation
+    (2, 64, 64, 24, 72),      # several chunks, two ci tiles
+    (2, 64, 128, 19, 35),     # odd H and W: border chunks (rows below the image, pieces straddling the right edge)
+    (1, 128, 256, 13, 33),
+    (1, 256, 512, 9, 83),     # W = 83 as the 1333x800 block-5 map
+    (1, 40, 70, 11, 17),      # channel counts that are not multiples of the tiles
+    (1, 32, 128, 5, 166),
+    (2, 32, 128, 3, 333),     # H = 3: every chunk is a border chunk
+    (1, 40, 130, 1, 70),      # a single row
+    (3, 32, 64, 4, 3),        # narrower than one 16-B piece
+    (1, 24, 64, 50, 83),      # the block-5 map itself
+    (3, 16, 48, 7, 21),
+    (2, 64, 64, 40, 100),     # interior (plain) chunks on all sides
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", WG_SHAPES)
+def test_wino4_wgrad(n, cin, cout, h, w):
+    """dW, db of ptmi_conv3x3_wino4_wgrad against torch CPU fp32 autograd: 1e-4 relative + 1e-4 of the gradient's scale (the bar of
+    the F(2x2,3x3)-domain and direct kernels' tests); bit-identical repeats; accumulate = 1 adds"""
+    gen = g(31 + n * 1000 + cin + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=gen)
+    wt = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.1).requires_grad_()
+    b = torch.zeros(cout, requires_grad=True)
+    gy = torch.randn(n, cout, h, w, generator=gen)
+    F.conv2d(x, wt, b, padding=1).backward(gy)
+    dw, db = _wino4_wgrad(x.to(DEV), gy.to(DEV), cout)
+    scale = float(wt.grad.abs().max())
+    close(dw, wt.grad, 1e-4, 1e-4 * scale, "dW")
+    close(db, b.grad, 1e-4, 1e-4 * float(b.grad.abs().max()), "db")
+    dw2, db2 = _wino4_wgrad(x.to(DEV), gy.to(DEV), cout)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "the split reduction runs in a fixed order"
+    acc = (dw.clone(), db.clone())
+    _wino4_wgrad(x.to(DEV), gy.to(DEV), cout, accumulate_into=acc)
+    close(acc[0], 2 * wt.grad, 1e-4, 2e-4 * scale, "dW accumulate")
+    close(acc[1], 2 * b.grad, 1e-4, 2e-4 * float(b.grad.abs().max()), "db accumulate")
+
+
+def test_wino4_wgrad_layer_shape_vs_direct_kernel():
+    """A trainable layer at the 1333x800 map size (conv4: 256 -> 512 at 100x166, 2 images) against the direct split-K kernel"""
+    from probabilisticteacher_amd import _lib, ops
+    gen = g(5)
+    x = torch.randn(2, 256, 100, 166, generator=gen).to(DEV)
+    gy = torch.randn(2, 512, 100, 166, generator=gen).to(DEV)
+    dw, db = _wino4_wgrad(x, gy, 512)
+    ws = torch.empty(_lib.load().ptmi_conv3x3_wgrad_ws_floats(2, 256, 512, 100, 166), device=DEV)
+    dw_d, db_d = torch.empty_like(dw), torch.empty_like(db)
+    _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x), ops._ptr(gy), ops._ptr(dw_d), ops._ptr(db_d), ops._ptr(ws), 2, 256, 512,
+              100, 166, 0, ops._stream())
+    scale = float(dw_d.abs().max())
+    close(dw, dw_d, 1e-4, 1e-4 * scale, "dW wino4 vs direct")
+    close(db, db_d, 1e-4, 1e-4 * float(db_d.abs().max()), "db")
