@@ -150,6 +150,11 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
  * zero): dW (Cout, Cin, 3, 3) and db (Cout) in fp32 (same contract as ptmi_conv3x3_wgrad: split partials in a caller-allocated
  * workspace of ptmi_p8_wgrad_ws_floats floats, summed in a fixed order; accumulate != 0 adds to dW / db).  The contraction runs
  * over pixels: operands reach the MFMA through ds_read_b64_tr_b16; db is the product of dy with an all-ones operand. */
+/* 1 if ptmi_p8_wgrad / ptmi_p8_gemm_nt serve the shape (their per-launch 32-bit buffer offsets: a P8 tensor of at most 4 GiB,
+ * e.g. conv1_2 (64 channels, 1333x800) up to 31 images; fc1 up to ~85 k ROIs); the host side routes larger shapes elsewhere
+ * (p8.wgrad: the fp32 direct kernel on the widened operands -- the same products, fp32 accumulation). */
+int ptmi_p8_wgrad_fits(int n, int cin, int cout, int h, int w);
+int ptmi_p8_gemm_nt_fits(int m, int n, int k);
 int64_t ptmi_p8_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout,
                   int h, int w, int accumulate, ptmi_stream_t s);

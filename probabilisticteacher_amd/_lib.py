@@ -50,6 +50,8 @@ SIGNATURES = {
     "ptmi_p8_packed_elems": (_i64, [_i, _i]),
     "ptmi_p8_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ptmi_p8_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_p8_wgrad_fits": (_i, [_i, _i, _i, _i, _i]),
+    "ptmi_p8_gemm_nt_fits": (_i, [_i, _i, _i]),
     "ptmi_p8_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_p8_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_p8m_elems": (_i64, [_i, _i]),

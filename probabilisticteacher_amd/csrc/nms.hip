@@ -64,8 +64,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
         const float uni = aarea + carea[k] - inter;
         const float p = thr * uni;
         bool sup;
-        if (uni > 0.f && inter > p * HI) sup = true;
-        else if (uni > 0.f && inter < p * LO) sup = false;
+        // (p >= FLT_MIN: the 2^-24 bounds hold for NORMAL products only -- a denormal thr uni, or thr = 0 with an underflowing
+        // quotient, takes the division)
+        if (uni > 0.f && p >= 1.17549435e-38f && inter > p * HI) sup = true;
+        else if (uni > 0.f && p >= 1.17549435e-38f && inter < p * LO) sup = false;
         else sup = inter / uni > thr;
         if (sup) bits |= 1ull << k;
     }

@@ -997,14 +997,22 @@ int64_t ptmi_p8_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
     return (int64_t)p8_wgrad_splits(n, cin, cout, h, w) * (9 * (int64_t)cout * cin + cout);
 }
 
+int ptmi_p8_wgrad_fits(int n, int cin, int cout, int h, int w)
+{
+    if (n <= 0 || cin <= 0 || cout <= 0 || h <= 0 || w <= 0) return 0;
+    const P8Dims d = p8_dims(n, h, w);
+    const int xcb = ptmi_p8_planes(cin), dcb = ptmi_p8_planes(cout);
+    return (int64_t)xcb * d.PT * 16 < (1ll << 32) && (int64_t)dcb * d.PT * 16 < (1ll << 32) && d.PT < (1ll << 31) / 2;
+}
+
 int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h, int w,
                   int accumulate, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_wgrad: bad args");
     const P8Dims d = p8_dims(n, h, w);
     const int xcb = ptmi_p8_planes(cin), dcb = ptmi_p8_planes(cout);
-    PTMI_CHECK_ARG((int64_t)xcb * d.PT * 16 < (1ll << 32) && (int64_t)dcb * d.PT * 16 < (1ll << 32) && d.PT < (1ll << 31) / 2,
-                   "p8_wgrad: tensors beyond the 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d)", n, cin, cout, h, w);
+    PTMI_CHECK_ARG(ptmi_p8_wgrad_fits(n, cin, cout, h, w),
+                   "p8_wgrad: tensors beyond the 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d; ptmi_p8_wgrad_fits)", n, cin, cout, h, w);
     const int S = p8_wgrad_splits(n, cin, cout, h, w);
     const int coTiles = cdiv(cout, G_CO), ciTiles = cdiv(cin, G_CI), tilesC = cdiv(d.WS, 32);
     const int64_t nTiles = (int64_t)cdiv(d.ROWS, 4) * tilesC;

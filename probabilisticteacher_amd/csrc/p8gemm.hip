@@ -251,6 +251,11 @@ int64_t ptmi_p8_gemm_nt_ws_floats(int m, int n, int k)
     return S > 1 ? (int64_t)S * m * n : 0;
 }
 
+int ptmi_p8_gemm_nt_fits(int m, int n, int k)
+{
+    return m > 0 && n > 0 && k > 0 && (int64_t)cdiv(k, 8) * m * 16 < (1ll << 32) && (int64_t)cdiv(k, 8) * n * 16 < (1ll << 32);
+}
+
 int ptmi_p8_gemm_nt(const void* a, const void* b, float* c, const float* bias, float* ws, int m, int n, int k, int ldc, int relu,
                     ptmi_stream_t s)
 {

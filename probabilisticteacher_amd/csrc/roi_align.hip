@@ -170,9 +170,7 @@ __global__ __launch_bounds__(64) void roi_bin_tables_kernel(const float* __restr
 }
 
 constexpr int RF2_THREADS = 1024, RF2_SLOTS = 20, RF2_CG = 4;
-#ifndef RF2_CG8
-#define RF2_CG8 8
-#endif
+constexpr int RF2_CG8 = 8;   // channel planes per workgroup where they fit (variants: tools/exp/roi_variants.sh edits a COPY of this file)
 
 // PACK: instead of the fp32 (R, C, 7, 7) tensor the kernel writes the flattened ROI features as the bf16 "P8 matrix" operands of the
 // box head's first Linear layer under SOLVER.AMP.ENABLED (csrc/p8gemm.hip): xk[k / 8][R][8] (k = c * 49 + bin: the forward GEMM's
@@ -345,12 +343,8 @@ __global__ __launch_bounds__(64) void roi_bwd_tables_kernel(const float* __restr
 //   * everything a ROI needs is fetched while the previous one is accumulated: headers two ROIs ahead (scalar), the 4 x 49
 //     gradients, the band's rows of the Wy table and the first window's Wx rows one ahead.
 constexpr int RB3_PLANES = 4;
-#ifndef RB3_WAVES
-#define RB3_WAVES 8          // row bands = waves per workgroup (6 and 4 measured slower: tools/exp/roi_variants.sh)
-#endif
-#ifndef RB3_UNROLL
-#define RB3_UNROLL 2         // rows in flight per lane
-#endif
+constexpr int RB3_WAVES = 8;     // row bands = waves per workgroup (6 and 4 measured slower: tools/exp/roi_variants.sh)
+constexpr int RB3_UNROLL = 2;    // rows in flight per lane
 
 __global__ __launch_bounds__(64 * RB3_WAVES, RB3_WAVES == 6 ? 3 : 4) void roi_align_bwd_band_kernel(const float* __restrict__ dout, const void* __restrict__ ws,
                                                                  const int32_t* __restrict__ img_off, float* __restrict__ dfeat,

@@ -52,7 +52,12 @@ __global__ __launch_bounds__(LS_THREADS) void segsort_lds_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int beg = seg[blockIdx.x], n = seg[blockIdx.x + 1] - beg;
     if (n <= 0) return;
-    if (n > LS_CAP && (topk <= 0 || topk > LS_CAP || n >= 65536)) __builtin_trap();      // the caller's max_len / topk did not describe this segment
+    if (n > LS_CAP && (topk <= 0 || topk > LS_CAP || n >= 65536)) {
+        // the caller's max_len / topk did not describe this segment: no GPU fault (a trap aborts the process without a message --
+        // ADVICE r4) -- the segment's output is NaN keys over index 0, which the consumers' non-finite checks turn into an error
+        for (int i = tid; i < n; i += LS_THREADS) { keys_out[beg + i] = __builtin_nanf(""); idx_out[beg + i] = 0; }
+        return;
+    }
     const float* kin = keys_in + beg;
     int cnt;                                          // entries in LDS
     if (n <= LS_CAP) {

@@ -103,6 +103,10 @@ class BucketedGradReducer:
             raise ValueError(f"unknown gradient exchange {mode!r}")
         self.fp, self.world, self.group, self.mode = fp, world_size, group, mode
         self.active = world_size > 1 or force
+        # collectives of one group complete in issue order (RCCL's stream): the reduce-scatter mode can then issue each bucket's
+        # all-gather right behind its reduce-scatter
+        self.stream_ordered = bool(dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl")
+        self.gather_handles: List = []
         grad = fp.attach_grads()
         names = [n for n, p in fp.params.items() if p.requires_grad]
         self.buckets: List[Tuple[int, int]] = []         # (start, end) in elements, bucket 0 = tail of the buffer
@@ -154,9 +158,12 @@ class BucketedGradReducer:
     def reset(self):
         for h in getattr(self, "handles", []):      # collectives of an abandoned step: drain before re-arming
             h.wait()
+        for h in getattr(self, "gather_handles", []):
+            h.wait()
         self.pending = list(self.size)
         self.next = 0
         self.handles = []
+        self.gather_handles = []
         self.launched_in_backward = 0               # (diagnostic) buckets that left before finish()
 
     def _make_hook(self, bs):
@@ -170,12 +177,15 @@ class BucketedGradReducer:
         s, e = self.buckets[b]
         if self.mode == "all_reduce":
             self.handles.append(dist.all_reduce(self._grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        else:       # first half now (hidden behind the rest of backward); the all-gathers follow in finish(), after the
-            # reduce-scatters have completed -- no reliance on a backend running one group's collectives in issue order
-            # (RCCL's stream does, gloo's worker threads do not: a world-size-2 gloo test caught the all-gather overtaking)
+        else:       # first half now (hidden behind the rest of backward)
             buf = self.fp.grad_storage[s:e]
             self.handles.append(dist.reduce_scatter_tensor(self.shards[b], buf, op=dist.ReduceOp.SUM, group=self.group,
                                                            async_op=True))
+            if self.stream_ordered:
+                # RCCL runs one group's collectives in issue order on its stream: the all-gather can follow at once and overlaps
+                # with backward as well.  gloo's worker threads do not keep that order (a world-size-2 gloo test caught
+                # the all-gather overtaking): there it is issued in finish(), after the reduce-scatters have completed
+                self.gather_handles.append(dist.all_gather_into_tensor(buf, self.shards[b], group=self.group, async_op=True))
 
     def _launch_ready(self):
         while self.next < len(self.buckets) and self.pending[self.next] <= 0:
@@ -193,10 +203,12 @@ class BucketedGradReducer:
                 h.wait()
             self.handles = []
             if self.mode == "reduce_scatter":       # second half: every rank's reduced shard back into the flat buffer
-                hs = [dist.all_gather_into_tensor(self.fp.grad_storage[s:e], self.shards[b], group=self.group, async_op=True)
-                      for b, (s, e) in enumerate(self.buckets)]
+                hs = self.gather_handles if self.stream_ordered else [
+                    dist.all_gather_into_tensor(self.fp.grad_storage[s:e], self.shards[b], group=self.group, async_op=True)
+                    for b, (s, e) in enumerate(self.buckets)]
                 for h in hs:
                     h.wait()
+                self.gather_handles = []
             if self.world > 1:
                 self._grad.div_(self.world)
         n_early = self.launched_in_backward

@@ -86,6 +86,8 @@ class FastRCNNConvFCHead(nn.Module):
             dim = H.FC_DIM
         self.output_size = dim
 
+    accepts_deferred_roi_align = True      # forward() takes ROIPooler's DeferredROIAlign (SOLVER.AMP.ENABLED) as well as a tensor
+
     def forward(self, x):
         first = 0
         if isinstance(x, DeferredROIAlign):
@@ -271,6 +273,8 @@ class GuassianROIHead(nn.Module):
             proposals = self.label_and_sample_proposals(proposals, targets, branch=branch)
         feats = [features[f] for f in self.box_in_features]
         box_features = self.box_pooler(feats, [x.proposal_boxes for x in proposals])
+        if isinstance(box_features, DeferredROIAlign) and not getattr(self.box_head, "accepts_deferred_roi_align", False):
+            box_features = box_features.materialize()       # any other head registered in ROI_BOX_HEAD_REGISTRY gets a tensor
         predictions = self.box_predictor(self.box_head(box_features))
         del box_features
         if branch == "unsupervised" and self.training:

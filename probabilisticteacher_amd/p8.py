@@ -89,6 +89,15 @@ def wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, cin: int, cout: int, h: int
     """(dW (cout, cin, 3, 3), db (cout,)) fp32 from the layer's P8 input and P8 output gradient"""
     dw = torch.empty((cout, cin, 3, 3), dtype=F32, device=x.device)
     db = torch.empty(cout, dtype=F32, device=x.device)
+    if not _lib.load().ptmi_p8_wgrad_fits(n, cin, cout, h, w):
+        # a P8 tensor beyond the kernel's 32-bit offsets (ADVICE r4: conv1_2 with >= 32 images when blocks 1-2 are trainable): the
+        # direct fp32 split-K kernel on the WIDENED operands -- the same bf16-rounded products, fp32 accumulation, another summation order
+        x32, dy32 = to_nchw(_chk(x, cin, n, h, w, "p8 wgrad input"), n, cin, h, w), to_nchw(_chk(dy, cout, n, h, w, "p8 wgrad grad"), n, cout, h, w)
+        ws = ops._ws("wgrad", _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+        with ops._prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
+            _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x32), ops._ptr(dy32), ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0,
+                      ops._stream())
+        return dw, db
     ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
     with ops._prof("p8_wgrad", 2.0 * 9 * cin * cout * h * w * n):
         _lib.call("ptmi_p8_wgrad", ops._ptr(_chk(x, cin, n, h, w, "p8 wgrad input")), ops._ptr(_chk(dy, cout, n, h, w, "p8 wgrad grad")),
@@ -254,6 +263,9 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, m: int, n: int, k: int, bias: Opti
             swapped: bool = False) -> torch.Tensor:
     """C (m, n) fp32 = A . B^T (+ bias) (+ ReLU) from two packed operands (pack_matrix) with k octets each.
     swapped: compute C^T = B . A^T and store it transposed -- the same matrix through 16-byte stores (large, store-bound outputs)"""
+    if not _lib.load().ptmi_p8_gemm_nt_fits(m, n, k):
+        raise _lib.PtmiError(f"p8.gemm_nt: operands of {m} x {k} / {n} x {k} exceed the kernel's 32-bit buffer offsets (4 GiB per packed "
+                             "operand: fc1 up to ~85 k ROIs per call) -- lower the per-GPU batch or SOLVER.AMP.ENABLED = False")
     c = torch.empty((m, n), dtype=F32, device=a.device)
     if swapped:
         assert bias is None and not relu
@@ -279,7 +291,9 @@ class _LinearP8(torch.autograd.Function):
         n = weight.shape[0]
         y = gemm_nt(pack_matrix(x, r, k, k, True), pack_matrix(weight, n, k, k, True), r, n, k, bias, relu)
         # for dW the input is needed with the ROW index as k: packed now (bf16: half of what saving x would hold)
-        xt = pack_matrix(x, k, r, k, False) if ctx.needs_input_grad[1] else None
+        # (needs_input_grad reflects weight.requires_grad even under torch.no_grad(): student inference with trainable weights must
+        # not pack and write a second R x 25088 bf16 tensor nobody reads -- ADVICE r4)
+        xt = pack_matrix(x, k, r, k, False) if (torch.is_grad_enabled() and ctx.needs_input_grad[1]) else None
         ctx.meta = (r, k, n, relu, ctx.needs_input_grad[0])
         ctx.save_for_backward(xt, weight, y if relu else None)
         return y
@@ -310,7 +324,7 @@ class _RoiAlignLinearP8(torch.autograd.Function):
         weight, bias = ops._chk(weight.contiguous()), ops._chk(bias.contiguous())
         n_img, c, h, w = feat.shape
         r, k, n = rois.shape[0], c * pooled * pooled, weight.shape[0]
-        need_w = ctx.needs_input_grad[5]
+        need_w = torch.is_grad_enabled() and ctx.needs_input_grad[5]       # (see _LinearP8.forward)
         xk, xt = ops.roi_align_p8m(feat, rois, img_offsets, pooled, scale, need_w)
         y = gemm_nt(xk, pack_matrix(weight, n, k, k, True), r, n, k, bias, relu)
         ctx.meta = (r, k, n, relu, (n_img, c, h, w), pooled, float(scale))
