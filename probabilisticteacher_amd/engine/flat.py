@@ -93,7 +93,7 @@ class BucketedGradReducer:
     left (parameters that received no gradient this step keep their zeros), waits, and divides by the world size."""
 
     def __init__(self, fp: FlatParams, world_size: int, bucket_elems: int = 16 * 1024 * 1024, group=None,
-                 force: bool = False, mode: str = "all_reduce"):
+                 force: bool = False, mode: str = "all_reduce", last_bucket_elems: int = 2 * 1024 * 1024):
         """force: install the hooks and run the collectives even for world_size 1 (the sum over one rank is the identity;
         used to exercise the RCCL / stream-ordering path on a single GPU).
         mode: "all_reduce" -- one all-reduce per bucket; "reduce_scatter" -- the same exchange spelled as a reduce-scatter
@@ -121,6 +121,19 @@ class BucketedGradReducer:
                     self.bucket_of[m] = len(self.buckets)
                 self.buckets.append((off, end))
                 end, members = off, []
+        # the LAST bucket (the first trainable layers: their gradients are ready when backward ends, nothing is left to hide its
+        # exchange behind) is at most last_bucket_elems (8 MB): cut at the highest parameter boundary that keeps it so
+        if self.buckets and self.buckets[-1][1] - self.buckets[-1][0] > last_bucket_elems:
+            s0, e0 = self.buckets[-1]
+            b_last = len(self.buckets) - 1
+            bounds = sorted(fp.index[n][0] for n in names if s0 < fp.index[n][0] < e0)
+            cut = max([b for b in bounds if b - s0 <= last_bucket_elems], default=None)
+            if cut is not None:
+                self.buckets[-1] = (cut, e0)
+                self.buckets.append((s0, cut))
+                for n in names:
+                    if self.bucket_of.get(n) == b_last and fp.index[n][0] < cut:
+                        self.bucket_of[n] = b_last + 1
         if mode == "reduce_scatter":
             # bucket boundaries on multiples of the world size (equal shards): a cut moves UP to the next multiple, i.e. the
             # first elements of a bucket's lowest parameter travel with the following (later) bucket -- which therefore also
@@ -165,6 +178,7 @@ class BucketedGradReducer:
         self.handles = []
         self.gather_handles = []
         self.launched_in_backward = 0               # (diagnostic) buckets that left before finish()
+        self.tail_ms, self.tail_elems = getattr(self, "tail_ms", 0.0), getattr(self, "tail_elems", 0)
 
     def _make_hook(self, bs):
         def hook(_param):
@@ -196,6 +210,9 @@ class BucketedGradReducer:
     def finish(self) -> torch.Tensor:
         """Call after backward(): launches the remaining buckets in order, waits for all, averages."""
         if self.active:
+            import time
+            t0 = time.perf_counter()
+            self.tail_elems = sum(e - s for s, e in self.buckets[self.next:])     # (diagnostic) what could not leave during backward
             while self.next < len(self.buckets):
                 self._launch(self.next)
                 self.next += 1
@@ -211,6 +228,9 @@ class BucketedGradReducer:
                 self.gather_handles = []
             if self.world > 1:
                 self._grad.div_(self.world)
+            # (diagnostic) host time from the end of backward to the last collective's completion handle: with gloo (blocking
+            # waits) the exposed tail of the exchange; with RCCL the waits only order streams
+            self.tail_ms = 1e3 * (time.perf_counter() - t0)
         n_early = self.launched_in_backward
         self.reset()
         self.launched_in_backward = n_early
