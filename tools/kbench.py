@@ -41,8 +41,9 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--bf16", action="store_true", help="the FC GEMMs on ptmi_gemm_bf16 (fractions stay relative to the fp32 MFMA "
                                                         "peak); the bf16 3x3 convolutions are tools/kbench_p8.py's")
-    ap.add_argument("--algo", default="auto", choices=["auto", "direct"], help="fp32 forward / dgrad algorithm "
-                    "(auto = fused Winograd where it applies; TF/s are ALGORITHMIC direct-convolution FLOPs either way)")
+    ap.add_argument("--algo", default="auto", choices=["auto", "wino2", "direct"], help="fp32 forward / dgrad algorithm "
+                    "(auto = fused Winograd F(4x4,3x3) / F(2x2,3x3) where they apply, wino2 = F(2x2,3x3) only; TF/s are ALGORITHMIC "
+                    "direct-convolution FLOPs either way)")
     a = ap.parse_args()
     ops.set_conv_algo(a.algo)
     if a.bf16:
@@ -74,14 +75,23 @@ def main():
                           cout, h, w, 0, ops._stream())
             ms = timeit(f, a.iters)
             print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}")
-            if a.algo == "auto" and cout >= 64:
+            if a.algo in ("auto", "wino2") and cout >= 64:
                 ws2 = torch.empty(_lib.load().ptmi_conv3x3_wino_wgrad_ws_floats(a.n, cin, cout, h, w), device=dev)
 
                 def f2():
                     _lib.call("ptmi_conv3x3_wino_wgrad", ops._ptr(x), ops._ptr(dy), ops._ptr(dw), None, ops._ptr(ws2), a.n,
                               cin, cout, h, w, 0, ops._stream())
                 ms = timeit(f2, a.iters)
-                print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}  (winograd)")
+                print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}  (winograd F(2x2,3x3) domain)")
+                if _lib.load().ptmi_conv3x3_wino4_wgrad_fits(h, w):
+                    ws3 = torch.empty(_lib.load().ptmi_conv3x3_wino4_wgrad_ws_floats(a.n, cin, cout, h, w), device=dev)
+
+                    def f3():
+                        _lib.call("ptmi_conv3x3_wino4_wgrad", ops._ptr(x), ops._ptr(dy), ops._ptr(dw), None, ops._ptr(ws3), a.n,
+                                  cin, cout, h, w, 0, ops._stream())
+                    ms = timeit(f3, a.iters)
+                    print(f"{name:8s} wgrad n={a.n} {ms:9.3f} ms  {fl / ms / 1e9:7.1f} TF/s  {fl / ms / 1e9 / PEAK:5.1%}  (winograd F(4x4,3x3) domain"
+                          f"{'' if ops._wino4_wgrad_fill(h, w) >= ops._WINO4_WGRAD_MIN_FILL else '; NOT routed here: chunk fill < 0.9'})")
         del x
     if "gemm" in which:
         for r in (512 * a.n, 1024 * a.n, 2000 * a.n):
