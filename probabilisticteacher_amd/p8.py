@@ -284,16 +284,16 @@ class _LinearP8(torch.autograd.Function):
     operands packed with their contraction index as k; fp32 accumulation, fp32 y / dX / dW / db."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu: bool):
+    def forward(ctx, x, weight, bias, relu: bool, recording: bool = True):
         x = ops._chk(x.contiguous(), name="linear input")
         weight, bias = ops._chk(weight.contiguous()), ops._chk(bias.contiguous())
         r, k = x.shape
         n = weight.shape[0]
         y = gemm_nt(pack_matrix(x, r, k, k, True), pack_matrix(weight, n, k, k, True), r, n, k, bias, relu)
         # for dW the input is needed with the ROW index as k: packed now (bf16: half of what saving x would hold)
-        # (needs_input_grad reflects weight.requires_grad even under torch.no_grad(): student inference with trainable weights must
-        # not pack and write a second R x 25088 bf16 tensor nobody reads -- ADVICE r4)
-        xt = pack_matrix(x, k, r, k, False) if (torch.is_grad_enabled() and ctx.needs_input_grad[1]) else None
+        # (`recording` = torch.is_grad_enabled() at the CALL -- inside forward() grad mode is always off -- : inference with trainable
+        # weights must not pack and write a second R x 25088 bf16 tensor nobody reads; ADVICE r4)
+        xt = pack_matrix(x, k, r, k, False) if (recording and ctx.needs_input_grad[1]) else None
         ctx.meta = (r, k, n, relu, ctx.needs_input_grad[0])
         ctx.save_for_backward(xt, weight, y if relu else None)
         return y
@@ -311,7 +311,7 @@ class _LinearP8(torch.autograd.Function):
             dw = gemm_nt(pack_matrix(dz, n, r, n, False), xt, n, k, r)
         if ctx.needs_input_grad[2]:                        # the bias gradient sums the values the GEMMs consumed (rounded)
             db = ops.colsum(dz.to(BF16).to(F32))
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class _RoiAlignLinearP8(torch.autograd.Function):
@@ -320,11 +320,11 @@ class _RoiAlignLinearP8(torch.autograd.Function):
     over it); backward = _LinearP8's three GEMMs, then the grouped ROIAlign backward on dX."""
 
     @staticmethod
-    def forward(ctx, feat, rois, img_offsets, pooled: int, scale: float, weight, bias, relu: bool):
+    def forward(ctx, feat, rois, img_offsets, pooled: int, scale: float, weight, bias, relu: bool, recording: bool = True):
         weight, bias = ops._chk(weight.contiguous()), ops._chk(bias.contiguous())
         n_img, c, h, w = feat.shape
         r, k, n = rois.shape[0], c * pooled * pooled, weight.shape[0]
-        need_w = torch.is_grad_enabled() and ctx.needs_input_grad[5]       # (see _LinearP8.forward)
+        need_w = recording and ctx.needs_input_grad[5]       # (see _LinearP8.forward)
         xk, xt = ops.roi_align_p8m(feat, rois, img_offsets, pooled, scale, need_w)
         y = gemm_nt(xk, pack_matrix(weight, n, k, k, True), r, n, k, bias, relu)
         ctx.meta = (r, k, n, relu, (n_img, c, h, w), pooled, float(scale))
@@ -345,15 +345,15 @@ class _RoiAlignLinearP8(torch.autograd.Function):
             dw = gemm_nt(pack_matrix(dz, n, r, n, False), xt, n, k, r)
         if ctx.needs_input_grad[6]:
             db = ops.colsum(dz.to(BF16).to(F32))
-        return dfeat, None, None, None, None, dw, db, None
+        return dfeat, None, None, None, None, dw, db, None, None
 
 
 def roi_align_linear(feat, rois, img_offsets, pooled: int, scale: float, weight, bias, relu: bool) -> torch.Tensor:
-    return _RoiAlignLinearP8.apply(feat, rois, img_offsets, pooled, scale, weight, bias, relu)
+    return _RoiAlignLinearP8.apply(feat, rois, img_offsets, pooled, scale, weight, bias, relu, torch.is_grad_enabled())
 
 
 LINEAR_MIN_K = 4096        # below this (fc2, the predictors) the operand packs cost what the GEMM saves: ptmi_gemm_bf16 keeps those
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
-    return _LinearP8.apply(x, weight, bias, relu)
+    return _LinearP8.apply(x, weight, bias, relu, torch.is_grad_enabled())

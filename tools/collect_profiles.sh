@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round profile set, on the GPU box:  bash tools/collect_profiles.sh r04   -> gpurun_out/<tag>_* (copy what is judged into profiles/)
-TAG=${1:-r04}
+# Round profile set, on the GPU box:  bash tools/collect_profiles.sh r05   -> gpurun_out/<tag>_* (copy what is judged into profiles/)
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -28,6 +28,18 @@ timeout 600 python tools/kbench_p8.py --n 48 --which conv,dgrad,wgrad --iters 3 
 timeout 600 python tools/kbench_p8.py --n 16 --which gemm --iters 3 > gpurun_out/${TAG}_kbench_p8_fc1_gemm_bf16.txt 2>&1
 timeout 600 bash tools/exp/p8_pmc.sh conv3_2 conv 48 > gpurun_out/${TAG}_p8_conv3_2_fwd_n48_pmc.txt 2>&1
 timeout 600 bash tools/exp/p8_pmc.sh conv3_2 wgrad 48 > gpurun_out/${TAG}_p8_conv3_2_wgrad_n48_pmc.txt 2>&1
+# round 5: the F(4x4,3x3) kernels alone -- per-layer times against the F(2x2,3x3) kernels, per-tile phase stamps + shader clock,
+# elimination variants (tools/exp/make_wino4_variant.py must have been run in the dev container: tools/exp/_bin travels), HBM-side traffic
+timeout 600 python tools/exp/wino4_bench.py --n 16 --iters 10 > gpurun_out/${TAG}_wino4_vs_wino_per_layer_n16.txt 2>&1
+timeout 600 python tools/exp/wino4_bench.py --n 48 --iters 5 > gpurun_out/${TAG}_wino4_vs_wino_per_layer_n48.txt 2>&1
+timeout 600 python tools/exp/wino4w_bench.py --n 48 > gpurun_out/${TAG}_wino4_wgrad_vs_wino_wgrad_n48.txt 2>&1
+if [ -f tools/exp/_bin/libptmi355_w4_stamp.so ]; then
+  timeout 300 python tools/exp/wino4_bench.py --only4 --stamps --lib tools/exp/_bin/libptmi355_w4_stamp.so --n 16 --layers conv1_2,conv2_2,conv3_2,conv4_2 --iters 3 --reps 1 > gpurun_out/${TAG}_wino4_tile_stamps.txt 2>&1
+  for v in base noxf nolds nodma noho mfonly; do
+    [ -f tools/exp/_bin/libptmi355_w4_$v.so ] && { echo "== $v"; timeout 200 python tools/exp/wino4_bench.py --only4 --lib tools/exp/_bin/libptmi355_w4_$v.so --layers conv3_2,conv1_2 --n 16 --iters 10 2>&1 | grep conv; }
+  done > gpurun_out/${TAG}_wino4_elimination.txt 2>&1
+fi
+for L in conv1_2 conv3_2 conv4_2; do timeout 300 bash tools/exp/wino4_traffic.sh "" $L 48; done > gpurun_out/${TAG}_wino4_traffic_per_layer_n48.txt 2>&1
 # ROIAlign at the step's launch shapes / ROI extents, host-boundness of the step
 timeout 300 python tools/exp/roi_bench.py > gpurun_out/${TAG}_roi_align_step_shapes.txt 2>&1
 timeout 600 python tools/exp/host_bound.py > gpurun_out/${TAG}_host_bound_fp32.txt 2>&1
