@@ -253,20 +253,12 @@ def wino_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
 def wino4_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:
     """FLOPs of the v_mfma_f32_16x16x4_f32 instructions one ptmi_conv3x3_wino4_fwd launch issues: a wave runs 72 MFMAs
     (2048 FLOP each: 36 positions x two 16-channel tiles) per 4-channel chunk for its 32 channels x 16 tiles (one tile row of
-    the FLAT tile line, csrc/wino4.hip); waves none of whose tiles lies inside an image issue none."""
-    import numpy as np
+    the FLAT tile line, csrc/wino4.hip); the persistent kernel runs every wave of every tile (a wave whose tile row lies below
+    the image would idle its SIMD either way).  (Checked against SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, profiles/r05_*.)"""
     co_tiles, chunks, bands = -(-cout // 64), cin // 4, -(-h // 8)
     period = (w + 4) & ~3
-    n_strips = n * bands
-    n_pix = -(-(n_strips * period) // 64)
-    tu = (np.arange(n_pix, dtype=np.int64)[:, None] * 64 + 4 * np.arange(16, dtype=np.int64)[None, :])
-    st, px = tu // period, tu % period
-    col_ok = (st < n_strips) & (px < w)
-    band = st % bands
-    waves = 0
-    for wn in (0, 1):
-        waves += int((col_ok & (band * 8 + 4 * wn < h)).any(axis=1).sum())
-    return float(waves) * 2 * co_tiles * chunks * 72 * 2048
+    n_pix = -(-(n * bands * period) // 64)
+    return float(n_pix) * co_tiles * 4 * chunks * 72 * 2048
 
 
 def wino4_wgrad_issued_flops(n: int, cin: int, cout: int, h: int, w: int) -> float:

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """tools/gen_loss_curve_golden.py -- the ORACLE side of the bounded BASELINE configs[4] loss-curve test, run in the dev
-container (CPU, ~12 min per trajectory): final_s2c.yaml (K = 1), burn-in then mutual learning on the workload of
+container (CPU, ~12 min per 300-iteration trajectory on 8 threads; round 5's six 500-iteration trajectories: two processes of three
+seeds each on 3 threads, ~85 min, then --merge): final_s2c.yaml (K = 1), burn-in then mutual learning on the workload of
 tests/curve_common.py, once per sampler-key seed of curve_common.KEY_SEEDS (same data, same initial weights, different
 random anchor / ROI subsets: the spread between these trajectories is the yardstick the test measures the HIP side with).
 Commits only numbers: tests/golden/loss_curve_s2c.npz = per-iteration oracle losses of every trajectory (`<key>@<seed>`),
@@ -28,7 +29,21 @@ def main():
     ap.add_argument("--seeds", default="")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default="")
+    ap.add_argument("--merge", nargs="*", default=[], help="merge the .npz files of several --seeds runs (run in parallel processes) "
+                                                           "into tests/golden/loss_curve_s2c.npz, trajectories in curve_common.KEY_SEEDS order")
     a = ap.parse_args()
+    if a.merge:
+        parts = [np.load(f) for f in a.merge]
+        for q in parts[1:]:
+            assert (q["settings_keys"] == parts[0]["settings_keys"]).all() and (q["settings_vals"] == parts[0]["settings_vals"]).all()
+        arrays = {k: q[k] for q in parts for k in q.files if "@" in k}
+        have = sorted(int(s) for q in parts for s in q["seeds"])
+        assert have == sorted(cc.KEY_SEEDS), (have, cc.KEY_SEEDS)
+        out = a.out or os.path.join(ROOT, "tests", "golden", "loss_curve_s2c.npz")
+        np.savez_compressed(out, settings_keys=parts[0]["settings_keys"], settings_vals=parts[0]["settings_vals"],
+                            seeds=np.array(cc.KEY_SEEDS), **arrays)
+        print("wrote", out, os.path.getsize(out), "bytes")
+        return
     st = dict(cc.SETTINGS)
     for kv in a.set:
         k, v = kv.split("=")
