@@ -6,7 +6,8 @@
     (on the GPU box)  python tools/exp/wino4_bench.py --only4 --lib tools/exp/_bin/libptmi355_w4_noxf.so --layers conv3_2
 
 parts: mf = the MFMAs, xf = the input transforms' FMAs, wr = window reads, ar = A-operand reads, dma = the LDS-DMA instructions,
-ho = the hand-over (counted vmcnt, fix-ups, barrier).  The `else` of a removed `if constexpr` pair goes with it."""
+ho = the hand-over (counted vmcnt, fix-ups, barrier).  W4FILE=wino4w: the weight-gradient kernel (parts mf, xf, rd = raw operand
+reads, dma, ho) -> libptmi355_w4w_<name>.so.  The `else` of a removed `if constexpr` pair goes with it."""
 import os
 import subprocess
 import sys
@@ -27,7 +28,9 @@ def main():
     extra = []
     while args and args[0].startswith("-"):
         extra.append(args.pop(0))
-    src = open(os.environ.get("W4SRC", SRC)).read().splitlines()
+    which = os.environ.get("W4FILE", "wino4")       # wino4 (forward / dgrad) or wino4w (weight gradient)
+    objs = [o for o in objs if os.path.basename(o) != which + ".o"] + ([os.path.join(ROOT, "probabilisticteacher_amd", "_build", "wino4.o")] if which != "wino4" else [])
+    src = open(os.environ.get("W4SRC", os.path.join(ROOT, "probabilisticteacher_amd", "csrc", which + ".hip"))).read().splitlines()
     for name, parts in zip(args[0::2], args[1::2]):
         drop = set() if parts == "none" else set(parts.split(","))
         out = [ln for ln in src if not any(f"[x4:{p}]" in ln for p in drop)]
@@ -50,7 +53,7 @@ def main():
             obj = os.path.join(BIN, f"w4_{name}.o")
             subprocess.check_call(["hipcc"] + FLAGS + extra + ["-c", tmp, "-o", obj])
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
-                                   os.path.join(BIN, f"libptmi355_w4_{name}.so")] + objs + [obj])
+                                   os.path.join(BIN, f"libptmi355_{'w4' if which == 'wino4' else 'w4w'}_{name}.so")] + objs + [obj])
         finally:
             os.remove(tmp)
         print("built", name, "without", sorted(drop))
