@@ -761,9 +761,14 @@ int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, c
     const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;      // tile ids (colocate: some beyond nPix -- the end)
     PTMI_CHECK_ARG(nWg < (1ll << 31) - 4096, "conv3x3_wino4_fwd: too many tiles");
     // persistent workgroups: one per CU (a multiple of 8: a tile stays on the XCD of its id mod 8)
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
-        cus = 256;
+    static int cus_cached = 0;                               // (one query per process: 35 launches per step)
+    int cus = cus_cached;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            cus = 256;
+        cus_cached = cus;
+    }
     const int64_t grid = nWg < (cus / 8) * 8 ? nWg : (cus / 8) * 8;
     hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)grid), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
                        cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate, (int)nWg);
