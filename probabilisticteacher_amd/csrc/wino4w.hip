@@ -129,18 +129,15 @@ template <int... I, class F>
 __device__ __forceinline__ void zfor(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
 
 // ---- the k-step schedule: 18 slots (MFMA q on the current operands + its share of the NEXT k-step's operands)
-//   slots 0 .. 4: the 19 raw reads (four per slot: dY rows 0 .. 3, then the five window rows x three parts)
+//   slots 0 .. 6: the 19 raw reads (three per slot: dY rows 0 .. 3, then the five window rows x three parts)
 //   slot 7 of a chunk's first k-step: the hand-over for the next chunk
 //   slots 8, 10, .., 16: one DMA instruction each
-//   slots 6 .. 17: the 112 transform FMAs (0 .. 39 W: vertical 16, horizontal 24; 40 .. 75 V vertical; 76 .. 111 V horizontal) -- the first
-//   one five slots (> 300 cycles) behind the reads it consumes: with the FMAs from slot 2 on (first version) the wave sat in lgkmcnt
-//   waits -- removing the raw reads altogether gained 24 % (tools/exp/make_wino4_variant.py, W4FILE=wino4w)
+//   slots 2 .. 17: the 112 transform FMAs, seven per slot: 0 .. 39 W (vertical 16, horizontal 24), 40 .. 75 V vertical, 76 .. 111 V horizontal
+//   (reads four per slot and the FMAs from slot 6 on -- five slots behind the reads they consume -- measured 2 % SLOWER: the reads' cost
+//   is not latency)
 constexpr int ZHAND = 7;
-constexpr int ZRPS = 4;                                      // raw reads per slot
-constexpr int ZV0 = 6;                                       // first slot of the transform FMAs
 __host__ __device__ constexpr int z_dma_at(int s) { return (s >= 8 && s <= 16 && !(s & 1)) ? (s - 8) / 2 : -1; }
-__host__ __device__ constexpr int z_valu_before(int s) { return s <= ZV0 ? 0 : (s >= 18 ? 112 : ((s - ZV0) * 112) / (18 - ZV0)); }
-__host__ __device__ constexpr int z_reads_before(int s) { return s * ZRPS > 19 ? 19 : s * ZRPS; }
+__host__ __device__ constexpr int z_valu_before(int s) { return s < 2 ? 0 : ((s - 2) * 7 > 112 ? 112 : (s - 2) * 7); }
 
 template <int PH>
 __device__ __forceinline__ void wino4_wgrad_body(
@@ -361,10 +358,9 @@ __device__ __forceinline__ void wino4_wgrad_body(
                 constexpr int Q = decltype(q_c)::value;
                 if constexpr (Q < 16) zmfma_a(accA[Q], WA[KS][Q], VB[KS][Q]);   // [x4:mf]
                 else zmfma_v(accV[Q - 16], WA[KS][Q], VB[KS][Q]);   // [x4:mf]
-                {
-                    constexpr int r0 = z_reads_before(Q), r1 = z_reads_before(Q + 1);
-                    zfor(std::make_integer_sequence<int, r1 - r0>{}, [&](auto r_c) __attribute__((always_inline)) {
-                        raw_read(std::integral_constant<int, r0 + decltype(r_c)::value>{}, src, ks8);   // [x4:rd]
+                if constexpr (Q <= 6) {
+                    zfor(std::make_integer_sequence<int, (Q == 6 ? 1 : 3)>{}, [&](auto r_c) __attribute__((always_inline)) {
+                        raw_read(std::integral_constant<int, 3 * Q + decltype(r_c)::value>{}, src, ks8);   // [x4:rd]
                     });
                 }
                 if constexpr (Q == ZHAND && KS == 0) {
