@@ -39,6 +39,9 @@ if [ -f tools/exp/_bin/libptmi355_w4_stamp.so ]; then
     [ -f tools/exp/_bin/libptmi355_w4_$v.so ] && { echo "== $v"; timeout 200 python tools/exp/wino4_bench.py --only4 --lib tools/exp/_bin/libptmi355_w4_$v.so --layers conv3_2,conv1_2 --n 16 --iters 10 2>&1 | grep conv; }
   done > gpurun_out/${TAG}_wino4_elimination.txt 2>&1
 fi
+for v in base noxf nord nodma noho mfonly; do
+  [ -f tools/exp/_bin/libptmi355_w4w_$v.so ] && { echo "== $v"; timeout 200 python tools/exp/wino4w_bench.py --lib tools/exp/_bin/libptmi355_w4w_$v.so --layers conv3_2,conv4_2 --n 16 2>&1 | grep conv; }
+done > gpurun_out/${TAG}_wino4_wgrad_elimination.txt 2>&1
 for L in conv1_2 conv3_2 conv4_2; do timeout 300 bash tools/exp/wino4_traffic.sh "" $L 48; done > gpurun_out/${TAG}_wino4_traffic_per_layer_n48.txt 2>&1
 # ROIAlign at the step's launch shapes / ROI extents, host-boundness of the step
 timeout 300 python tools/exp/roi_bench.py > gpurun_out/${TAG}_roi_align_step_shapes.txt 2>&1
