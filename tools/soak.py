@@ -28,3 +28,6 @@ for i in range(iters):
         print(f"iter {i}: {ms:.0f} ms/it total_loss {m['total_loss']:.3f} grad_norm {m['grad_norm']:.1f} "
               f"allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB",
               flush=True)
+        bad = {k: v for k, v in m.items() if v != v}
+        if bad:                                  # which terms are NaN (an unsupervised term over ZERO rows is 0 / 0 in the reference too)
+            print("   non-finite metrics:", sorted(bad), " all:", {k: round(v, 4) for k, v in m.items()}, flush=True)
