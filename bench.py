@@ -191,6 +191,8 @@ def main():
                     help="N = 1 default run only: skip the two extra legs that the JSON line carries next to the fp32 headline -- "
                          "`amp` (the same workload with SOLVER.AMP.ENABLED, BASELINE configs[4]'s precision) and `student_only` "
                          "(BASELINE configs[1], batch 8)")
+    ap.add_argument("--batches", type=int, default=2,
+                    help="distinct synthetic batches resident in HBM, rotated over the steps (the `sustained` leg uses 4)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
                     help="auto (N = 1): measure roofline.traffic after the timed region by re-running one step under rocprofv3 "
                          "PMC passes; off: report the committed profile's number, labelled as such")
@@ -229,7 +231,8 @@ def main():
     def batch():
         return (synth_records(gen, B, H, W, K, dev), synth_records(gen, B, H, W, K, dev),
                 synth_records(gen, B, H, W, K, dev), synth_records(gen, B, H, W, K, dev))
-    batches = [batch() for _ in range(2)]                               # resident in HBM before timing
+    NB = max(1, args.batches)
+    batches = [batch() for _ in range(NB)]                              # resident in HBM before timing
 
     def sync():
         torch.cuda.synchronize()
@@ -243,7 +246,7 @@ def main():
     pool = torch.empty(min(64 << 30, total_mem // 4), dtype=torch.uint8, device=dev)
     del pool
     for i in range(args.warmup):
-        trainer.run_step(batches[i % 2])
+        trainer.run_step(batches[i % NB])
     sync()
     ops.profile_start()
     ms0 = torch.cuda.memory_stats()
@@ -251,7 +254,7 @@ def main():
     step_ms, early = [], []
     for i in range(args.steps):
         ts = time.perf_counter()
-        trainer.run_step(batches[i % 2])          # (ends with the metrics read-back, i.e. synchronised)
+        trainer.run_step(batches[i % NB])         # (ends with the metrics read-back, i.e. synchronised)
         step_ms.append(1e3 * (time.perf_counter() - ts))
         early.append(trainer.reducer.launched_in_backward)
     sync()
@@ -361,6 +364,24 @@ def main():
             size = ["--height", str(H), "--width", str(W)]
             out["amp"] = extra_leg(["--amp", "--per-gpu-batch", str(B)] + size)
             out["student_only"] = extra_leg(["--student-only", "--per-gpu-batch", "4"] + size, pmc="off")
+            # the headline workload again, 100 timed steps over FOUR rotating batches (ROI counts vary with the batch, so the
+            # allocator and the variable-size kernels see more shapes than in the 20-step / 2-batch headline)
+            out["sustained"] = extra_leg(["--per-gpu-batch", str(B), "--batches", "4"] + size, steps=100, pmc="off")
+
+            def compact(leg, with_roof=True):
+                if "error" in leg:
+                    return {"error": leg["error"][:60]}
+                c = {"value": round(leg["value"], 2), "ms_per_step": round(leg["ms_per_step"], 2)}
+                if with_roof:
+                    rf = leg["roofline"]
+                    c["frac"] = round(rf["frac"], 4)
+                    c["traffic_ratio"] = (round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3)
+                                          if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch") else None)
+                return c
+            # LAST key of the line, compact: what survives in a record that keeps only the tail of stdout
+            legs = {"amp": compact(out["amp"]), "student_only": compact(out["student_only"]),
+                    "sustained": dict(compact(out["sustained"], False), steps=100, batches=4)}
+            out["legs"] = legs
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

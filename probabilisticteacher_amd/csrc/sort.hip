@@ -54,7 +54,9 @@ __global__ __launch_bounds__(LS_THREADS) void segsort_lds_kernel(const float* __
     if (n <= 0) return;
     if (n > LS_CAP && (topk <= 0 || topk > LS_CAP || n >= 65536)) {
         // the caller's max_len / topk did not describe this segment: no GPU fault (a trap aborts the process without a message --
-        // ADVICE r4) -- the segment's output is NaN keys over index 0, which the consumers' non-finite checks turn into an error
+        // ADVICE r4) -- the segment's output is NaN keys over index 0.  The host wrapper (ops.segsort_desc) checks the callers'
+        // host-side segment lengths against max_len before the launch, so the product path cannot get here; a raw
+        // C-ABI caller sees the NaNs
         for (int i = tid; i < n; i += LS_THREADS) { keys_out[beg + i] = __builtin_nanf(""); idx_out[beg + i] = 0; }
         return;
     }

@@ -10,6 +10,8 @@ collectives on the flat gradient buffer (sized for xGMI: big messages, no per-te
 from collections import OrderedDict
 from typing import Dict, List, Tuple
 
+import time
+
 import torch
 import torch.distributed as dist
 from torch import nn
@@ -103,6 +105,7 @@ class BucketedGradReducer:
             raise ValueError(f"unknown gradient exchange {mode!r}")
         self.fp, self.world, self.group, self.mode = fp, world_size, group, mode
         self.active = world_size > 1 or force
+        self.diagnostics = False        # True: finish() also measures tail_ms (host clock; tests / tools set it, the step does not pay for it)
         # collectives of one group complete in issue order (RCCL's stream): the reduce-scatter mode can then issue each bucket's
         # all-gather right behind its reduce-scatter
         self.stream_ordered = bool(dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl")
@@ -183,6 +186,12 @@ class BucketedGradReducer:
     def _make_hook(self, bs):
         def hook(_param):
             for b in bs:
+                # a bucket that has left must never be touched again: its collective (and, on RCCL, the in-place all-gather) owns
+                # grad_storage[s:e] until finish().  One backward() per step keeps this true; a second backward or gradient
+                # accumulation without finish() / zero_grad() in between would not -- fail loudly instead of racing
+                if b < self.next:
+                    raise RuntimeError(f"gradient bucket {b} received another gradient after its collective was launched: "
+                                       "call finish() (or zero_grad()) between two backward passes")
                 self.pending[b] -= 1
             self._launch_ready()
         return hook
@@ -210,8 +219,7 @@ class BucketedGradReducer:
     def finish(self) -> torch.Tensor:
         """Call after backward(): launches the remaining buckets in order, waits for all, averages."""
         if self.active:
-            import time
-            t0 = time.perf_counter()
+            t0 = time.perf_counter() if self.diagnostics else 0.0
             self.tail_elems = sum(e - s for s, e in self.buckets[self.next:])     # (diagnostic) what could not leave during backward
             while self.next < len(self.buckets):
                 self._launch(self.next)
@@ -230,7 +238,8 @@ class BucketedGradReducer:
                 self._grad.div_(self.world)
             # (diagnostic) host time from the end of backward to the last collective's completion handle: with gloo (blocking
             # waits) the exposed tail of the exchange; with RCCL the waits only order streams
-            self.tail_ms = 1e3 * (time.perf_counter() - t0)
+            if self.diagnostics:
+                self.tail_ms = 1e3 * (time.perf_counter() - t0)
         n_early = self.launched_in_backward
         self.reset()
         self.launched_in_backward = n_early

@@ -205,7 +205,7 @@ class GuassianFastRCNNOutputLayers(nn.Module):
         if cap > 524288:
             raise ValueError(f"ROI inference: {K} classes x {max(counts)} proposals = {cap} NMS candidates per image exceed the "
                              "524 288 the single-pass bitmask NMS holds; lower MODEL.RPN.POST_NMS_TOPK_TEST")
-        srt, order = ops.segsort_desc(keys.view(-1), seg, max_len=cap)
+        srt, order = ops.segsort_desc(keys.view(-1), seg, max_len=cap, lengths=[K * c for c in counts])
         nms_boxes = ops.roi_infer_nms_boxes(boxes, order, seg, img_max, cap, K)
         topk = self.test_topk_per_image if self.test_topk_per_image >= 0 else max(cap, 1)
         keep, kcnt = ops.nms_batched(nms_boxes, seg, cap, float(self.test_nms_thresh), int(max(topk, 1)),

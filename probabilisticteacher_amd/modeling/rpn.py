@@ -79,13 +79,13 @@ def find_top_rpn_proposals(decoded, logits, sigma_logits, image_sizes, nms_thres
     dev = logits.device
     k = min(r, pre_nms_topk)
     seg = torch.arange(0, (n + 1) * r, r, dtype=torch.int32, device=dev)
-    srt, idx = ops.segsort_desc(logits.reshape(-1), seg, max_len=r, topk=k)      # (rpn_prepare reads the first k of each row)
+    srt, idx = ops.segsort_desc(logits.reshape(-1), seg, max_len=r, topk=k, lengths=(r,) * n)      # (rpn_prepare reads the first k of each row)
     sizes = torch.tensor([[float(h), float(w)] for h, w in image_sizes], dtype=torch.float32).pin_memory().to(
         dev, non_blocking=True)
     boxes, keys, counts, nonfinite = ops.rpn_prepare(decoded, srt.view(n, r), idx.view(n, r), sigma_logits, sizes, k,
                                                      float(min_box_size))
     seg2 = torch.arange(0, (n + 1) * k, k, dtype=torch.int32, device=dev)
-    s2, i2 = ops.segsort_desc(keys.view(-1), seg2, max_len=k)
+    s2, i2 = ops.segsort_desc(keys.view(-1), seg2, max_len=k, lengths=(k,) * n)
     sb = torch.gather(boxes, 1, i2.view(n, k, 1).long().expand(n, k, 4)).view(n * k, 4)
     keep, kcnt = ops.nms_batched(sb, seg2, k, float(nms_thresh), int(post_nms_topk), seg_counts=counts)
     host = torch.cat([kcnt, nonfinite]).cpu().tolist()                # the one sync

@@ -179,15 +179,14 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
     dw = torch.empty(cout, cin, 3, 3, dtype=F32, device=x.device)
     db = torch.empty(cout, dtype=F32, device=x.device)
     lib = _lib.load()
-    if (_CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and cin >= _WINO4_WGRAD_MIN_CIN and cout >= _WINO_WGRAD_MIN_C
-            and lib.ptmi_conv3x3_wino4_wgrad_fits(h, w) and _wino4_wgrad_fill(h, w) >= _WINO4_WGRAD_MIN_FILL):
+    kind = _wgrad_kind(cin, cout, h, w)
+    if kind == "wino4w":
         # round 5: the F(4x4,3x3)-domain kernel (csrc/wino4w.hip; workgroup = 64 co x 32 ci)
         ws = _ws("wgrad", lib.ptmi_conv3x3_wino4_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
         with _prof("conv3x3_wino4_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino4_wgrad_issued_flops(n, cin, cout, h, w)):
             _lib.call("ptmi_conv3x3_wino4_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
                       _stream())
-    elif (_use_wino(cin) and cin >= _WINO_WGRAD_MIN_C and cout >= _WINO_WGRAD_MIN_C
-            and lib.ptmi_conv3x3_wino_wgrad_fits(h, w)):
+    elif kind == "wino":
         ws = _ws("wgrad", lib.ptmi_conv3x3_wino_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
         with _prof("conv3x3_wino_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino_wgrad_issued_flops(n, cin, cout, h, w)):
             _lib.call("ptmi_conv3x3_wino_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
@@ -219,6 +218,19 @@ _WINO4_WGRAD_MIN_FILL = 0.9    # ... and walks the map in chunks of 4 rows x 16 
 
 def _wino4_wgrad_fill(h: int, w: int) -> float:
     return (h * w) / float(-(-h // 4) * 4 * -(-w // 16) * 16)
+
+
+def _wgrad_kind(cin: int, cout: int, h: int, w: int) -> str:
+    """'wino4w' | 'wino' | 'direct': the kernel family ops.conv3x3_wgrad routes a weight-gradient launch of this shape to
+    (F(4x4,3x3)-domain csrc/wino4w.hip, F(2x2,3x3)-domain csrc/wino.hip, direct split-K csrc/conv.hip)"""
+    lib = _lib.load()
+    if (_CONV_ALGO == "auto" and _OPERAND_ROUNDING is None and cin >= _WINO4_WGRAD_MIN_CIN and cout >= _WINO_WGRAD_MIN_C
+            and lib.ptmi_conv3x3_wino4_wgrad_fits(h, w) and _wino4_wgrad_fill(h, w) >= _WINO4_WGRAD_MIN_FILL):
+        return "wino4w"
+    if (_use_wino(cin) and cin >= _WINO_WGRAD_MIN_C and cout >= _WINO_WGRAD_MIN_C
+            and lib.ptmi_conv3x3_wino_wgrad_fits(h, w)):
+        return "wino"
+    return "direct"
 
 
 def set_conv_algo(mode: str) -> None:
@@ -896,14 +908,23 @@ def rpn_subsample_relabel(labels: torch.Tensor, keys: torch.Tensor, num_samples:
 
 # ============================================================================ sort / proposals / NMS
 def segsort_desc(keys: torch.Tensor, seg_offsets: torch.Tensor, max_len: Optional[int] = None,
-                 topk: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                 topk: Optional[int] = None, lengths: Optional[Sequence[int]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Stable descending sort inside each segment.  Returns (sorted keys, index within segment int32).
     max_len: the longest segment, if the caller knows it (no device read here) -- segments of up to 16 384 keys are then sorted
     by the LDS kernel; topk: the caller only reads the first topk entries of every segment (longer segments come back with
-    their first topk entries in order and (-inf, 0) behind them)."""
+    their first topk entries in order and (-inf, 0) behind them).  lengths: the HOST copy of the segment lengths the caller
+    built seg_offsets from -- checked here against max_len and the key count (a max_len that does not describe the
+    segments makes the LDS kernel emit NaN keys, which only one of the three callers would have noticed; all three now pass
+    their host lengths, so the mismatch is a PtmiError before any launch)."""
     keys = _chk(keys.contiguous())
     seg_offsets = _chk(seg_offsets.contiguous(), torch.int32)
     total, nseg = keys.numel(), seg_offsets.numel() - 1
+    if lengths is not None:
+        longest = max(lengths) if len(lengths) else 0
+        if len(lengths) != nseg or sum(lengths) != total or (max_len is not None and longest > max_len):
+            raise _lib.PtmiError(f"segsort_desc: segment lengths {list(lengths)[:8]}... (n = {len(lengths)}, sum {sum(lengths)}, longest "
+                                 f"{longest}) do not match {nseg} segments / {total} keys / max_len {max_len}")
+        max_len = longest if max_len is None else max_len
     out = torch.empty_like(keys)
     idx = torch.empty(total, dtype=torch.int32, device=keys.device)
     if total == 0:

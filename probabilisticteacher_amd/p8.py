@@ -85,18 +85,38 @@ def conv3x3_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     return y
 
 
+_WGRAD_FALLBACK_BYTES = 1 << 30     # per fp32 operand copy of p8.wgrad's oversize fallback
+
+
+def _widen_images(t: torch.Tensor, n: int, c: int, h: int, w: int, i0: int, i1: int) -> torch.Tensor:
+    """fp32 (i1 - i0, C, H, W) of images i0 .. i1 - 1 of a P8 tensor (exact: bf16 -> fp32).  A strided view + one copy: the
+    oversize fallback of wgrad only (the whole-tensor conversion is the HIP kernel behind to_nchw)."""
+    v = t[:, 1:, 1:, :].reshape(t.shape[0], n, h + 1, w, 8)[:, i0:i1, :h]          # (planes, k, H, W, 8)
+    return v.permute(1, 0, 4, 2, 3).reshape(i1 - i0, t.shape[0] * 8, h, w)[:, :c].to(F32).contiguous()
+
+
 def wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, cin: int, cout: int, h: int, w: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """(dW (cout, cin, 3, 3), db (cout,)) fp32 from the layer's P8 input and P8 output gradient"""
     dw = torch.empty((cout, cin, 3, 3), dtype=F32, device=x.device)
     db = torch.empty(cout, dtype=F32, device=x.device)
     if not _lib.load().ptmi_p8_wgrad_fits(n, cin, cout, h, w):
         # a P8 tensor beyond the kernel's 32-bit offsets (ADVICE r4: conv1_2 with >= 32 images when blocks 1-2 are trainable): the
-        # direct fp32 split-K kernel on the WIDENED operands -- the same bf16-rounded products, fp32 accumulation, another summation order
-        x32, dy32 = to_nchw(_chk(x, cin, n, h, w, "p8 wgrad input"), n, cin, h, w), to_nchw(_chk(dy, cout, n, h, w, "p8 wgrad grad"), n, cout, h, w)
-        ws = ops._ws("wgrad", _lib.load().ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
-        with ops._prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
-            _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x32), ops._ptr(dy32), ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0,
-                      ops._stream())
+        # direct fp32 split-K kernel on the WIDENED operands -- the same bf16-rounded products, fp32 accumulation, another summation
+        # order -- over groups of images (accumulate = 1 from the second group on), so that the two fp32 copies stay bounded
+        # (ADVICE r5: 8.7 GB each for conv1_2 with 32 images when widened whole)
+        _chk(x, cin, n, h, w, "p8 wgrad input")
+        _chk(dy, cout, n, h, w, "p8 wgrad grad")
+        group = max(1, min(n, _WGRAD_FALLBACK_BYTES // (4 * max(cin, cout) * h * w)))
+        dbg = torch.empty(cout, dtype=F32, device=x.device)
+        for i0 in range(0, n, group):
+            i1 = min(n, i0 + group)
+            x32, dy32 = _widen_images(x, n, cin, h, w, i0, i1), _widen_images(dy, n, cout, h, w, i0, i1)
+            ws = ops._ws("wgrad", _lib.load().ptmi_conv3x3_wgrad_ws_floats(i1 - i0, cin, cout, h, w) * 4, x.device)
+            with ops._prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * (i1 - i0)):
+                _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x32), ops._ptr(dy32), ops._ptr(dw), ops._ptr(dbg if i0 else db), ops._ptr(ws),
+                          i1 - i0, cin, cout, h, w, int(i0 > 0), ops._stream())
+            if i0:
+                db += dbg
         return dw, db
     ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
     with ops._prof("p8_wgrad", 2.0 * 9 * cin * cout * h * w * n):

@@ -25,6 +25,7 @@ from tests.helpers import close, keyed_perm_source, match_detections
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+MAX_TIED_ROWS_PERMUTED = 4      # per image and proposal stage: rows allowed to move inside a 1e-6-relative score tie (see _ProposalLog.check)
 
 
 def _threads():
@@ -225,9 +226,9 @@ def test_frozen_blocks_and_rpn_conv_full_size_vs_torch():
 
 def test_conv3_2_at_n48_bench_launch_shape_vs_torch():
     """ONE launch of each conv3_2 kernel at the joint student pass's batch (n = 48 = 32 labelled views + 16 unlabelled):
-    forward (epilogue 1), dgrad with the producer's ReLU mask (epilogue 3) on the Winograd kernel; weight + bias gradient on the
-    Winograd-domain kernel (the one the fp32 step runs) AND on the direct split-K kernel (n = 48 split count, merged main +
-    right-edge launch)."""
+    forward (epilogue 1), dgrad with the producer's ReLU mask (epilogue 3) on the F(4x4,3x3) kernel (csrc/wino4.hip); weight +
+    bias gradient on the F(4x4,3x3)-domain kernel (csrc/wino4w.hip, the one the fp32 step runs) AND on the direct split-K
+    kernel (n = 48 split count, merged main + right-edge launch).  The routes are asserted, not assumed."""
     from probabilisticteacher_amd import ops
     from probabilisticteacher_amd import _lib
     _threads()
@@ -242,16 +243,19 @@ def test_conv3_2_at_n48_bench_launch_shape_vs_torch():
     yrelu = F.relu(yr)
     yr.backward(gy)
     xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
+    assert ops._conv_kind(c, c, (h, w)) == "wino4", "conv3_2 forward / dgrad must route to the F(4x4,3x3) kernel"
     yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0, 1, (h, w)), bd, None, c, 1)
     _rel(yd, yrelu.detach(), 1e-4, "conv3_2 forward n=48")
     del yd
     dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1, 3, (h, w)), None, xd, c, 3)
     _rel(dx, xr.grad * (x > 0), 1e-4, "conv3_2 dgrad + mask n=48")
     del dx
-    # the kernel the fp32 step runs (ops.conv3x3_wgrad routes 64+-channel fp32 layers to ptmi_conv3x3_wino_wgrad): 3.3 GB per
-    # operand -- the shape where its 32-bit buffer offsets, split count and chunk clamp matter
-    assert ops._use_wino(c, c, (h, w)) and _lib.load().ptmi_conv3x3_wino_wgrad_fits(h, w)
+    # the kernel the fp32 step runs (ops.conv3x3_wgrad routes this shape to ptmi_conv3x3_wino4_wgrad): 3.3 GB per operand -- the
+    # shape where its 32-bit buffer offsets, split count and chunk clamp matter
+    assert ops._wgrad_kind(c, c, h, w) == "wino4w", "conv3_2 weight gradient must route to the F(4x4,3x3)-domain kernel"
+    ops.profile_start()
     dw, db = ops.conv3x3_wgrad(xd, gd, c)
+    assert list(ops.profile_stop()) == ["conv3x3_wino4_wgrad"]
     _rel(dw, wr.grad, 1e-4, "conv3_2 Winograd wgrad n=48")
     _rel(db, br.grad, 1e-4, "conv3_2 Winograd bias grad n=48")
     dw2, db2 = ops.conv3x3_wgrad(xd, gd, c)
@@ -267,9 +271,9 @@ def test_conv3_2_at_n48_bench_launch_shape_vs_torch():
 
 
 def test_conv4_2_at_n48_bench_launch_shape_vs_torch():
-    """The 512-channel launch shape of the joint student pass (n = 48, 512 -> 512 at 100 x 166): Winograd forward (8 channel
-    tiles: one U slab per XCD), dgrad with the producer's ReLU mask, Winograd weight + bias gradient (chunks of 7 k-steps: 42 tile
-    pairs per row), each as ONE launch against torch CPU fp32."""
+    """The 512-channel launch shape of the joint student pass (n = 48, 512 -> 512 at 100 x 166): F(4x4,3x3) forward (8 channel
+    tiles), dgrad with the producer's ReLU mask, F(4x4,3x3)-domain weight + bias gradient (chunks of 4 rows x 16 columns, fill
+    0.94), each as ONE launch against torch CPU fp32; routes asserted."""
     from probabilisticteacher_amd import ops
     from probabilisticteacher_amd import _lib
     _threads()
@@ -284,16 +288,62 @@ def test_conv4_2_at_n48_bench_launch_shape_vs_torch():
     yrelu = F.relu(yr)
     yr.backward(gy)
     xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
-    assert ops._use_wino(c, c, (h, w)) and _lib.load().ptmi_conv3x3_wino_wgrad_fits(h, w)
+    assert ops._conv_kind(c, c, (h, w)) == "wino4" and ops._wgrad_kind(c, c, h, w) == "wino4w"
     yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0, 1, (h, w)), bd, None, c, 1)
     _rel(yd, yrelu.detach(), 1e-4, "conv4_2 forward n=48")
     del yd
     dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1, 3, (h, w)), None, xd, c, 3)
     _rel(dx, xr.grad * (x > 0), 1e-4, "conv4_2 dgrad + mask n=48")
     del dx
+    ops.profile_start()
     dw, db = ops.conv3x3_wgrad(xd, gd, c)
+    assert list(ops.profile_stop()) == ["conv3x3_wino4_wgrad"]
     _rel(dw, wr.grad, 1e-4, "conv4_2 Winograd wgrad n=48")
     _rel(db, br.grad, 1e-4, "conv4_2 Winograd bias grad n=48")
+
+
+def test_conv5_2_at_n48_bench_launch_shape_vs_torch():
+    """The 50 x 83 launch shape of the joint student pass (n = 48, 512 -> 512; conv5_x and the RPN conv): F(4x4,3x3) forward and
+    dgrad, and the weight + bias gradient on whichever kernel ops.conv3x3_wgrad routes this map to (the route is printed and its
+    profile key asserted: round 5 kept it on the F(2x2,3x3)-domain kernel conv3x3_wino_wgrad_kernel<7>, chunk fill 0.83), each
+    as ONE launch against torch CPU fp32.  Both weight-gradient kernels are checked at this shape, whatever the route."""
+    from probabilisticteacher_amd import ops
+    from probabilisticteacher_amd import _lib
+    _threads()
+    gen = torch.Generator().manual_seed(4852)
+    n, c, h, w = 48, 512, 50, 83
+    x = torch.relu(torch.randn(n, c, h, w, generator=gen))
+    wt = torch.randn(c, c, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * c))
+    b = torch.randn(c, generator=gen) * 0.1
+    gy = torch.randn(n, c, h, w, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br, padding=1)
+    yrelu = F.relu(yr)
+    yr.backward(gy)
+    xd, wd, bd, gd = x.to(DEV), wt.to(DEV), b.to(DEV), gy.to(DEV)
+    assert ops._conv_kind(c, c, (h, w)) == "wino4"
+    yd = ops.conv3x3_raw(xd, ops.conv3x3_pack(wd, 0, 1, (h, w)), bd, None, c, 1)
+    _rel(yd, yrelu.detach(), 1e-4, "conv5_2 forward n=48")
+    del yd
+    dx = ops.conv3x3_raw(gd, ops.conv3x3_pack(wd, 1, 3, (h, w)), None, xd, c, 3)
+    _rel(dx, xr.grad * (x > 0), 1e-4, "conv5_2 dgrad + mask n=48")
+    del dx
+    kind = ops._wgrad_kind(c, c, h, w)
+    print(f"conv5_2 n=48 weight-gradient route: {kind}")
+    assert kind in ("wino", "wino4w")
+    ops.profile_start()
+    dw, db = ops.conv3x3_wgrad(xd, gd, c)
+    assert list(ops.profile_stop()) == [{"wino": "conv3x3_wino_wgrad", "wino4w": "conv3x3_wino4_wgrad"}[kind]]
+    _rel(dw, wr.grad, 1e-4, f"conv5_2 routed ({kind}) wgrad n=48")
+    _rel(db, br.grad, 1e-4, f"conv5_2 routed ({kind}) bias grad n=48")
+    lib = _lib.load()
+    for name in ("ptmi_conv3x3_wino_wgrad", "ptmi_conv3x3_wino4_wgrad"):       # both Winograd-domain kernels, called by name
+        assert getattr(lib, name + "_fits")(h, w)
+        dw, db = torch.empty_like(wd), torch.empty(c, device=DEV)
+        ws = torch.empty(getattr(lib, name + "_ws_floats")(n, c, c, h, w), device=DEV)
+        _lib.call(name, ops._ptr(xd), ops._ptr(gd), ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, c, c, h, w, 0, ops._stream())
+        _rel(dw, wr.grad, 1e-4, f"conv5_2 {name} n=48")
+        _rel(db, br.grad, 1e-4, f"conv5_2 {name} bias grad n=48")
 
 
 def _records(gen, n_img, h, w, K, m0=3):
@@ -416,12 +466,20 @@ class _ProposalLog:
                 run = torch.zeros(len(rs), dtype=torch.long)
                 run[1:] = torch.cumsum(((srt[:-1] - srt[1:]).abs() > 1e-6 * srt[:-1].abs()).long(), 0)
                 bad = (hb != rb).any(dim=1)
+                n_perm = int(bad.sum())
                 for rid in run[bad].unique().tolist():
                     rows = (run == rid).nonzero()[:, 0]
                     a = sorted(map(tuple, hb[rows].tolist()))
                     b = sorted(map(tuple, rb[rows].tolist()))
                     assert len(rows) > 1 and a == b, ("HIP proposals differ from the oracle's find_top_rpn_proposals run on the SAME "
                                                       f"inputs beyond a permutation of score-tied rows: rows {rows.tolist()}")
+                # the relaxation is BOUNDED and reported: at most MAX_TIED_ROWS_PERMUTED rows per image may sit at another position
+                # of their tie run (north_star: keep-masks bit-exact -- the kept SET is still exact, only the order inside a tie moves)
+                print(f"  proposal stage call {k}: {n_perm} of {len(hb)} proposal rows permuted inside 1e-6-relative score ties "
+                      f"(cap {MAX_TIED_ROWS_PERMUTED})")
+                self.permuted_rows = getattr(self, "permuted_rows", 0) + n_perm
+                assert n_perm <= MAX_TIED_ROWS_PERMUTED, (f"{n_perm} proposal rows of stage call {k} are permuted inside score ties: more "
+                                                          f"than the {MAX_TIED_ROWS_PERMUTED} a last-ulp sigmoid difference explains")
                 hs = hs.clone()
                 hs_sorted, rs_sorted = torch.sort(hs, descending=True)[0], torch.sort(rs, descending=True)[0]
                 close(hs_sorted, rs_sorted, 1e-5, 1e-6, "proposal scores on identical inputs (tied rows permuted)")
@@ -643,3 +701,25 @@ def test_baseline_config3_per_gpu_share_b8_plus_8_1333x800_vs_oracle(monkeypatch
         print(f"\n[configs[3] per-GPU share 1333x800 B=8+8] proposals: {res['log'].check_sets()}; pseudo labels "
               f"{[len(p) for p in res['tr'].mine]}; losses HIP {m} oracle {om}")
     _compare_step(m, om, res["tr"], res["state"], res["params"], SUP + UNSUP, "configs[3] per-GPU share B=8+8")
+
+
+def test_baseline_config2_bench_batch_b16_plus_16_1333x800_vs_oracle(monkeypatch, capsys):
+    """configs[2] at the BENCH's batch (16 labelled + 16 unlabelled 1333 x 800 images on one GPU; VERDICT r5 weak #3 / next-round
+    item 7): the joint 48-image student pass, the 16-image teacher pass, matcher / sampler / NMS / pseudo-label relabelling batched
+    over 16 / 32 / 48 images -- the exact launch shapes `bench.py` times -- against the oracle's per-image loops.  Same bar as the
+    smaller steps: 8 losses 1e-4, gradient norm 1e-3, updated-parameter probes 1e-4; proposals exact up to the bounded tie
+    permutation (MAX_TIED_ROWS_PERMUTED).  The oracle keeps the activations of a 48-image fp32 backward in host memory
+    (~ 2.6 GB per image and pass): skipped, with the reason, on a host with < 400 GB available."""
+    import psutil
+    avail = psutil.virtual_memory().available / 2 ** 30
+    if avail < 400:
+        pytest.skip(f"the CPU oracle's 48-image backward needs ~ 300 GB of host memory; {avail:.0f} GB available "
+                    "(the 8 + 8 step above covers the same code paths at n = 24)")
+    res = mutual_learning_step_vs_oracle(monkeypatch, "configs/pt/final_c2f.yaml", 800, 1333, n_img=16, seed=161)
+    m, om = res["m"], res["om"]
+    check_teacher_and_pseudo_labels(res)
+    assert set(SUP + UNSUP) <= set(m) and set(SUP + UNSUP) <= set(om)
+    with capsys.disabled():
+        print(f"\n[configs[2] bench batch 1333x800 B=16+16] proposals: {res['log'].check_sets()}; pseudo labels "
+              f"{[len(p) for p in res['tr'].mine]}; losses HIP {m} oracle {om}")
+    _compare_step(m, om, res["tr"], res["state"], res["params"], SUP + UNSUP, "configs[2] bench batch B=16+16")

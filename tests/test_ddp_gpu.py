@@ -183,13 +183,19 @@ def _install_gloo_cuda_shims():
     dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_gather = all_gather_into_tensor, reduce_scatter_tensor, all_gather
 
 
-def _two_rank_worker(rank, world, port, mode, q):
+def _two_rank_worker(rank, world, port, mode, q, backend="gloo"):
     import numpy as np
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    _install_gloo_cuda_shims()
+    if backend == "nccl":                            # RCCL, one GPU per rank (needs >= 2 visible GPUs)
+        DEV = f"cuda:{rank}"                         # noqa: N806  (shadows the module constant for everything below)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV))
+    else:
+        DEV = "cuda:0"                               # noqa: N806
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        _install_gloo_cuda_shims()
     from bench import synth_records
     from probabilisticteacher_amd.config import setup_cfg
     from probabilisticteacher_amd.engine import PTrainer
@@ -297,6 +303,33 @@ def test_real_run_step_on_two_ranks_sharing_the_gpu(mode):
         assert abs(got - want) <= 1e-6 * abs(want) + 1e-7, f"step 0 {k}: reported {got} vs mean of the local losses {want}"
 
 
+@pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
+def test_real_run_step_on_two_ranks_over_rccl(mode):
+    """the same three-step, two-rank check as above on the `nccl` (= RCCL) backend with one GPU per rank -- the only
+    configuration that takes the stream-ordered path of engine/flat.py (each bucket's in-place all-gather issued right behind its
+    reduce-scatter, during backward).  Needs two visible GPUs: skipped, with the reason, on the 1-GPU boxes this repo is tested on."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"{torch.cuda.device_count()} GPU visible: the 2-rank RCCL run needs 2 (the gloo variant above runs everywhere)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, mode, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=900) for _ in procs], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = out
+    for d in out:
+        assert d["start_equal"], "start-up broadcast"
+        assert all(d["same"]), f"replicas diverged: {d['same']}"
+        assert d["grad_err"] <= 1e-6, f"exchanged gradient vs mean of local gradients: {d['grad_err']:.3e}"
+        assert all(e >= d["n_buckets"] - 1 for e in d["early"]), (d["early"], d["n_buckets"])
+    assert (a["grad_head"] == b["grad_head"]).all()
+
+
 def _two_rank_fullsize_worker(rank, world, port, mode, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -316,6 +349,7 @@ def _two_rank_fullsize_worker(rank, world, port, mode, q):
     gen = torch.Generator().manual_seed(4242 + 1000 * rank)
     batch = tuple(synth_records(gen, B, 800, 1333, K, DEV) for _ in range(4))
     early, tails, tail_mb = [], [], []
+    tr.reducer.diagnostics = True                    # (finish() measures tail_ms)
     for _ in range(3):
         tr.run_step(batch)
         early.append(tr.reducer.launched_in_backward)

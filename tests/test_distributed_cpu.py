@@ -108,7 +108,19 @@ def _worker_bucketed(rank, world, port, q, mode="all_reduce"):
         ((ref(x) - y) ** 2).mean().backward()
         want = allreduce_mean_(rflat.grad, world).clone()
         res.append((got.numpy(), want.numpy(), launched))
-    q.put((rank, res, list(red.buckets), red.bucket_of["unused"]))
+    # a second backward() without finish() / zero_grad() in between would write into buckets whose collectives are in
+    # flight -- the hook refuses (same on every rank, so nobody is left waiting); zero_grad() then drains and re-arms
+    flat.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()
+    try:
+        ((model(x) - y) ** 2).mean().backward()
+        refused = False
+    except RuntimeError as e:
+        refused = "after its collective was launched" in str(e)
+    flat.zero_grad()
+    ((model(x) - y) ** 2).mean().backward()
+    red.finish()
+    q.put((rank, res, list(red.buckets), red.bucket_of["unused"], refused))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -129,7 +141,8 @@ def test_bucketed_reducer_overlaps_and_matches_plain_allreduce(mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, res, buckets, unused_bucket in out:
+    for rank, res, buckets, unused_bucket, refused in out:
+        assert refused, "a second backward before finish() must be refused by the bucket hooks"
         assert len(buckets) >= 3 and buckets[0][1] == max(b[1] for b in buckets), "bucket 0 is the tail of the buffer"
         assert sorted(buckets)[0][0] == 0 and all(a[0] == b[1] for a, b in zip(buckets[:-1], buckets[1:])), "contiguous cover"
         for got, want, launched in res:

@@ -429,6 +429,23 @@ def test_segsort_lds_kernel(ops, sizes, topk):
     assert torch.equal(ops.segsort_desc(keys.to(DEV), offs.to(DEV), max_len=max(sizes), topk=topk)[1].cpu().long(), si), "repeatable"
 
 
+def test_segsort_host_lengths_guard(ops):
+    """a max_len / topk that does not describe the segments is a PtmiError BEFORE the launch when the caller hands over
+    its host-side segment lengths (all three product call sites do) -- not NaN keys that only a training-mode check would notice"""
+    from probabilisticteacher_amd._lib import PtmiError
+    sizes = [300, 17000, 5]
+    keys = torch.randn(sum(sizes), generator=g(9))
+    offs = torch.tensor([0] + list(np.cumsum(sizes)), dtype=torch.int32)
+    with pytest.raises(PtmiError, match="segment lengths"):
+        ops.segsort_desc(keys.to(DEV), offs.to(DEV), max_len=16384, lengths=sizes)            # longest segment > max_len
+    with pytest.raises(PtmiError, match="segment lengths"):
+        ops.segsort_desc(keys.to(DEV), offs.to(DEV), max_len=17000, lengths=[300, 17000])     # wrong segment count
+    sk, si = ops.segsort_desc(keys.to(DEV), offs.to(DEV), lengths=sizes)                       # max_len derived from the lengths
+    for a, b in zip(offs[:-1].tolist(), offs[1:].tolist()):
+        rk, ri = torch.sort(keys[a:b], descending=True, stable=True)
+        assert torch.equal(si.cpu().long()[a:b], ri) and torch.equal(sk.cpu()[a:b], rk)
+
+
 @pytest.mark.parametrize("counts,thr,max_keep", [([300, 0, 1, 65, 1000], 0.7, 2000), ([12000, 9000], 0.7, 2000),
                                                  ([5000], 0.5, 100)])
 def test_nms_bit_exact(ops, counts, thr, max_keep):

@@ -220,6 +220,48 @@ def test_p8_wgrad_full_size_layers(name, cin, cout, h, w):
     assert float((db.cpu() - br.grad).abs().max()) <= 1e-4 * sb, f"{name} db"
 
 
+def test_p8_wgrad_oversize_fallback_matches_native_kernel(monkeypatch):
+    """p8.wgrad's route for a P8 tensor beyond the kernel's 32-bit offsets (ptmi_p8_wgrad_fits = 0) -- the direct fp32
+    split-K kernel on widened operands, over GROUPS of images with accumulate = 1 -- forced on a small shape and compared with the
+    native bf16 kernel (same exact bf16 products, fp32 accumulation in another order: the fp32 bar) and with torch CPU."""
+    from probabilisticteacher_amd import _lib, ops, p8
+    n, cin, cout, h, w = 5, 32, 48, 21, 30
+    x = rb(torch.relu(torch.randn(n, cin, h, w, generator=g(61))))
+    gy = rb(torch.randn(n, cout, h, w, generator=g(62)))
+    wr = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    br = torch.zeros(cout, requires_grad=True)
+    F.conv2d(x, wr, br, padding=1).backward(gy)
+    xp, gp = p8.from_nchw(x.to(DEV)), p8.from_nchw(gy.to(DEV))
+    dw_native, db_native = p8.wgrad(xp, gp, n, cin, cout, h, w)
+    lib = _lib.load()
+
+    class NoFit:
+        def __getattr__(self, name):
+            return (lambda *a: 0) if name == "ptmi_p8_wgrad_fits" else getattr(lib, name)
+    monkeypatch.setattr(_lib, "load", lambda: NoFit())
+    monkeypatch.setattr(p8, "_WGRAD_FALLBACK_BYTES", 2 * 4 * max(cin, cout) * h * w)      # groups of 2 images: 2 + 2 + 1
+    ops.profile_start()
+    dw, db = p8.wgrad(xp, gp, n, cin, cout, h, w)
+    prof = ops.profile_stop()
+    assert list(prof) == ["conv3x3_wgrad"] and prof["conv3x3_wgrad"]["calls"] == 3, prof
+    s, sb = float(wr.grad.abs().max()), float(br.grad.abs().max())
+    for name, a, b, sc in (("dW vs native", dw, dw_native, s), ("db vs native", db, db_native, sb),
+                           ("dW vs torch", dw.cpu(), wr.grad, s), ("db vs torch", db.cpu(), br.grad, sb)):
+        err = float((a - b).abs().max())
+        assert err <= 1e-4 * sc + 1e-6, f"{name}: max abs err {err:.3e} vs scale {sc:.3e}"
+
+
+def test_p8_gemm_nt_rejects_operands_beyond_32_bit_offsets():
+    """ADVICE r5: p8.gemm_nt raises PtmiError (no silent wrap) when a packed operand exceeds the kernel's 4 GiB buffer range;
+    nothing is launched, so the operands can be tiny stand-ins"""
+    from probabilisticteacher_amd import _lib, p8
+    m, n, k = 90000, 1024, 25088                    # fc1 with 90 k ROIs: 4.5 GB packed
+    assert not _lib.load().ptmi_p8_gemm_nt_fits(m, n, k) and _lib.load().ptmi_p8_gemm_nt_fits(32000, n, k)
+    a = torch.zeros(8, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.PtmiError, match="32-bit buffer offsets"):
+        p8.gemm_nt(a, a, m, n, k)
+
+
 GEMM_SHAPES = [  # m (rows), n (outputs), k
     (300, 70, 200),            # one ragged tile, k not a multiple of 64 (zero-filled octets), no split
     (512, 256, 1024),          # exact tiles

@@ -249,6 +249,39 @@ def _routing_guard(ops, key, issued_flops):
     close(y, ref, 1e-4, 1e-4, "two-layer block")
 
 
+def test_routing_guard_wino4_wgrad_from_the_autograd_node():
+    """a map with chunk fill >= 0.9 (40 x 96: whole 4 x 16 chunks) sends the weight gradients of the autograd nodes to
+    conv3x3_wino4_wgrad -- including the 32-input-channel layer (cin 32 .. 63 with cout >= 64 ran the direct kernel before round 5) --
+    and the issued-FLOP model matches what the profile hooks record; values vs torch CPU at the 1e-4 bar."""
+    from probabilisticteacher_amd import ops
+    gen = g(22)
+    h, w = 40, 96
+    assert ops._wino4_wgrad_fill(h, w) >= ops._WINO4_WGRAD_MIN_FILL
+    assert ops._wgrad_kind(32, 64, h, w) == "wino4w" and ops._wgrad_kind(64, 128, h, w) == "wino4w"
+    assert ops._wgrad_kind(512, 512, 50, 83) == "wino", "round 5/6 routing of the 50 x 83 maps (fill 0.83)"
+    x = torch.randn(2, 32, h, w, generator=gen).to(DEV).requires_grad_()
+    w1 = (torch.randn(64, 32, 3, 3, generator=gen) * 0.07).to(DEV).requires_grad_()
+    b1 = (torch.randn(64, generator=gen) * 0.1).to(DEV).requires_grad_()
+    w2 = (torch.randn(128, 64, 3, 3, generator=gen) * 0.05).to(DEV).requires_grad_()
+    b2 = (torch.randn(128, generator=gen) * 0.1).to(DEV).requires_grad_()
+    gy = torch.randn(2, 128, h, w, generator=gen)
+    ops.profile_start()
+    y = ops.conv3x3(ops.conv3x3(x, w1, b1, True), w2, b2, True)
+    y.backward(gy.to(DEV))
+    prof = ops.profile_stop()
+    assert prof["conv3x3_wino4_wgrad"]["calls"] == 2 and "conv3x3_wino_wgrad" not in prof and "conv3x3_wgrad" not in prof, prof.keys()
+    assert prof["conv3x3_wino4_wgrad"]["issued"] == (ops.wino4_wgrad_issued_flops(2, 32, 64, h, w) +
+                                                     ops.wino4_wgrad_issued_flops(2, 64, 128, h, w))
+    xr, w1r, b1r, w2r, b2r = (t.detach().cpu().requires_grad_() for t in (x, w1, b1, w2, b2))
+    yr = F.relu(F.conv2d(F.relu(F.conv2d(xr, w1r, b1r, padding=1)), w2r, b2r, padding=1))
+    yr.backward(gy)
+    close(y, yr.detach(), 1e-4, 1e-4, "two-layer block")
+    for name, a, b in (("dW1", w1.grad, w1r.grad), ("db1", b1.grad, b1r.grad), ("dW2", w2.grad, w2r.grad), ("db2", b2.grad, b2r.grad)):
+        sc = float(b.abs().max())
+        err = float((a.cpu() - b).abs().max())
+        assert err <= 1e-4 * sc, f"{name}: max abs err {err:.3e} vs scale {sc:.3e}"
+
+
 def test_map_beyond_the_winograd_32bit_offsets_runs_the_direct_kernel():
     """ptmi_conv3x3_wino_fwd / _wgrad reject maps whose per-workgroup byte offsets exceed 32 bits (about 8 M pixels at
     64 channels); ops routes such a layer to the direct kernels instead of surfacing the exception (ptmi_conv3x3_wino_fwd_fits /
