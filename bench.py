@@ -191,6 +191,9 @@ def main():
                     help="N = 1 default run only: skip the two extra legs that the JSON line carries next to the fp32 headline -- "
                          "`amp` (the same workload with SOLVER.AMP.ENABLED, BASELINE configs[4]'s precision) and `student_only` "
                          "(BASELINE configs[1], batch 8)")
+    ap.add_argument("--tile-schedule", default=None, choices=["static", "dynamic"],
+                    help="tile schedule of the persistent F(4x4,3x3) kernel (default: PTrainer's choice -- static on one GPU, dynamic "
+                         "work queues when the gradient exchange is active; csrc/wino4.hip)")
     ap.add_argument("--batches", type=int, default=2,
                     help="distinct synthetic batches resident in HBM, rotated over the steps (the `sustained` leg uses 4)")
     ap.add_argument("--pmc-traffic", default="auto", choices=["auto", "off"],
@@ -225,6 +228,8 @@ def main():
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     torch.manual_seed(0)                                                # identical init on all ranks
     trainer = PTrainer(cfg, grad_reduce=args.grad_reduce)
+    if args.tile_schedule:
+        ops.set_tile_schedule(args.tile_schedule)
     gen = torch.Generator().manual_seed(1234 + rank * 1000)
     H, W = args.height, args.width
 
@@ -375,8 +380,9 @@ def main():
                 if with_roof:
                     rf = leg["roofline"]
                     c["frac"] = round(rf["frac"], 4)
+                    measured = str(rf.get("traffic_source", "")).startswith("measured in this run")   # (not the committed-profile fallback)
                     c["traffic_ratio"] = (round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3)
-                                          if rf.get("traffic") and rf.get("algorithmic_bytes_per_launch") else None)
+                                          if measured and rf.get("traffic") and rf.get("algorithmic_bytes_per_launch") else None)
                 return c
             # LAST key of the line, compact: what survives in a record that keeps only the tail of stdout
             legs = {"amp": compact(out["amp"]), "student_only": compact(out["student_only"]),

@@ -94,6 +94,18 @@ int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, c
                            float* y, int n, int cin, int cout, int h, int w, int epilogue,
                            ptmi_stream_t s);
 int ptmi_conv3x3_wino4_fwd_fits(int cin, int cout, int h, int w);
+/* ptmi_conv3x3_wino4_fwd with a DYNAMIC tile schedule (round 6).  The kernel runs one persistent workgroup per CU; with the
+ * static schedule of ptmi_conv3x3_wino4_fwd workgroup b walks tiles b, b + grid, ..., so a workgroup whose CU is held by another
+ * kernel when the launch starts (an RCCL collective overlapping backward: pt/engine/trainer.py:92-95,384 under DDP) still runs
+ * its whole share after everyone else has finished -- up to 2x on the launch.  Here the workgroups draw tile ids from eight
+ * queues (queue q = the ids = q mod 8 of the same enumeration: the XCD affinity of the static walk is kept; a workgroup starts
+ * on the queue of the XCD it runs on and moves on when that is exhausted).  sched: 16 int32 in device memory, ZERO before the
+ * first launch; the last workgroup of a launch zeroes it again, so one buffer serves every launch of ONE stream (launches that
+ * may overlap -- different streams -- need different buffers).  sched == NULL: the static schedule.  Results are bit-identical
+ * either way (a tile's arithmetic does not depend on who computes it). */
+int ptmi_conv3x3_wino4_fwd_sched(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                                 float* y, int n, int cin, int cout, int h, int w, int epilogue,
+                                 int32_t* sched, ptmi_stream_t s);
 /* Winograd-domain weight gradient (same contract as ptmi_conv3x3_wgrad; replaces cuDNN's Winograd-nonfused BWD_FILTER
  * for the trainable 3x3 layers with >= 64 input and output channels): dU_p[co][ci] = sum over tiles of (A dY A^T)_p V_p on v_mfma_f32_32x32x2_f32 (16 instead
  * of 36 multiplies per tile and channel pair), split over contiguous tile ranges whose partials (workspace
@@ -461,6 +473,13 @@ int ptmi_aug_hflip_batched(const int64_t* desc, int n, int64_t max_elems, ptmi_s
  *              p4 = output size along the pass, p5 = 0: (3,h,w) -> (3,h,p4), 1: (3,h,w) -> (3,p4,w).  A resize is the x pass
  *              followed by the y pass (a pass whose size does not change is skipped).  Down-scaling factors up to 15. */
 int ptmi_aug_resize_pass_batched(const int64_t* desc, int n, int64_t max_out_elems, ptmi_stream_t s);
+
+/* ------------------------------------------------------------------ diagnostics
+ * CU-contention probe (round 6; no counterpart in the reference): n_cus workgroups that each hold one CU (64 KB of LDS: no
+ * MFMA workgroup of this library fits beside one) for `microseconds` on stream s -- stands in for a collective's kernels
+ * (RCCL all-reduce overlapping backward under DDP, pt/engine/trainer.py:92-95,384) when only one GPU is at hand.
+ * tools/exp/contention.py, tests/test_wino4_gpu.py.  scratch: one int32 in device memory (never written). */
+int ptmi_hold_cus(int32_t* scratch, int n_cus, int microseconds, ptmi_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ptmi_conv3x3_wino4_packed_floats": (_i64, [_i, _i]),
     "ptmi_conv3x3_wino4_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wino4_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_wino4_fwd_sched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ptmi_conv3x3_wino4_fwd_fits": (_i, [_i, _i, _i, _i]),
     "ptmi_conv3x3_wino4_wgrad_fits": (_i, [_i, _i]),
     "ptmi_conv3x3_wino4_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "ptmi_rpn_soft_obj_loss": (_i, [_vp, _vp, _i64, _i, _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ptmi_kl_efl_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "ptmi_get_deltas_bwd_src": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp, _vp]),
+    "ptmi_hold_cus": (_i, [_vp, _i, _i, _vp]),
     "ptmi_ema_update": (_i, [_vp, _vp, _i64, _f, _f, _vp]),
     "ptmi_sumsq": (_i, [_vp, _i64, _vp, _vp, _vp]),
     "ptmi_clip_sgd_step": (_i, [_vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _i, _vp]),

@@ -262,9 +262,34 @@ inline unsigned grid_for(int64_t n, int per = 256, int cap = 8192)
     return (unsigned)b;
 }
 
+// hold_cus: `n` workgroups that each take 64 KB of (dynamic, so the optimiser cannot drop it) LDS and spin on the 100 MHz real-time
+// counter for `ticks` -- a stand-in for a co-running collective kernel: no >= 100-KB workgroup of this library (every MFMA kernel)
+// fits beside one, and the 512-register persistent convolution waves fit beside nothing at all
+__global__ __launch_bounds__(256) void hold_cus_kernel(int* __restrict__ out, unsigned long long ticks)
+{
+    extern __shared__ int hold_pad[];
+    hold_pad[threadIdx.x] = (int)threadIdx.x;
+    unsigned long long t0, t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+    do {
+        __builtin_amdgcn_s_sleep(32);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+    } while (t - t0 < ticks);
+    if (ticks == 0xFFFFFFFFFFFFFFFFull) out[0] = hold_pad[(threadIdx.x + 1) & 255];     // (never: keeps the LDS accesses alive)
+}
+
 }  // namespace
 
 extern "C" {
+
+int ptmi_hold_cus(int32_t* scratch, int n_cus, int microseconds, ptmi_stream_t s)
+{
+    PTMI_CHECK_ARG(scratch && n_cus > 0 && n_cus <= 4096 && microseconds > 0 && microseconds <= 10000000, "hold_cus: bad args");
+    hipLaunchKernelGGL(hold_cus_kernel, dim3((unsigned)n_cus), dim3(256), 65536, (hipStream_t)s, (int*)scratch,
+                       (unsigned long long)microseconds * 100ull);
+    PTMI_LAUNCH_CHECK("hold_cus");
+    return 0;
+}
 
 int ptmi_maxpool2x2_fwd(const float* x, float* y, int nc, int h, int w, ptmi_stream_t s)
 {

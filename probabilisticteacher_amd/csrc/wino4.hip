@@ -63,6 +63,7 @@ constexpr int XUI = XUS / 4 / XNT;      // 9 U DMA instructions per lane and chu
 constexpr int XPI = XPSP / 4 / XNT;     // 3 patch DMA instructions per lane and chunk
 constexpr int XDI = XUI + XPI;          // 12
 constexpr int XNU = 3, XNP = 4;         // stages
+constexpr int XRUN = 32;                // dynamic schedule: pixel tiles per channel-tile run of a queue (= the workgroups of one XCD)
 constexpr int XLDS = XNU * XUS + XNP * XPSP;   // 39936 floats = 159744 B
 
 // transform constants (a = 3/4, b = 3/2)
@@ -155,9 +156,14 @@ __host__ __device__ constexpr int x_valu_before(int s)
 __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi,
-    int coTiles, int bands, int period, int nPix, int colocate, int nTiles)
+    int coTiles, int bands, int period, int nPix, int colocate, int nTiles, int* __restrict__ sched)
 {
-    __shared__ __attribute__((aligned(16))) float lds[XLDS];
+    // ONE LDS object (a second __shared__ variable makes the LDS lowering attach alias scopes to every access, and the waitcnt pass
+    // then protects each window / A read against the LDS-DMA instructions with s_waitcnt vmcnt(0): measured as 40 extra waits per
+    // chunk pair in the ISA); the dynamic schedule's three words sit behind the stages
+    __shared__ __attribute__((aligned(16))) float lds[XLDS + 4];
+    typedef __attribute__((address_space(3))) int xlds_int_t;
+    volatile xlds_int_t* const sched_ids = (volatile xlds_int_t*)(lds + XLDS);   // [0], [1] the workgroup's first two tile ids, [2] the id after the next
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,6 +181,29 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     auto decode = [&](int vid, int& cot, int& pix) __attribute__((always_inline)) {
         cot = 0; pix = 0;
         if (vid >= nTiles) return false;
+        if (colocate && sched != nullptr) {
+            // dynamic schedule, <= 4 channel tiles: queue q = vid & 7 owns the pixel tiles = q mod 8 (Gq of them); its index k = vid >> 3
+            // walks them in RUNS of XRUN pixel tiles per channel tile -- the ~32 workgroups of an XCD then work on ONE weight slab
+            // at a time (0.6 - 2.4 MB: L2-resident) instead of all of them (the static walk keeps 4 slabs = up to 9.4 MB live per 4-MB
+            // L2).  The last, shorter cycle uses runs of the remaining length, so the valid indices of a queue are a PREFIX of it
+            const int q = vid & 7, k = vid >> 3;
+            const int Gq = (nPix - q + 7) >> 3;                      // pixel tiles of this queue
+            if (k >= Gq * coTiles) return false;
+            const int full = Gq / XRUN;                              // whole cycles of XRUN pixel tiles x coTiles
+            const int c = k / (XRUN * coTiles);
+            int g;
+            if (c < full) {
+                const int rem = k - c * (XRUN * coTiles);
+                cot = rem / XRUN;
+                g = c * XRUN + (rem - cot * XRUN);
+            } else {
+                const int rt = Gq - full * XRUN, kk = k - full * (XRUN * coTiles);
+                cot = kk / rt;
+                g = full * XRUN + (kk - cot * rt);
+            }
+            pix = g * 8 + q;
+            return true;
+        }
         if (colocate) {
             const int slot = vid >> 3;
             cot = slot % coTiles;
@@ -185,6 +214,39 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         pix = vid / coTiles;
         return true;
     };
+
+    // ---- tile schedule.  sched == nullptr: STATIC -- workgroup b walks b, b + grid, ... (a workgroup that starts late -- its CU
+    // was held by another kernel, e.g. a collective's -- still runs its whole share after the others have finished: up to 2x on the
+    // launch).  sched != nullptr: DYNAMIC -- eight queues over the SAME enumeration (queue q = the ids = q mod 8, so a queue keeps
+    // the XCD affinity of the static walk: one weight slab per XCD with 8 channel tiles, the channel tiles of a pixel tile back to
+    // back with <= 4); a workgroup draws from the queue of the XCD it runs on (HW_REG_XCC_ID) and, once that is exhausted, from the
+    // following ones.  sched[q] = next index of queue q, sched[8] = workgroups finished; the last one out zeroes all nine, so the
+    // buffer is zero again when the launch ends (one buffer per stream: launches on one stream do not overlap).
+    // Only wave 0 draws (lane 0 issues the atomic); ids reach the other waves through sched_ids[] behind a barrier.  ids are
+    // drawn one tile ahead of make_next(), i.e. two tiles ahead of the MFMAs: no wave ever waits for an atomic in the steady state.
+    const bool dyn = sched != nullptr;
+    int sq = 0, sleft = 8;                                   // (wave 0) queue drawn from / queues not yet seen exhausted
+    bool want_draw = false, have_pend = false;               // (wave 0) slot consumed: draw at this chunk's hand-over / drawn, unresolved
+    int pend_k = 0;                                          // (wave 0, lane 0) the unresolved draw's queue index
+    auto id_ok = [&](int v) __attribute__((always_inline)) { int c_, p_; return decode(v, c_, p_); };
+    auto draw_add = [&](int cnt) __attribute__((always_inline)) {          // -> the queue's index before the add (wave-uniform)
+        int k = 0;
+        if (lane == 0) k = __hip_atomic_fetch_add(sched + sq, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_amdgcn_readfirstlane(k);
+    };
+    // a valid id for index k of queue sq -- or, the queue being exhausted there, the first valid id of the following queues;
+    // nTiles = everything has been handed out (a queue's valid ids are a prefix of it: once exhausted, always exhausted)
+    auto resolve = [&](int k) __attribute__((always_inline)) {
+        for (;;) {
+            if (sleft == 0) return nTiles;
+            const long long v = 8ll * k + sq;
+            if (v < nTiles && id_ok((int)v)) return (int)v;
+            sq = (sq + 1) & 7;
+            --sleft;
+            if (sleft) k = draw_add(1);
+        }
+    };
+    int c_vid = 0;                                           // id of the tile the slab cursor is in (= the next tile at a tile's end)
 
     // ---- DMA-side state of a tile: the lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first
     // plane of the tile's first image; periods are multiples of 4, so a piece lies in ONE strip
@@ -256,7 +318,13 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         if (ucur == nChunks) {
             slab = n_slab; urange = n_urange; wv = (unsigned)tid * 16u;
             ucur = 0;
-            make_next(n_vid + grid);
+            c_vid = n_vid;
+            int nid = n_vid + grid;
+            if (dyn) {                                       // (written by wave 0 at least one barrier ago)
+                nid = __builtin_amdgcn_readfirstlane(sched_ids[2]);
+                want_draw = true;
+            }
+            make_next(nid);
         }
     };
 
@@ -312,9 +380,39 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     const int b_off = kq * XPL + (wn * 4) * XPP + 4 * ttx + 3;                             // + row * 72 + {0, 1 (b128), 5}
 
     int vid = blockIdx.x;
+    int vid1 = vid + grid;                                   // the workgroup's second tile
+    // the last workgroup out re-arms the schedule for the next launch on this stream
+    auto sched_exit = [&]() __attribute__((always_inline)) {
+        if (dyn && tid == 0) {
+            const int done = __hip_atomic_fetch_add(sched + 8, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == grid - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    if (dyn) {
+        if (wave == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            sq = (int)(xcc & 7u);
+            const int k = draw_add(3);                       // three ids in one round trip: this tile, the next, the one after
+            // (sleft == 8 <=> still on the own queue, whose indices k .. k + 2 this workgroup owns; a later queue: a fresh draw each)
+            const int a = resolve(k);
+            const int b = resolve(sleft == 8 ? k + 1 : (sleft ? draw_add(1) : 0));
+            const int c = resolve(sleft == 8 ? k + 2 : (sleft ? draw_add(1) : 0));
+            if (lane == 0) { sched_ids[0] = a; sched_ids[1] = b; sched_ids[2] = c; }
+        }
+        __syncthreads();
+        vid = __builtin_amdgcn_readfirstlane(sched_ids[0]);
+        vid1 = __builtin_amdgcn_readfirstlane(sched_ids[1]);
+    }
     {
         int c0, p0;
-        if (!decode(vid, c0, p0)) return;                    // (workgroup-uniform)
+        if (!decode(vid, c0, p0)) {                          // (workgroup-uniform)
+            sched_exit();
+            return;
+        }
     }
     // the lane's 8 biases of a tile (channels co_w + 16 ct + 4 kq + r), fetched at the head of the tile
     f32x4 bv[2];
@@ -335,7 +433,12 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     make_next(vid);
     pcur = ucur = nChunks;                                   // "wrapped": the first issue of either kind switches to the state just made
     patch_wrap();
-    slab_wrap();                                             // (also makes the state of tile vid + grid)
+    {                                                        // slab_wrap() by hand: the second tile's id is vid1, the slot stays untouched
+        slab = n_slab; urange = n_urange; wv = (unsigned)tid * 16u;
+        ucur = 0;
+        c_vid = n_vid;
+        make_next(vid1);
+    }
     auto issue_patch = [&](int stage) __attribute__((always_inline)) {
         patch_wrap();
 #pragma unroll
@@ -439,6 +542,14 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
                 skipwait = false;
                 fixup(pf, fix_ho, edge_ho);   // [x4:ho]
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // [x4:ho]
+                // dynamic schedule (wave 0): slab_wrap consumed the slot at this chunk's head -- draw the next id now, straight after
+                // the counted wait (vector-memory results return in order: the next hand-over's count then covers the atomic, and
+                // nothing waits for it before that).  It is resolved and published at the tile's end, behind the vmcnt(0) there
+                if (dyn && wave == 0 && want_draw) {
+                    want_draw = false;
+                    have_pend = true;
+                    if (sleft && lane == 0) pend_k = __hip_atomic_fetch_add(sched + sq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             constexpr int wr = x_wread_at(S);
             if constexpr (wr >= 0) wread(std::integral_constant<int, (wr >= 0 ? wr : 0)>{}, pb);   // [x4:wr]
@@ -648,10 +759,15 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         // the last chunk's own DMA instructions (the next tile's chunk 1 slab / chunk 2 patch): with them done, nothing the next
         // tile's counted waits rely on is older than the epilogue's stores
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (dyn && wave == 0 && have_pend) {                 // the id drawn two chunks ago: valid, or the next queue's, or "none left"
+            have_pend = false;
+            const int v = resolve(__builtin_amdgcn_readfirstlane(pend_k));
+            if (lane == 0) sched_ids[2] = v;
+        }
         // [x4@t3]
         epilogue(vid);
         // [x4@t4]
-        vid += grid;
+        vid = c_vid;                                         // (static schedule: vid + grid)
         {
             int c0, p0;
             if (!decode(vid, c0, p0)) break;
@@ -659,6 +775,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         load_bias(vid);
         skipwait = true;
     }
+    sched_exit();
 }
 
 // U = G g G^T (6x6 per filter) laid out as the kernel's LDS image: [channel tile (64)][chunk (4 ci)][ci][position group 9][co 64]
@@ -741,8 +858,22 @@ int ptmi_conv3x3_wino4_fwd_fits(int cin, int cout, int h, int w)
     return (img_span * cin + XKC) * h * w * 4 < (1ll << 32) && (img_span * cout + XBM) * h * w * 4 < (1ll << 32);
 }
 
-int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
-                           int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
+// CUs of the current device: a hardware constant, looked up once per device id (35 launches per step); a benign race at worst
+// writes the same value twice
+static int wino4_device_cus()
+{
+    static int cus_by_dev[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64 && cus_by_dev[dev] > 0) return cus_by_dev[dev];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    if (dev >= 0 && dev < 64) cus_by_dev[dev] = cus;
+    return cus;
+}
+
+int ptmi_conv3x3_wino4_fwd_sched(const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
+                                 int cin, int cout, int h, int w, int epilogue, int32_t* sched, ptmi_stream_t s)
 {
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino4_fwd: bad args");
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "conv3x3_wino4_fwd: bad epilogue %d", epilogue);
@@ -761,19 +892,18 @@ int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, c
     const int64_t nWg = colocate ? cdiv64(nPix, 8) * 8 * coTiles : nPix * coTiles;      // tile ids (colocate: some beyond nPix -- the end)
     PTMI_CHECK_ARG(nWg < (1ll << 31) - 4096, "conv3x3_wino4_fwd: too many tiles");
     // persistent workgroups: one per CU (a multiple of 8: a tile stays on the XCD of its id mod 8)
-    static int cus_cached = 0;                               // (one query per process: 35 launches per step)
-    int cus = cus_cached;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
-            cus = 256;
-        cus_cached = cus;
-    }
+    const int cus = wino4_device_cus();
     const int64_t grid = nWg < (cus / 8) * 8 ? nWg : (cus / 8) * 8;
     hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)grid), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
-                       cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate, (int)nWg);
+                       cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate, (int)nWg, (int*)sched);
     PTMI_LAUNCH_CHECK("conv3x3_wino4_fwd");
     return 0;
+}
+
+int ptmi_conv3x3_wino4_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref, float* y, int n,
+                           int cin, int cout, int h, int w, int epilogue, ptmi_stream_t s)
+{
+    return ptmi_conv3x3_wino4_fwd_sched(x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue, nullptr, s);
 }
 
 }  // extern "C"

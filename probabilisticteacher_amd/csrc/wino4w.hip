@@ -480,12 +480,18 @@ __global__ void wino4_wgrad_reduce_kernel(const float* __restrict__ partial, con
     }
 }
 
-// splits per (co tile, ci tile): fill the chip's 256 one-workgroup-per-CU slots
+// splits per (co tile, ci tile): W4W_WAVES_OF_WORKGROUPS x the chip's 256 one-workgroup-per-CU slots.  1 = one long workgroup per
+// CU (round 5); more = the hardware dispatcher hands the later workgroups to whichever CU frees up first -- the non-persistent
+// form of work stealing: CUs held by another kernel when the launch starts (a collective overlapping backward) then cost their
+// share instead of a second pass (tools/exp/contention.py), for one more prologue / partial-sum store per extra workgroup
+#ifndef W4W_WAVES_OF_WORKGROUPS
+#define W4W_WAVES_OF_WORKGROUPS 1
+#endif
 static int wino4_wgrad_splits(int n, int cin, int cout, int h, int w)
 {
     const int pairs = cdiv(cout, ZC) * cdiv(cin, ZI);
     const int64_t chunks = (int64_t)n * cdiv(h, 4) * cdiv(w, 16);
-    int S = cdiv(256, pairs);
+    int S = cdiv(256 * W4W_WAVES_OF_WORKGROUPS, pairs);
     if (S > chunks) S = (int)chunks;
     return S < 1 ? 1 : S;
 }

@@ -342,6 +342,41 @@ def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int, hw: Optional[Tuple[i
     return wp
 
 
+_TILE_SCHEDULE = "dynamic"      # persistent F(4x4,3x3) kernel: "dynamic" (work queues, csrc/wino4.hip) | "static" (b, b + grid, ...)
+_SCHED_BUFS: dict = {}
+
+
+def set_tile_schedule(mode: str) -> None:
+    """Tile schedule of the persistent forward / dgrad kernel: "dynamic" (default: workgroups draw tiles from eight XCD queues,
+    so CUs held by another kernel -- an RCCL collective overlapping backward -- cost their share, not a second pass) or "static"
+    (the round-5 walk b, b + grid, ...; comparison runs and tools/exp/contention.py)."""
+    global _TILE_SCHEDULE
+    if mode not in ("dynamic", "static"):
+        raise ValueError(f"unknown tile schedule {mode!r}")
+    _TILE_SCHEDULE = mode
+
+
+def _sched_buf(device):
+    """the 16-int32 schedule words of ptmi_conv3x3_wino4_fwd_sched for the CURRENT stream of `device` (zero at creation; the
+    kernel leaves them zero) -- one buffer per (device, stream): launches that may overlap must not share one"""
+    if _TILE_SCHEDULE != "dynamic":
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    b = _SCHED_BUFS.get(key)
+    if b is None:
+        b = _SCHED_BUFS[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return b
+
+
+def _conv_fwd_call(kind: str, x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue):
+    if kind == "wino4":
+        _lib.call("ptmi_conv3x3_wino4_fwd_sched", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
+                  epilogue, _ptr(_sched_buf(x.device)), _stream())
+    else:
+        _lib.call(_CONV_ABI[kind] + "_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w, epilogue,
+                  _stream())
+
+
 def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor:
     """wp = conv3x3_pack(w, mode, epilogue) with the SAME epilogue."""
     _no_native_bf16("ops.conv3x3_raw")
@@ -356,7 +391,7 @@ def conv3x3_raw(x, wp, bias, mask_ref, cout: int, epilogue: int) -> torch.Tensor
         raise _lib.PtmiError(f"conv3x3_raw: packed weights have {wp.numel()} floats, the {kind} kernel this {h}x{w} map is "
                              f"routed to takes {want} (pass hw=(H, W) to conv3x3_pack)")
     with _prof("conv3x3_" + kind, 2.0 * 9 * cin * cout * h * w * n, nbytes, _conv_issued(kind, n, cin, cout, h, w)):
-        _lib.call(abi + "_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w, epilogue, _stream())
+        _conv_fwd_call(kind, x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue)
     return y
 
 
@@ -373,8 +408,7 @@ def conv3x3_relu_pool_nograd(x, weight, bias) -> torch.Tensor:
     kind = _conv_kind(cin, cout, (h, w))
     with _prof("conv3x3_" + kind, 2.0 * 9 * cin * cout * h * w * n, 4.0 * (n * h * w * (cin + cout / 4.0) + 9 * cin * cout),
                _conv_issued(kind, n, cin, cout, h, w)):
-        _lib.call(_CONV_ABI[kind] + "_fwd", _ptr(x), _ptr(wp), _ptr(_chk(bias.contiguous())), None,
-                  _ptr(y), n, cin, cout, h, w, 4, _stream())
+        _conv_fwd_call(kind, x, wp, _chk(bias.contiguous()), None, y, n, cin, cout, h, w, 4)
     return _rnd_stored(y)
 
 

@@ -4,6 +4,8 @@
 Tolerances: losses rtol 1e-4 (BASELINE.json north_star: "loss parity vs CPU reference to 1e-4"); gradients
 rtol 2e-3 of the tensor norm (fp32 MFMA k-ordered accumulation vs oneDNN blocking); box coordinates 2e-3 px;
 class indices, sampler draw sizes (== label counts) exact."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -189,6 +191,87 @@ def test_run_step_matches_reference_golden():
                 close(tsd[k].flatten()[:16].cpu(), z[f"it{it}_t_head_{k}"], 1e-4, 1e-6, f"teacher head {k}")
     finally:
         sampling.set_key_source(None)
+
+
+def test_run_step_long_reference_golden_replayed_on_hip(capsys):
+    """Round 6: the FOURTEEN real reference iterations of tests/golden/run_step_long.npz (3 burn-in,
+    the keep_rate = 0 copy, 10 EMA-0.9996 mutual-learning steps, the reference's LR warm-up; tools/gen_golden.py::
+    gen_run_step_long) replayed on the HIP trainer from the same start, the student consuming the REFERENCE's pseudo labels:
+    per iteration every metric and 7 parameter probes of student and teacher -- momentum, weight decay, EMA and the schedule over a
+    horizon where they matter.  Tolerances: iteration 0 runs on identical weights (1e-4); afterwards the fp32 summation-order
+    differences of MFMA vs oneDNN compound through the optimiser (1e-3 for the metrics, as in the 3-iteration test)."""
+    from probabilisticteacher_amd.engine import PTrainer
+    from probabilisticteacher_amd.modeling import sampling
+    from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    z = load("run_step_long")
+    K, tau, B, burn, iters = int(z["K"]), tuple(float(v) for v in z["tau"]), int(z["B"]), int(z["burn"]), int(z["iters"])
+    cfg = _cfg(K, "DifferentiableAnchorGenerator", tau, burn=burn)
+    assert cfg.SOLVER.BASE_LR == float(z["base_lr"]) and cfg.SOLVER.WARMUP_ITERS == int(z["warmup_iters"])
+    assert cfg.UNSUPNET.EMA_KEEP_RATE == float(z["ema_keep_rate"])
+    ocfg = opt.Cfg(num_classes=K, anchor_generator="DifferentiableAnchorGenerator", tau=tau, burn_up_step=burn)
+    ratios = []
+
+    class ReplayTrainer(PTrainer):
+        override = None
+        mine = None
+
+        def process_pseudo_label(self, proposals, proposal_type, psedo_label_method=""):
+            out, n = super().process_pseudo_label(proposals, proposal_type, psedo_label_method)
+            self.mine = out
+            return (self.override, n) if self.override is not None else (out, n)
+
+    tr = ReplayTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
+    _load_params(tr.model, opt.golden_params(ocfg, int(z["seed"])))
+    _load_params(tr.model_teacher, opt.golden_params(ocfg, int(z["teacher_seed"])))
+    probes = sorted({k.split("_s_sum_")[1] for k in z.files if "_s_sum_" in k})
+    report = []
+    try:
+        for it in range(iters):
+            data = tuple(_gpu_records(z, f"it{it}_{nm}", B) for nm in ("lq", "lk", "uq", "uk"))
+            ratios[:] = [float(v) for v in z[f"it{it}_ratios"]]
+            tr.override = None
+            if f"it{it}_pseudo0_pseudo_boxes" in z.files:
+                ov = []
+                for i in range(B):
+                    h, w = data[3][i]["image"].shape[-2:]
+                    inst = FreeInstances((h, w))
+                    inst.pseudo_boxes = Boxes(torch.from_numpy(z[f"it{it}_pseudo{i}_pseudo_boxes"]).to(DEV))
+                    inst.scores_logists = torch.from_numpy(z[f"it{it}_pseudo{i}_scores_logists"]).to(DEV)
+                    inst.boxes_sigma = torch.from_numpy(z[f"it{it}_pseudo{i}_boxes_sigma"]).to(DEV)
+                    ov.append(inst)
+                tr.override = ov
+            sampling.set_key_source(perm_key_source(opt.SeededPerm(700 + it)))
+            from probabilisticteacher_amd.solver import lr_at
+            assert abs(lr_at(cfg, it) - float(z[f"it{it}_lr"])) <= 1e-12
+            m = tr.run_step(data)
+            frac = None
+            if tr.override is not None:
+                for mine, ref in zip(tr.mine, tr.override):
+                    ca = np.zeros(len(mine), np.int64)
+                    cb = np.zeros(len(ref), np.int64)
+                    frac, _ = match_detections(mine.pseudo_boxes.tensor.cpu(), ca, ref.pseudo_boxes.tensor.cpu(), cb, box_tol=5e-2)
+                    assert frac >= 0.90, f"iteration {it}: the HIP teacher's pseudo boxes matched {frac:.3f} of the reference teacher's"
+            worst = 0.0
+            for k in z.files:
+                if k.startswith(f"it{it}_m_"):
+                    name = k[len(f"it{it}_m_"):]
+                    if np.isnan(z[k]):
+                        assert math.isnan(m[name]), f"{k}: reference NaN (empty mean), HIP {m[name]}"
+                        continue
+                    worst = max(worst, abs(m[name] - float(z[k])) / (abs(float(z[k])) + 1e-6))
+                    close(torch.tensor(m[name]), z[k], 1e-4 if it == 0 else 1e-3, 1e-6, k)
+            ssd, tsd = tr.model.state_dict(), tr.model_teacher.state_dict()
+            sum_atol = 2e-4 if it == 0 else 1e-3
+            for k in probes:
+                close(ssd[k].double().sum().cpu(), z[f"it{it}_s_sum_{k}"], 1e-5, sum_atol, f"it {it} student sum {k}")
+                close(ssd[k].flatten()[:16].cpu(), z[f"it{it}_s_head_{k}"], 1e-4, 1e-6, f"it {it} student head {k}")
+                close(tsd[k].double().sum().cpu(), z[f"it{it}_t_sum_{k}"], 1e-5, sum_atol, f"it {it} teacher sum {k}")
+                close(tsd[k].flatten()[:16].cpu(), z[f"it{it}_t_head_{k}"], 1e-4, 1e-6, f"it {it} teacher head {k}")
+            report.append(f"it {it}: worst metric deviation {worst:.2e}" + (f", pseudo boxes matched {frac:.3f}" if frac is not None else ""))
+    finally:
+        sampling.set_key_source(None)
+        with capsys.disabled():
+            print("\n[run_step_long on HIP] " + "; ".join(report))
 
 
 def test_full_size_1333x800_backbone_and_rpn_vs_oracle():

@@ -184,6 +184,69 @@ def test_run_step_matches_reference():
             close(state["teacher"][k].flatten()[:16], z[f"it{it}_t_head_{k}"], 1e-5, 1e-7, f"teacher head {k}")
 
 
+def test_run_step_long_matches_reference_over_14_iterations():
+    """Round 6 (VERDICT r5 next-round item 2b): FOURTEEN real PTrainer.run_step iterations of the reference (tools/gen_golden.py::
+    gen_run_step_long: 3 burn-in, the keep_rate = 0 copy step, 10 EMA-0.9996 mutual-learning steps, the reference's LR warm-up
+    active) replayed by the oracle from the same start: the reference's MULTI-STEP dynamics -- momentum accumulating over 14 steps,
+    weight decay, the teacher drifting away from the student by EMA, pseudo labels of a changing teacher, the warm-up schedule --
+    pin the oracle's, per iteration: every metric, 7 parameter probes of student and teacher, the teacher's pseudo labels."""
+    z = load("run_step_long")
+    burn, iters = int(z["burn"]), int(z["iters"])
+    assert iters >= 12 and iters - burn - 1 >= 8
+    cfg = _ocfg(z, "DifferentiableAnchorGenerator", burn=burn)
+    cfg.tau = tuple(float(v) for v in z["tau"])
+    assert cfg.base_lr == float(z["base_lr"]) and cfg.warmup_iters == int(z["warmup_iters"]) and cfg.ema_keep_rate == float(z["ema_keep_rate"])
+    state = {"student": opt.golden_params(cfg, int(z["seed"])), "teacher": opt.golden_params(cfg, int(z["teacher_seed"])),
+             "bufs": {}, "iter": 0}
+    B = int(z["B"])
+    probes = sorted({k.split("_s_sum_")[1] for k in z.files if "_s_sum_" in k})
+    live = 0
+    for it in range(iters):
+        assert abs(opt.lr_at(cfg, it) - float(z[f"it{it}_lr"])) <= 1e-12, "LR schedule"
+        data = tuple(records(z, f"it{it}_{nm}", B) for nm in ("lq", "lk", "uq", "uk"))
+        rr = [float(v) for v in z[f"it{it}_ratios"]]
+        ratios = {"label": rr, "unlabel": []} if it < burn else {"unlabel": rr[:B], "label": rr[B:2 * B]}
+        override = None
+        if f"it{it}_pseudo0_pseudo_boxes" in z.files:
+            override = []
+            for i in range(B):
+                h, w = data[3][i]["image"].shape[-2:]
+                inst = opt.FreeInstances((h, w))
+                inst.pseudo_boxes = d2.Boxes(torch.from_numpy(z[f"it{it}_pseudo{i}_pseudo_boxes"]))
+                inst.scores_logists = torch.from_numpy(z[f"it{it}_pseudo{i}_scores_logists"])
+                inst.boxes_sigma = torch.from_numpy(z[f"it{it}_pseudo{i}_boxes_sigma"])
+                override.append(inst)
+        assert (override is not None) == (it >= burn)
+        m = opt.run_step(cfg, state, data, ratios, perm_fn=opt.SeededPerm(700 + it), pseudo_override=override)
+        if override is not None:
+            for mine, ref in zip(state["last_pseudo"], override):
+                assert len(ref) > 0
+                close(mine.pseudo_boxes.tensor, ref.pseudo_boxes.tensor, 1e-4, 5e-3, f"it {it} pseudo boxes")
+                close(mine.scores_logists, ref.scores_logists, 1e-4, 1e-3, f"it {it} pseudo logits")
+                close(mine.boxes_sigma, ref.boxes_sigma, 1e-4, 1e-3, f"it {it} pseudo sigma")
+        for k in z.files:
+            if k.startswith(f"it{it}_m_"):
+                name = k[len(f"it{it}_m_"):]
+                if np.isnan(z[k]):           # the reference's own empty-mean terms (the copy step's ROI terms): NaN on both sides
+                    assert np.isnan(m[name]), f"{k}: reference NaN, oracle {m[name]}"
+                    continue
+                close(m[name], z[k], 2e-4, 1e-6, k)
+                live += name.endswith("_unsup") and abs(float(z[k])) > 1e-6
+        for k in probes:
+            # sums of up to 25.7 M weights that cancel to ~0.4 (fc1): the per-weight fp32 differences of two summation orders add up
+            # like a random walk -- 1e-4 absolute over the first iterations (as the 3-iteration test), 5e-4 once 14 optimiser steps
+            # have compounded them (measured 1.7e-4 at iteration 7); the 16-value heads below are the sharp check
+            sum_atol = 1e-4 if it < 3 else 5e-4
+            close(state["student"][k].double().sum(), z[f"it{it}_s_sum_{k}"], 1e-5, sum_atol, f"it {it} student sum {k}")
+            close(state["student"][k].flatten()[:16], z[f"it{it}_s_head_{k}"], 1e-5, 1e-7, f"it {it} student head {k}")
+            close(state["teacher"][k].double().sum(), z[f"it{it}_t_sum_{k}"], 1e-5, sum_atol, f"it {it} teacher sum {k}")
+            close(state["teacher"][k].flatten()[:16], z[f"it{it}_t_head_{k}"], 1e-5, 1e-7, f"it {it} teacher head {k}")
+    assert live >= 4 * (iters - burn - 1), f"only {live} live unsupervised loss values in the fixture"
+    # the EMA teacher really moved away from the student (else the last ten steps would pin nothing the copy step does not)
+    k = "roi_heads.box_predictor.cls_score.bias"
+    assert float((state["student"][k] - state["teacher"][k]).abs().max()) > 1e-4
+
+
 def test_rpn_loss_weight_is_applied_twice_to_supervised_losses_only():
     """MODEL.RPN.LOSS_WEIGHT = 2, BBOX_REG_LOSS_WEIGHT = 0.5 on the REAL reference model (tests/golden/rpn_loss_weight.npz):
     the supervised RPN losses carry the weight dict squared (rpn.py:254 and rpn.py:141), the unsupervised ones no weight

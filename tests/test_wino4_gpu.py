@@ -193,3 +193,76 @@ def test_wino4_wgrad_layer_shape_vs_direct_kernel():
     scale = float(dw_d.abs().max())
     close(dw, dw_d, 1e-4, 1e-4 * scale, "dW wino4 vs direct")
     close(db, db_d, 1e-4, 1e-4 * float(db_d.abs().max()), "db")
+
+
+# ---- round 6: the dynamic tile schedule (ptmi_conv3x3_wino4_fwd_sched) ------------------------------------------------------
+def _wino4_sched(x, wp, bias, mask, epilogue, conv_cout, sched):
+    from probabilisticteacher_amd import _lib, ops
+    n, cin, h, w = x.shape
+    y = torch.full((n, conv_cout, h // 2, w // 2) if epilogue == 4 else (n, conv_cout, h, w), float("nan"), device=DEV)
+    _lib.call("ptmi_conv3x3_wino4_fwd_sched", ops._ptr(x), ops._ptr(wp), ops._ptr(bias), ops._ptr(mask), ops._ptr(y), n, cin,
+              conv_cout, h, w, epilogue, ops._ptr(sched), ops._stream())
+    return y
+
+
+SCHED_SHAPES = SHAPES + [
+    (6, 64, 64, 100, 166),     # one channel tile, 1014 pixel tiles: ~4 tiles per workgroup, nPix % 8 != 0 (colocate tail ids invalid)
+    (4, 64, 256, 50, 83),      # four channel tiles (colocated on one queue each), 155 pixel tiles
+    (3, 128, 512, 50, 83),     # eight channel tiles: queue q = channel tile q
+    (1, 64, 192, 8, 64),       # fewer tiles (3) than queues
+    (2, 64, 640, 30, 70),      # ten channel tiles
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", SCHED_SHAPES)
+def test_wino4_dynamic_schedule_is_bit_identical_to_static_and_rearms(n, cin, cout, h, w):
+    """The work-queue schedule hands every tile to exactly one workgroup: the output equals the static walk's BIT FOR BIT (a tile's
+    arithmetic does not depend on who computes it; a tile drawn twice would also pass, a tile never drawn leaves the NaN fill), for
+    every epilogue, and the 16 schedule words are zero again after each launch -- the same buffer serves the next launch."""
+    from probabilisticteacher_amd import _lib, ops
+    gen = g(n * 977 + cin + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=gen).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))).to(DEV)
+    b = (torch.randn(cout, generator=gen) * 0.1).to(DEV)
+    wp = torch.empty(_lib.load().ptmi_conv3x3_wino4_packed_floats(cin, cout), device=DEV)
+    _lib.call("ptmi_conv3x3_wino4_pack_weights", ops._ptr(wt), ops._ptr(wp), cout, cin, 0, ops._stream())
+    mask = torch.randn(n, cout, h, w, generator=gen).to(DEV)
+    sched = torch.zeros(16, dtype=torch.int32, device=DEV)
+    for epi, bias, m in ((1, b, None), (2, None, None), (3, None, mask), (4, b, None)):
+        if epi == 4 and (h < 2 or w < 2):
+            continue
+        ref = _wino4_sched(x, wp, bias, m, epi, cout, None)                 # static
+        assert bool(torch.isfinite(ref).all())
+        for rep in range(3):                                                # the buffer re-arms itself
+            got = _wino4_sched(x, wp, bias, m, epi, cout, sched)
+            assert torch.equal(got, ref), f"epilogue {epi} launch {rep}: dynamic schedule differs from the static walk"
+            assert not bool(sched.any()), f"epilogue {epi} launch {rep}: schedule words not zero after the launch: {sched.tolist()}"
+
+
+def test_wino4_dynamic_schedule_under_cu_contention():
+    """A side stream holds 64 CUs' worth of LDS while the convolution launches (what an RCCL kernel overlapping backward does):
+    the output stays bit-identical and the schedule words re-arm.  (Timing under contention: tools/exp/contention.py.)"""
+    from probabilisticteacher_amd import _lib, ops
+    gen = g(77)
+    n, cin, cout, h, w = 8, 64, 128, 100, 166
+    x = torch.randn(n, cin, h, w, generator=gen).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.04).to(DEV)
+    b = (torch.randn(cout, generator=gen) * 0.1).to(DEV)
+    wp = torch.empty(_lib.load().ptmi_conv3x3_wino4_packed_floats(cin, cout), device=DEV)
+    _lib.call("ptmi_conv3x3_wino4_pack_weights", ops._ptr(wt), ops._ptr(wp), cout, cin, 0, ops._stream())
+    sched = torch.zeros(16, dtype=torch.int32, device=DEV)
+    ref = _wino4_sched(x, wp, b, None, 1, cout, None)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            _lib.call("ptmi_hold_cus", ops._ptr(flag), 64, 20000, ctypes_stream(side))
+        got = _wino4_sched(x, wp, b, None, 1, cout, sched)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref) and not bool(sched.any())
+
+
+def ctypes_stream(s):
+    import ctypes
+    return ctypes.c_void_p(s.cuda_stream)

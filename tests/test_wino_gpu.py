@@ -266,14 +266,18 @@ def test_routing_guard_wino4_wgrad_from_the_autograd_node():
     b2 = (torch.randn(128, generator=gen) * 0.1).to(DEV).requires_grad_()
     gy = torch.randn(2, 128, h, w, generator=gen)
     ops.profile_start()
-    y = ops.conv3x3(ops.conv3x3(x, w1, b1, True), w2, b2, True)
+    a1 = ops.conv3x3(x, w1, b1, True)
+    y = ops.conv3x3(a1, w2, b2, True)
     y.backward(gy.to(DEV))
     prof = ops.profile_stop()
     assert prof["conv3x3_wino4_wgrad"]["calls"] == 2 and "conv3x3_wino_wgrad" not in prof and "conv3x3_wgrad" not in prof, prof.keys()
     assert prof["conv3x3_wino4_wgrad"]["issued"] == (ops.wino4_wgrad_issued_flops(2, 32, 64, h, w) +
                                                      ops.wino4_wgrad_issued_flops(2, 64, 128, h, w))
     xr, w1r, b1r, w2r, b2r = (t.detach().cpu().requires_grad_() for t in (x, w1, b1, w2, b2))
-    yr = F.relu(F.conv2d(F.relu(F.conv2d(xr, w1r, b1r, padding=1)), w2r, b2r, padding=1))
+    # the reference backward uses the HIP side's ReLU decisions (a pre-activation within rounding of 0 flips its mask bit between any
+    # two fp32 implementations, and ONE flipped pixel moves a 7 680-pixel weight-gradient sum by ~1e-3 of its scale: first run of this test)
+    m1, m2 = (a1.detach().cpu() > 0).float(), (y.detach().cpu() > 0).float()
+    yr = F.conv2d(F.conv2d(xr, w1r, b1r, padding=1) * m1, w2r, b2r, padding=1) * m2
     yr.backward(gy)
     close(y, yr.detach(), 1e-4, 1e-4, "two-layer block")
     for name, a, b in (("dW1", w1.grad, w1r.grad), ("db1", b1.grad, b1r.grad), ("dW2", w2.grad, w2r.grad), ("db2", b2.grad, b2r.grad)):

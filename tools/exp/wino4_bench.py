@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--only4", action="store_true")
     ap.add_argument("--custom", action="append", default=[], help="name=cin,cout,h,w (repeatable)")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions; the minimum is reported")
+    ap.add_argument("--sched", action="store_true", help="wino4: ALSO time ptmi_conv3x3_wino4_fwd_sched (the dynamic tile schedule of round 6)")
     ap.add_argument("--stamps", action="store_true", help="--lib built with the `stamp` part: per-tile phase stamps of wave 0 of workgroup 0")
     a = ap.parse_args()
     from probabilisticteacher_amd import _lib
@@ -69,6 +70,26 @@ def main():
                 torch.cuda.synchronize()
                 ms = min(ms, e0.elapsed_time(e1) / a.iters)
             outs[kind] = (y, ms)
+            if a.sched and kind == "wino4":
+                sched = torch.zeros(16, dtype=torch.int32, device="cuda:0")
+                y_static = y.clone()
+
+                def fd():
+                    rc = lib.ptmi_conv3x3_wino4_fwd_sched(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()), vp(x.data_ptr()), vp(y.data_ptr()),
+                                                          a.n, cin, cout, h, w, a.epi, vp(sched.data_ptr()), st)
+                    assert rc == 0, _lib.load().ptmi_last_error()
+                fd()
+                torch.cuda.synchronize()
+                msd = 1e9
+                for _ in range(a.reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(a.iters):
+                        fd()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    msd = min(msd, e0.elapsed_time(e1) / a.iters)
+                line += f"  wino4 dynamic: {msd:7.3f} ms (x{msd / ms:.3f} of static; equal {bool(torch.equal(y, y_static))})"
             if a.stamps and kind == "wino4":
                 t = tr.cpu().view(64, 8).tolist()
                 last = max(k for k in range(64) if t[k][0])
