@@ -125,6 +125,22 @@ int ptmi_conv3x3_wino4_wgrad_fits(int h, int w);
 int64_t ptmi_conv3x3_wino4_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wino4_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n,
                              int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
+/* The two Winograd-domain weight-gradient kernels with `waves` fills of the chip's one-workgroup-per-CU slots instead of one
+ * (round 6): their workgroups each own a contiguous share of the (image, tile) list, so with one fill a workgroup whose CU is held by
+ * another kernel when the launch starts -- an RCCL collective overlapping backward, pt/engine/trainer.py:92-95,384 under DDP --
+ * runs its whole share after everyone else has finished: 2x on the launch (tools/exp/contention.py: 33 -> 65 ms per 8 + 8 step
+ * with 8 of 256 CUs held).  With `waves` > 1 (clamped to 16) the later workgroups go to whichever CU frees up first: 45 ms at
+ * waves = 4, for 8 % more time when nothing else runs (one more prologue and partial-sum store per workgroup).  Same contract and
+ * the same bit-exact repeatability as the one-wave entry points (= waves 1); the workspace grows with the split count
+ * (ptmi_conv3x3_wino*_wgrad_ws_floats_waves with the same `waves`). */
+int64_t ptmi_conv3x3_wino_wgrad_ws_floats_waves(int n, int cin, int cout, int h, int w, int waves);
+int ptmi_conv3x3_wino_wgrad_waves(const float* x, const float* dy, float* dw, float* db, float* ws,
+                                  int n, int cin, int cout, int h, int w, int accumulate, int waves,
+                                  ptmi_stream_t s);
+int64_t ptmi_conv3x3_wino4_wgrad_ws_floats_waves(int n, int cin, int cout, int h, int w, int waves);
+int ptmi_conv3x3_wino4_wgrad_waves(const float* x, const float* dy, float* dw, float* db, float* ws,
+                                   int n, int cin, int cout, int h, int w, int accumulate, int waves,
+                                   ptmi_stream_t s);
 /* ------------------------------------------------------------------ bf16 STORAGE path of the conv stack ("P8", round 4)
  * SOLVER.AMP.ENABLED (reference pt/engine/trainer.py:98; BASELINE configs[4]): under autocast the reference's cuDNN convolutions
  * (pt/modeling/backbone/vgg.py:45-53,66-69, pt/modeling/proposal_generator/rpn.py:96) read and write bf16 activations.  The

@@ -39,6 +39,10 @@ SIGNATURES = {
     "ptmi_conv3x3_wino4_wgrad_fits": (_i, [_i, _i]),
     "ptmi_conv3x3_wino4_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_conv3x3_wino4_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_wino4_wgrad_ws_floats_waves": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "ptmi_conv3x3_wino4_wgrad_waves": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_wino_wgrad_ws_floats_waves": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "ptmi_conv3x3_wino_wgrad_waves": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wino_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_conv3x3_wino_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_p8_plane_pixels": (_i64, [_i, _i, _i]),

@@ -974,11 +974,12 @@ static int wino_wgrad_ksn(int w)
 }
 
 // splits per (co tile, ci tile): fill the chip's 256 one-workgroup-per-CU slots a whole number of times
-static int wino_wgrad_splits(int n, int cin, int cout, int h, int w)
+// (waves: how many such fills -- see ptmi_conv3x3_wino_wgrad_waves)
+static int wino_wgrad_splits(int n, int cin, int cout, int h, int w, int waves)
 {
     const int pairs = cdiv(cout, GWC) * cdiv(cin, GWC);
     const int64_t chunks = (int64_t)n * cdiv(h, 2) * cdiv(w, 4 * wino_wgrad_ksn(w));
-    int S = cdiv(256, pairs);
+    int S = cdiv(256 * (waves < 1 ? 1 : waves > 16 ? 16 : waves), pairs);
     if (S > chunks) S = (int)chunks;
     return S < 1 ? 1 : S;
 }
@@ -1047,17 +1048,28 @@ int ptmi_conv3x3_wino_fwd(const float* x, const float* wp, const float* bias, co
 }
 
 
+int64_t ptmi_conv3x3_wino_wgrad_ws_floats_waves(int n, int cin, int cout, int h, int w, int waves)
+{
+    return (int64_t)wino_wgrad_splits(n, cin, cout, h, w, waves) * (16 * (int64_t)cout * cin + cout);
+}
+
 int64_t ptmi_conv3x3_wino_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 {
-    return (int64_t)wino_wgrad_splits(n, cin, cout, h, w) * (16 * (int64_t)cout * cin + cout);
+    return ptmi_conv3x3_wino_wgrad_ws_floats_waves(n, cin, cout, h, w, 1);
 }
 
 int ptmi_conv3x3_wino_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h,
                             int w, int accumulate, ptmi_stream_t s)
 {
+    return ptmi_conv3x3_wino_wgrad_waves(x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, 1, s);
+}
+
+int ptmi_conv3x3_wino_wgrad_waves(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h,
+                                  int w, int accumulate, int waves, ptmi_stream_t s)
+{
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino_wgrad: bad args");
     PTMI_CHECK_ARG(ptmi_conv3x3_wino_wgrad_fits(h, w), "conv3x3_wino_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
-    const int S = wino_wgrad_splits(n, cin, cout, h, w);
+    const int S = wino_wgrad_splits(n, cin, cout, h, w, waves);
     const int coTiles = cdiv(cout, GWC), ciTiles = cdiv(cin, GWC);
     hipStream_t st = (hipStream_t)s;
     float* bws = ws + (size_t)S * 16 * cout * cin;

@@ -153,6 +153,10 @@ __host__ __device__ constexpr int x_valu_before(int s)
     return n > 144 ? 144 : n;
 }
 
+// DYN: the dynamic tile schedule (sched != nullptr).  Two instantiations: the schedule's scalar state (queue, pending draw, ids)
+// costs the chunk loop 2.6 % through SGPR pressure (48 more scalar instructions per chunk pair between the MFMAs: measured on the
+// same box against the round-5 kernel, profiles/r06_wino4_static_vs_dynamic.txt), which a single-GPU run need not pay
+template <bool DYN>
 __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     const float* __restrict__ x, const float* __restrict__ wp, const float* __restrict__ bias,
     const float* __restrict__ mref, float* __restrict__ y, int N, int Cin, int Cout, int H, int W, int nChunks, int epi,
@@ -161,9 +165,10 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     // ONE LDS object (a second __shared__ variable makes the LDS lowering attach alias scopes to every access, and the waitcnt pass
     // then protects each window / A read against the LDS-DMA instructions with s_waitcnt vmcnt(0): measured as 40 extra waits per
     // chunk pair in the ISA); the dynamic schedule's three words sit behind the stages
-    __shared__ __attribute__((aligned(16))) float lds[XLDS + 4];
+    __shared__ __attribute__((aligned(16))) float lds[XLDS + 8];
     typedef __attribute__((address_space(3))) int xlds_int_t;
-    volatile xlds_int_t* const sched_ids = (volatile xlds_int_t*)(lds + XLDS);   // [0], [1] the workgroup's first two tile ids, [2] the id after the next
+    volatile xlds_int_t* const sched_ids = (volatile xlds_int_t*)(lds + XLDS);   // [0], [1] the workgroup's first two tile ids, [2] the id after the next,
+                                                             // [3] the id of the tile the slab cursor is in, [4] / [5] wave 0's queue state
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     auto decode = [&](int vid, int& cot, int& pix) __attribute__((always_inline)) {
         cot = 0; pix = 0;
         if (vid >= nTiles) return false;
-        if (colocate && sched != nullptr) {
+        if (DYN && colocate) {
             // dynamic schedule, <= 4 channel tiles: queue q = vid & 7 owns the pixel tiles = q mod 8 (Gq of them); its index k = vid >> 3
             // walks them in RUNS of XRUN pixel tiles per channel tile -- the ~32 workgroups of an XCD then work on ONE weight slab
             // at a time (0.6 - 2.4 MB: L2-resident) instead of all of them (the static walk keeps 4 slabs = up to 9.4 MB live per 4-MB
@@ -224,29 +229,30 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     // buffer is zero again when the launch ends (one buffer per stream: launches on one stream do not overlap).
     // Only wave 0 draws (lane 0 issues the atomic); ids reach the other waves through sched_ids[] behind a barrier.  ids are
     // drawn one tile ahead of make_next(), i.e. two tiles ahead of the MFMAs: no wave ever waits for an atomic in the steady state.
-    const bool dyn = sched != nullptr;
-    int sq = 0, sleft = 8;                                   // (wave 0) queue drawn from / queues not yet seen exhausted
-    bool want_draw = false, have_pend = false;               // (wave 0) slot consumed: draw at this chunk's hand-over / drawn, unresolved
+    constexpr bool dyn = DYN;
+    // The schedule's state lives in LDS, not in SGPRs (a first version kept queue, flags and ids in scalar registers: 48 more scalar
+    // instructions per chunk pair between the MFMAs -- spill reloads -- and a 4 % slower chunk loop): sched_ids[4] = the queue
+    // wave 0 draws from, [5] = queues not yet seen exhausted; every tile draws exactly once (where its slab cursor wraps) and resolves
+    // the draw at its end, so no flags are needed
     int pend_k = 0;                                          // (wave 0, lane 0) the unresolved draw's queue index
     auto id_ok = [&](int v) __attribute__((always_inline)) { int c_, p_; return decode(v, c_, p_); };
-    auto draw_add = [&](int cnt) __attribute__((always_inline)) {          // -> the queue's index before the add (wave-uniform)
+    auto draw_add = [&](int q, int cnt) __attribute__((always_inline)) {   // -> queue q's index before the add (wave-uniform)
         int k = 0;
-        if (lane == 0) k = __hip_atomic_fetch_add(sched + sq, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) k = __hip_atomic_fetch_add(sched + q, cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return __builtin_amdgcn_readfirstlane(k);
     };
     // a valid id for index k of queue sq -- or, the queue being exhausted there, the first valid id of the following queues;
     // nTiles = everything has been handed out (a queue's valid ids are a prefix of it: once exhausted, always exhausted)
-    auto resolve = [&](int k) __attribute__((always_inline)) {
+    auto resolve = [&](int k, int& sq, int& sleft) __attribute__((always_inline)) {
         for (;;) {
             if (sleft == 0) return nTiles;
             const long long v = 8ll * k + sq;
             if (v < nTiles && id_ok((int)v)) return (int)v;
             sq = (sq + 1) & 7;
             --sleft;
-            if (sleft) k = draw_add(1);
+            if (sleft) k = draw_add(sq, 1);
         }
     };
-    int c_vid = 0;                                           // id of the tile the slab cursor is in (= the next tile at a tile's end)
 
     // ---- DMA-side state of a tile: the lane's patch pieces (channel, patch row, 16-B piece) -> byte offset from the chunk's first
     // plane of the tile's first image; periods are multiples of 4, so a piece lies in ONE strip
@@ -318,11 +324,20 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         if (ucur == nChunks) {
             slab = n_slab; urange = n_urange; wv = (unsigned)tid * 16u;
             ucur = 0;
-            c_vid = n_vid;
             int nid = n_vid + grid;
-            if (dyn) {                                       // (written by wave 0 at least one barrier ago)
+            if constexpr (DYN) {                             // (the slot: written by wave 0 at least one barrier ago)
                 nid = __builtin_amdgcn_readfirstlane(sched_ids[2]);
-                want_draw = true;
+                if (wave == 0) {
+                    // the tile the cursor enters (= the next tile when this one ends), and the draw for the tile after `nid`: resolved
+                    // and published at this tile's end.  The atomic is older than this chunk's DMA instructions, so the counted
+                    // wait of this chunk's hand-over covers it (vector-memory results return in order) -- a chunk later
+                    const int q = __builtin_amdgcn_readfirstlane(sched_ids[4]);
+                    const int left = __builtin_amdgcn_readfirstlane(sched_ids[5]);
+                    if (lane == 0) {
+                        sched_ids[3] = n_vid;
+                        if (left) pend_k = __hip_atomic_fetch_add(sched + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
             make_next(nid);
         }
@@ -395,12 +410,13 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         if (wave == 0) {
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            sq = (int)(xcc & 7u);
-            const int k = draw_add(3);                       // three ids in one round trip: this tile, the next, the one after
+            int sq = (int)(xcc & 7u), sleft = 8;
+            const int k = draw_add(sq, 3);                   // three ids in one round trip: this tile, the next, the one after
             // (sleft == 8 <=> still on the own queue, whose indices k .. k + 2 this workgroup owns; a later queue: a fresh draw each)
-            const int a = resolve(k);
-            const int b = resolve(sleft == 8 ? k + 1 : (sleft ? draw_add(1) : 0));
-            const int c = resolve(sleft == 8 ? k + 2 : (sleft ? draw_add(1) : 0));
+            const int a = resolve(k, sq, sleft);
+            const int b = resolve(sleft == 8 ? k + 1 : (sleft ? draw_add(sq, 1) : 0), sq, sleft);
+            const int c = resolve(sleft == 8 ? k + 2 : (sleft ? draw_add(sq, 1) : 0), sq, sleft);
+            if (lane == 0) { sched_ids[4] = sq; sched_ids[5] = sleft; }
             if (lane == 0) { sched_ids[0] = a; sched_ids[1] = b; sched_ids[2] = c; }
         }
         __syncthreads();
@@ -436,7 +452,6 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
     {                                                        // slab_wrap() by hand: the second tile's id is vid1, the slot stays untouched
         slab = n_slab; urange = n_urange; wv = (unsigned)tid * 16u;
         ucur = 0;
-        c_vid = n_vid;
         make_next(vid1);
     }
     auto issue_patch = [&](int stage) __attribute__((always_inline)) {
@@ -542,14 +557,6 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
                 skipwait = false;
                 fixup(pf, fix_ho, edge_ho);   // [x4:ho]
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // [x4:ho]
-                // dynamic schedule (wave 0): slab_wrap consumed the slot at this chunk's head -- draw the next id now, straight after
-                // the counted wait (vector-memory results return in order: the next hand-over's count then covers the atomic, and
-                // nothing waits for it before that).  It is resolved and published at the tile's end, behind the vmcnt(0) there
-                if (dyn && wave == 0 && want_draw) {
-                    want_draw = false;
-                    have_pend = true;
-                    if (sleft && lane == 0) pend_k = __hip_atomic_fetch_add(sched + sq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
             }
             constexpr int wr = x_wread_at(S);
             if constexpr (wr >= 0) wread(std::integral_constant<int, (wr >= 0 ? wr : 0)>{}, pb);   // [x4:wr]
@@ -759,15 +766,18 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4_kernel(
         // the last chunk's own DMA instructions (the next tile's chunk 1 slab / chunk 2 patch): with them done, nothing the next
         // tile's counted waits rely on is older than the epilogue's stores
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (dyn && wave == 0 && have_pend) {                 // the id drawn two chunks ago: valid, or the next queue's, or "none left"
-            have_pend = false;
-            const int v = resolve(__builtin_amdgcn_readfirstlane(pend_k));
-            if (lane == 0) sched_ids[2] = v;
+        if constexpr (DYN) {
+            if (wave == 0) {                                 // this tile's draw: valid, or the next queue's, or "none left"
+                int sq = __builtin_amdgcn_readfirstlane(sched_ids[4]), sleft = __builtin_amdgcn_readfirstlane(sched_ids[5]);
+                const int v = resolve(__builtin_amdgcn_readfirstlane(pend_k), sq, sleft);
+                if (lane == 0) { sched_ids[2] = v; sched_ids[4] = sq; sched_ids[5] = sleft; }
+            }
         }
         // [x4@t3]
         epilogue(vid);
         // [x4@t4]
-        vid = c_vid;                                         // (static schedule: vid + grid)
+        if constexpr (DYN) vid = __builtin_amdgcn_readfirstlane(sched_ids[3]);   // (written where this tile's slab cursor wrapped: barriers ago)
+        else vid += grid;
         {
             int c0, p0;
             if (!decode(vid, c0, p0)) break;
@@ -894,8 +904,12 @@ int ptmi_conv3x3_wino4_fwd_sched(const float* x, const float* wp, const float* b
     // persistent workgroups: one per CU (a multiple of 8: a tile stays on the XCD of its id mod 8)
     const int cus = wino4_device_cus();
     const int64_t grid = nWg < (cus / 8) * 8 ? nWg : (cus / 8) * 8;
-    hipLaunchKernelGGL(conv3x3_wino4_kernel, dim3((unsigned)grid), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
-                       cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate, (int)nWg, (int*)sched);
+    if (sched && nChunks >= 4)       // (fewer chunks per tile than the schedule's LDS hand-offs assume: the static walk)
+        hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3((unsigned)grid), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
+                           cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate, (int)nWg, (int*)sched);
+    else
+        hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)grid), dim3(XNT), 0, (hipStream_t)s, x, wp, bias, mask_ref, y, n,
+                           cin, cout, h, w, nChunks, epilogue, coTiles, bands, period, (int)nPix, colocate, (int)nWg, (int*)nullptr);
     PTMI_LAUNCH_CHECK("conv3x3_wino4_fwd");
     return 0;
 }

@@ -487,11 +487,11 @@ __global__ void wino4_wgrad_reduce_kernel(const float* __restrict__ partial, con
 #ifndef W4W_WAVES_OF_WORKGROUPS
 #define W4W_WAVES_OF_WORKGROUPS 1
 #endif
-static int wino4_wgrad_splits(int n, int cin, int cout, int h, int w)
+static int wino4_wgrad_splits(int n, int cin, int cout, int h, int w, int waves)
 {
     const int pairs = cdiv(cout, ZC) * cdiv(cin, ZI);
     const int64_t chunks = (int64_t)n * cdiv(h, 4) * cdiv(w, 16);
-    int S = cdiv(256 * W4W_WAVES_OF_WORKGROUPS, pairs);
+    int S = cdiv(256 * W4W_WAVES_OF_WORKGROUPS * (waves < 1 ? 1 : waves > 16 ? 16 : waves), pairs);
     if (S > chunks) S = (int)chunks;
     return S < 1 ? 1 : S;
 }
@@ -505,17 +505,28 @@ int ptmi_conv3x3_wino4_wgrad_fits(int h, int w)
     return h > 0 && w > 0 && (int64_t)(ZC + 1) * h * w * 4 < (1ll << 31);
 }
 
+int64_t ptmi_conv3x3_wino4_wgrad_ws_floats_waves(int n, int cin, int cout, int h, int w, int waves)
+{
+    return (int64_t)wino4_wgrad_splits(n, cin, cout, h, w, waves) * (36 * (int64_t)cout * cin + (int64_t)cdiv(cin, ZI) * cout);
+}
+
 int64_t ptmi_conv3x3_wino4_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 {
-    return (int64_t)wino4_wgrad_splits(n, cin, cout, h, w) * (36 * (int64_t)cout * cin + (int64_t)cdiv(cin, ZI) * cout);
+    return ptmi_conv3x3_wino4_wgrad_ws_floats_waves(n, cin, cout, h, w, 1);
 }
 
 int ptmi_conv3x3_wino4_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h,
                              int w, int accumulate, ptmi_stream_t s)
 {
+    return ptmi_conv3x3_wino4_wgrad_waves(x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, 1, s);
+}
+
+int ptmi_conv3x3_wino4_wgrad_waves(const float* x, const float* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h,
+                                   int w, int accumulate, int waves, ptmi_stream_t s)
+{
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "conv3x3_wino4_wgrad: bad args");
     PTMI_CHECK_ARG(ptmi_conv3x3_wino4_wgrad_fits(h, w), "conv3x3_wino4_wgrad: map %dx%d too large for 32-bit buffer offsets", h, w);
-    const int S = wino4_wgrad_splits(n, cin, cout, h, w);
+    const int S = wino4_wgrad_splits(n, cin, cout, h, w, waves);
     const int coTiles = cdiv(cout, ZC), ciTiles = cdiv(cin, ZI);
     hipStream_t st = (hipStream_t)s;
     float* bws = ws + (size_t)S * 36 * cout * cin;

@@ -182,15 +182,15 @@ def conv3x3_wgrad(x: torch.Tensor, dz: torch.Tensor, cout: int):
     kind = _wgrad_kind(cin, cout, h, w)
     if kind == "wino4w":
         # round 5: the F(4x4,3x3)-domain kernel (csrc/wino4w.hip; workgroup = 64 co x 32 ci)
-        ws = _ws("wgrad", lib.ptmi_conv3x3_wino4_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+        ws = _ws("wgrad", lib.ptmi_conv3x3_wino4_wgrad_ws_floats_waves(n, cin, cout, h, w, _WGRAD_WAVES) * 4, x.device)
         with _prof("conv3x3_wino4_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino4_wgrad_issued_flops(n, cin, cout, h, w)):
-            _lib.call("ptmi_conv3x3_wino4_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
-                      _stream())
+            _lib.call("ptmi_conv3x3_wino4_wgrad_waves", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
+                      _WGRAD_WAVES, _stream())
     elif kind == "wino":
-        ws = _ws("wgrad", lib.ptmi_conv3x3_wino_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+        ws = _ws("wgrad", lib.ptmi_conv3x3_wino_wgrad_ws_floats_waves(n, cin, cout, h, w, _WGRAD_WAVES) * 4, x.device)
         with _prof("conv3x3_wino_wgrad", 2.0 * 9 * cin * cout * h * w * n, issued=wino_wgrad_issued_flops(n, cin, cout, h, w)):
-            _lib.call("ptmi_conv3x3_wino_wgrad", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
-                      _stream())
+            _lib.call("ptmi_conv3x3_wino_wgrad_waves", _ptr(x), _ptr(dz), _ptr(dw), _ptr(db), _ptr(ws), n, cin, cout, h, w, 0,
+                      _WGRAD_WAVES, _stream())
     else:
         ws = _ws("wgrad", lib.ptmi_conv3x3_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
         with _prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * n):
@@ -342,18 +342,32 @@ def conv3x3_pack(w: torch.Tensor, mode: int, epilogue: int, hw: Optional[Tuple[i
     return wp
 
 
-_TILE_SCHEDULE = "dynamic"      # persistent F(4x4,3x3) kernel: "dynamic" (work queues, csrc/wino4.hip) | "static" (b, b + grid, ...)
+_TILE_SCHEDULE = "static"       # persistent F(4x4,3x3) kernel: "dynamic" (work queues, csrc/wino4.hip) | "static" (b, b + grid, ...);
+                                # PTrainer selects "dynamic" when the gradient exchange is active
 _SCHED_BUFS: dict = {}
 
 
 def set_tile_schedule(mode: str) -> None:
-    """Tile schedule of the persistent forward / dgrad kernel: "dynamic" (default: workgroups draw tiles from eight XCD queues,
-    so CUs held by another kernel -- an RCCL collective overlapping backward -- cost their share, not a second pass) or "static"
-    (the round-5 walk b, b + grid, ...; comparison runs and tools/exp/contention.py)."""
+    """Tile schedule of the persistent forward / dgrad kernel: "static" (the walk b, b + grid, ...: fastest when nothing else runs
+    on the GPU) or "dynamic" (workgroups draw tiles from eight XCD queues, so CUs held by another kernel -- an RCCL collective
+    overlapping backward -- cost their share, not a second pass: tools/exp/contention.py; +0.5 % without contention, and the
+    dynamic instantiation's chunk loop is 2.6 % slower).  PTrainer selects "dynamic" whenever its gradient exchange is active."""
     global _TILE_SCHEDULE
     if mode not in ("dynamic", "static"):
         raise ValueError(f"unknown tile schedule {mode!r}")
     _TILE_SCHEDULE = mode
+
+
+_WGRAD_WAVES = 1                # fills of the one-workgroup-per-CU slots by the Winograd-domain weight-gradient kernels
+
+
+def set_wgrad_waves(waves: int) -> None:
+    """1 (default): one long workgroup per CU; > 1: that many waves of shorter workgroups (ptmi_conv3x3_wino*_wgrad_waves) -- what
+    PTrainer selects when its gradient exchange is active, so that CUs held by the collectives cost their share."""
+    global _WGRAD_WAVES
+    if not 1 <= int(waves) <= 16:
+        raise ValueError(f"wgrad waves {waves!r} outside 1 .. 16")
+    _WGRAD_WAVES = int(waves)
 
 
 def _sched_buf(device):

@@ -196,13 +196,19 @@ def test_run_step_matches_reference_golden():
 def test_run_step_long_reference_golden_replayed_on_hip(capsys):
     """Round 6: the FOURTEEN real reference iterations of tests/golden/run_step_long.npz (3 burn-in,
     the keep_rate = 0 copy, 10 EMA-0.9996 mutual-learning steps, the reference's LR warm-up; tools/gen_golden.py::
-    gen_run_step_long) replayed on the HIP trainer from the same start, the student consuming the REFERENCE's pseudo labels:
-    per iteration every metric and 7 parameter probes of student and teacher -- momentum, weight decay, EMA and the schedule over a
-    horizon where they matter.  Tolerances: iteration 0 runs on identical weights (1e-4); afterwards the fp32 summation-order
-    differences of MFMA vs oneDNN compound through the optimiser (1e-3 for the metrics, as in the 3-iteration test)."""
+    gen_run_step_long) on the HIP trainer, EVERY iteration against the reference's own numbers.
+    Two fp32 implementations that start from identical weights drift apart exponentially under SGD (measured here: worst metric
+    deviation 1e-7, 9e-6, 8e-5, 4e-4, 1e-3 over iterations 0 .. 4 -- each side samples its own proposals), so a free-running
+    14-step replay cannot be held to a tolerance.  Instead the ORACLE runs alongside (tests/test_oracle_golden.py holds it to the
+    reference at 2e-4 / 1e-5 over all 14 iterations) and carries the state: before iteration `it` the HIP trainer is given the
+    oracle's student, teacher, momentum buffers and iteration counter, takes the step -- EMA update, teacher pass, pseudo labels
+    (the student consumes the REFERENCE's, from the fixture), both student branches, backward, clip + SGD under the warm-up LR --
+    and its metrics and 7 + 7 parameter probes are compared with the REFERENCE's at the single-step bar: metrics 1e-3 (each
+    side's own proposal sample from weights that agree to ~1e-6; iteration 0, bit-identical weights: 1e-4), probe heads 1e-4."""
     from probabilisticteacher_amd.engine import PTrainer
     from probabilisticteacher_amd.modeling import sampling
     from probabilisticteacher_amd.structures import Boxes, FreeInstances
+    from probabilisticteacher_amd.solver import lr_at
     z = load("run_step_long")
     K, tau, B, burn, iters = int(z["K"]), tuple(float(v) for v in z["tau"]), int(z["B"]), int(z["burn"]), int(z["iters"])
     cfg = _cfg(K, "DifferentiableAnchorGenerator", tau, burn=burn)
@@ -221,57 +227,77 @@ def test_run_step_long_reference_golden_replayed_on_hip(capsys):
             return (self.override, n) if self.override is not None else (out, n)
 
     tr = ReplayTrainer(cfg, ratio_fn=lambda: ratios.pop(0))
-    _load_params(tr.model, opt.golden_params(ocfg, int(z["seed"])))
-    _load_params(tr.model_teacher, opt.golden_params(ocfg, int(z["teacher_seed"])))
+    state = {"student": opt.golden_params(ocfg, int(z["seed"])), "teacher": opt.golden_params(ocfg, int(z["teacher_seed"])),
+             "bufs": {}, "iter": 0}
     probes = sorted({k.split("_s_sum_")[1] for k in z.files if "_s_sum_" in k})
+    trainable = [n for n, p in tr.student.params.items() if p.requires_grad]
+
+    def inject(st):
+        """the oracle's state -> the HIP trainer (parameters through the state dicts, momentum into the flat buffer)"""
+        _load_params(tr.model, st["student"])
+        _load_params(tr.model_teacher, st["teacher"])
+        tr.iter = st["iter"]
+        tr._first_step = not st["bufs"]
+        if st["bufs"]:
+            assert set(st["bufs"]) == set(trainable), set(st["bufs"]) ^ set(trainable)
+            with torch.no_grad():
+                for n in trainable:
+                    off, k = tr.student.index[n]
+                    tr.momentum_buf[off:off + k].copy_(st["bufs"][n].reshape(-1))
+
     report = []
     try:
         for it in range(iters):
+            inject(state)
             data = tuple(_gpu_records(z, f"it{it}_{nm}", B) for nm in ("lq", "lk", "uq", "uk"))
-            ratios[:] = [float(v) for v in z[f"it{it}_ratios"]]
-            tr.override = None
+            odata = tuple(records(z, f"it{it}_{nm}", B) for nm in ("lq", "lk", "uq", "uk"))
+            rr = [float(v) for v in z[f"it{it}_ratios"]]
+            ratios[:] = rr
+            tr.override, o_override = None, None
             if f"it{it}_pseudo0_pseudo_boxes" in z.files:
-                ov = []
+                ov, oov = [], []
                 for i in range(B):
                     h, w = data[3][i]["image"].shape[-2:]
-                    inst = FreeInstances((h, w))
-                    inst.pseudo_boxes = Boxes(torch.from_numpy(z[f"it{it}_pseudo{i}_pseudo_boxes"]).to(DEV))
-                    inst.scores_logists = torch.from_numpy(z[f"it{it}_pseudo{i}_scores_logists"]).to(DEV)
-                    inst.boxes_sigma = torch.from_numpy(z[f"it{it}_pseudo{i}_boxes_sigma"]).to(DEV)
+                    inst, oinst = FreeInstances((h, w)), opt.FreeInstances((h, w))
+                    pb, sl, bs = (torch.from_numpy(z[f"it{it}_pseudo{i}_{f}"]) for f in ("pseudo_boxes", "scores_logists", "boxes_sigma"))
+                    inst.pseudo_boxes, inst.scores_logists, inst.boxes_sigma = Boxes(pb.to(DEV)), sl.to(DEV), bs.to(DEV)
+                    oinst.pseudo_boxes, oinst.scores_logists, oinst.boxes_sigma = d2.Boxes(pb.clone()), sl.clone(), bs.clone()
                     ov.append(inst)
-                tr.override = ov
+                    oov.append(oinst)
+                tr.override, o_override = ov, oov
             sampling.set_key_source(perm_key_source(opt.SeededPerm(700 + it)))
-            from probabilisticteacher_amd.solver import lr_at
             assert abs(lr_at(cfg, it) - float(z[f"it{it}_lr"])) <= 1e-12
             m = tr.run_step(data)
+            # the oracle takes the same step from the same state: the state carrier of the next iteration
+            om = opt.run_step(ocfg, state, odata, {"label": rr, "unlabel": []} if it < burn else {"unlabel": rr[:B], "label": rr[B:2 * B]},
+                              perm_fn=opt.SeededPerm(700 + it), pseudo_override=o_override)
             frac = None
             if tr.override is not None:
                 for mine, ref in zip(tr.mine, tr.override):
-                    ca = np.zeros(len(mine), np.int64)
-                    cb = np.zeros(len(ref), np.int64)
-                    frac, _ = match_detections(mine.pseudo_boxes.tensor.cpu(), ca, ref.pseudo_boxes.tensor.cpu(), cb, box_tol=5e-2)
-                    assert frac >= 0.90, f"iteration {it}: the HIP teacher's pseudo boxes matched {frac:.3f} of the reference teacher's"
+                    frac, _ = match_detections(mine.pseudo_boxes.tensor.cpu(), np.zeros(len(mine), np.int64),
+                                               ref.pseudo_boxes.tensor.cpu(), np.zeros(len(ref), np.int64), box_tol=5e-2)
+                    assert frac >= 0.95, f"iteration {it}: the HIP teacher's pseudo boxes matched {frac:.3f} of the reference teacher's"
             worst = 0.0
             for k in z.files:
                 if k.startswith(f"it{it}_m_"):
                     name = k[len(f"it{it}_m_"):]
                     if np.isnan(z[k]):
-                        assert math.isnan(m[name]), f"{k}: reference NaN (empty mean), HIP {m[name]}"
+                        assert math.isnan(m[name]) and math.isnan(om[name]), f"{k}: reference NaN (empty mean), HIP {m[name]}, oracle {om[name]}"
                         continue
+                    close(torch.tensor(om[name]), z[k], 2e-4, 1e-6, "oracle (state carrier) " + k)
                     worst = max(worst, abs(m[name] - float(z[k])) / (abs(float(z[k])) + 1e-6))
                     close(torch.tensor(m[name]), z[k], 1e-4 if it == 0 else 1e-3, 1e-6, k)
             ssd, tsd = tr.model.state_dict(), tr.model_teacher.state_dict()
-            sum_atol = 2e-4 if it == 0 else 1e-3
             for k in probes:
-                close(ssd[k].double().sum().cpu(), z[f"it{it}_s_sum_{k}"], 1e-5, sum_atol, f"it {it} student sum {k}")
+                close(ssd[k].double().sum().cpu(), z[f"it{it}_s_sum_{k}"], 1e-5, 1e-3, f"it {it} student sum {k}")
                 close(ssd[k].flatten()[:16].cpu(), z[f"it{it}_s_head_{k}"], 1e-4, 1e-6, f"it {it} student head {k}")
-                close(tsd[k].double().sum().cpu(), z[f"it{it}_t_sum_{k}"], 1e-5, sum_atol, f"it {it} teacher sum {k}")
+                close(tsd[k].double().sum().cpu(), z[f"it{it}_t_sum_{k}"], 1e-5, 1e-3, f"it {it} teacher sum {k}")
                 close(tsd[k].flatten()[:16].cpu(), z[f"it{it}_t_head_{k}"], 1e-4, 1e-6, f"it {it} teacher head {k}")
             report.append(f"it {it}: worst metric deviation {worst:.2e}" + (f", pseudo boxes matched {frac:.3f}" if frac is not None else ""))
     finally:
         sampling.set_key_source(None)
         with capsys.disabled():
-            print("\n[run_step_long on HIP] " + "; ".join(report))
+            print("\n[run_step_long on HIP, state carried by the oracle] " + "; ".join(report))
 
 
 def test_full_size_1333x800_backbone_and_rpn_vs_oracle():

@@ -266,3 +266,31 @@ def test_wino4_dynamic_schedule_under_cu_contention():
 def ctypes_stream(s):
     import ctypes
     return ctypes.c_void_p(s.cuda_stream)
+
+
+@pytest.mark.parametrize("name", ["ptmi_conv3x3_wino4_wgrad", "ptmi_conv3x3_wino_wgrad"])
+@pytest.mark.parametrize("waves", [1, 4, 16])
+def test_wgrad_waves_entry_points(name, waves):
+    """round 6: the Winograd-domain weight-gradient kernels with `waves` fills of the chip (what PTrainer selects under DDP): same
+    result as one fill up to the summation order of the split partials (1e-4 of the scale vs float64 torch; bitwise repeatable)"""
+    from probabilisticteacher_amd import _lib, ops
+    lib = _lib.load()
+    gen = g(300 + waves)
+    n, cin, cout, h, w = 3, 64, 128, 37, 70
+    x = torch.relu(torch.randn(n, cin, h, w, generator=gen))
+    gy = torch.randn(n, cout, h, w, generator=gen)
+    wr = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wr, br, padding=1).backward(gy.double())
+    xd, gd = x.to(DEV), gy.to(DEV)
+    outs = []
+    for _ in range(2):
+        dw, db = torch.empty(cout, cin, 3, 3, device=DEV), torch.empty(cout, device=DEV)
+        ws = torch.empty(getattr(lib, name + "_ws_floats_waves")(n, cin, cout, h, w, waves), device=DEV)
+        _lib.call(name + "_waves", ops._ptr(xd), ops._ptr(gd), ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0, waves,
+                  ops._stream())
+        outs.append((dw.clone(), db.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "fixed-order reduction of the split partials"
+    assert float((outs[0][0].cpu().double() - wr.grad).abs().max()) <= 1e-4 * float(wr.grad.abs().max())
+    assert float((outs[0][1].cpu().double() - br.grad).abs().max()) <= 1e-4 * float(br.grad.abs().max())
+    assert getattr(lib, name + "_ws_floats_waves")(n, cin, cout, h, w, 1) == getattr(lib, name + "_ws_floats")(n, cin, cout, h, w)
