@@ -125,6 +125,24 @@ int ptmi_conv3x3_wino4_wgrad_fits(int h, int w);
 int64_t ptmi_conv3x3_wino4_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wino4_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int n,
                              int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);
+/* ptmi_conv3x3_wino4_* with the 36 transform-domain positions SPLIT over the two waves of a tile row (round 6, csrc/wino4p.hip):
+ * same layers (pt/modeling/backbone/vgg.py:45-53,66-69, pt/modeling/proposal_generator/rpn.py:96), same contract, epilogues, dgrad
+ * convention (mode 1 pack), shape limits (ptmi_conv3x3_wino4p_fwd_fits == ptmi_conv3x3_wino4_fwd_fits) and tile schedules
+ * (sched as ptmi_conv3x3_wino4_fwd_sched; NULL = static).  A wave owns all 64 output channels x 18 positions instead of 32 channels
+ * x 36 positions: it transforms only its three rows of every window (72 instead of 144 FMAs per lane and 4-channel chunk -- beside
+ * fp32 MFMAs every FMA is issue time), and the two waves exchange partial 4x4 outputs through LDS in the epilogue.  The packed
+ * weights have their own layout (ptmi_conv3x3_wino4p_pack_weights); results agree with ptmi_conv3x3_wino4_fwd to fp32 rounding
+ * (the inverse transform's row sum is associated differently), not bit for bit. */
+int64_t ptmi_conv3x3_wino4p_packed_floats(int cin, int cout);
+int ptmi_conv3x3_wino4p_pack_weights(const float* w, float* wp, int w_cout, int w_cin, int mode,
+                                     ptmi_stream_t s);
+int ptmi_conv3x3_wino4p_fwd(const float* x, const float* wp, const float* bias, const float* mask_ref,
+                            float* y, int n, int cin, int cout, int h, int w, int epilogue,
+                            ptmi_stream_t s);
+int ptmi_conv3x3_wino4p_fwd_sched(const float* x, const float* wp, const float* bias,
+                                  const float* mask_ref, float* y, int n, int cin, int cout, int h,
+                                  int w, int epilogue, int32_t* sched, ptmi_stream_t s);
+int ptmi_conv3x3_wino4p_fwd_fits(int cin, int cout, int h, int w);
 /* The two Winograd-domain weight-gradient kernels with `waves` fills of the chip's one-workgroup-per-CU slots instead of one
  * (round 6): their workgroups each own a contiguous share of the (image, tile) list, so with one fill a workgroup whose CU is held by
  * another kernel when the launch starts -- an RCCL collective overlapping backward, pt/engine/trainer.py:92-95,384 under DDP --

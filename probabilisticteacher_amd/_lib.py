@@ -36,6 +36,11 @@ SIGNATURES = {
     "ptmi_conv3x3_wino4_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_conv3x3_wino4_fwd_sched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ptmi_conv3x3_wino4_fwd_fits": (_i, [_i, _i, _i, _i]),
+    "ptmi_conv3x3_wino4p_packed_floats": (_i64, [_i, _i]),
+    "ptmi_conv3x3_wino4p_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_wino4p_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_conv3x3_wino4p_fwd_sched": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ptmi_conv3x3_wino4p_fwd_fits": (_i, [_i, _i, _i, _i]),
     "ptmi_conv3x3_wino4_wgrad_fits": (_i, [_i, _i]),
     "ptmi_conv3x3_wino4_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_conv3x3_wino4_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libptmi355.so")
-SOURCES = ["abi.cpp", "conv.hip", "wino.hip", "wino4.hip", "wino4w.hip", "p8.hip", "p8gemm.hip", "gemm.hip", "misc.hip", "boxes.hip", "nms.hip", "sort.hip", "roi_align.hip",
+SOURCES = ["abi.cpp", "conv.hip", "wino.hip", "wino4.hip", "wino4p.hip", "wino4w.hip", "p8.hip", "p8gemm.hip", "gemm.hip", "misc.hip", "boxes.hip", "nms.hip", "sort.hip", "roi_align.hip",
            "losses.hip", "augment.hip"]
 # -ffp-contract=off: index-producing kernels (IoU, NMS, matcher) must evaluate fp32 expressions exactly as the
 # CPU reference does.  -munsafe-fp-atomics: hardware fp32 atomic add for the ROIAlign backward scatter.
@@ -22,7 +22,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-result"]
 # per-file extra flags.  wino4.hip: its transforms are scalar FMA sequences the SLP vectoriser would turn into v_pk_fma_f32 +
 # register shuffles (slower next to MFMAs)
-FILE_FLAGS = {"wino4.hip": ["-fno-slp-vectorize"], "wino4w.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"wino4.hip": ["-fno-slp-vectorize"], "wino4p.hip": ["-fno-slp-vectorize"], "wino4w.hip": ["-fno-slp-vectorize"]}
 
 
 def _deps_mtime():

@@ -29,18 +29,30 @@ def close(a, b, rtol, atol, what=""):
     return float(err.max())
 
 
+FAMS = ["wino4", "wino4p"]        # csrc/wino4.hip (round 5) / csrc/wino4p.hip (round 6: positions split over the wave pair) -- same contract
+FAM = "wino4"
+
+
+@pytest.fixture(params=FAMS)
+def fam(request):
+    global FAM
+    FAM = request.param
+    yield request.param
+    FAM = "wino4"
+
+
 def _wino4(x, wt, bias, mask, epilogue, mode=0):
-    """ptmi_conv3x3_wino4_pack_weights + ptmi_conv3x3_wino4_fwd on device tensors"""
+    """ptmi_conv3x3_<FAM>_pack_weights + ptmi_conv3x3_<FAM>_fwd on device tensors"""
     from probabilisticteacher_amd import _lib, ops
     call, ptr, stream = _lib.call, ops._ptr, ops._stream
     co, ci = wt.shape[0], wt.shape[1]
     conv_cin, conv_cout = (ci, co) if mode == 0 else (co, ci)
     n, cin, h, w = x.shape
     assert cin == conv_cin
-    wp = torch.empty(_lib.load().ptmi_conv3x3_wino4_packed_floats(conv_cin, conv_cout), device=DEV)
-    call("ptmi_conv3x3_wino4_pack_weights", ptr(wt), ptr(wp), co, ci, mode, stream())
+    wp = torch.empty(getattr(_lib.load(), f"ptmi_conv3x3_{FAM}_packed_floats")(conv_cin, conv_cout), device=DEV)
+    call(f"ptmi_conv3x3_{FAM}_pack_weights", ptr(wt), ptr(wp), co, ci, mode, stream())
     y = torch.full((n, conv_cout, h // 2, w // 2) if epilogue == 4 else (n, conv_cout, h, w), float("nan"), device=DEV)
-    call("ptmi_conv3x3_wino4_fwd", ptr(x), ptr(wp), ptr(bias), ptr(mask), ptr(y), n, conv_cin, conv_cout, h, w, epilogue,
+    call(f"ptmi_conv3x3_{FAM}_fwd", ptr(x), ptr(wp), ptr(bias), ptr(mask), ptr(y), n, conv_cin, conv_cout, h, w, epilogue,
          stream())
     return y
 
@@ -65,7 +77,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
-def test_wino4_forward_epilogues(n, cin, cout, h, w):
+def test_wino4_forward_epilogues(fam, n, cin, cout, h, w):
     gen = g(n * 1000 + cin + cout + h + w)
     x = torch.randn(n, cin, h, w, generator=gen)
     wt = torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))
@@ -80,7 +92,7 @@ def test_wino4_forward_epilogues(n, cin, cout, h, w):
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", SHAPES)
-def test_wino4_dgrad_with_relu_mask(n, cin, cout, h, w):
+def test_wino4_dgrad_with_relu_mask(fam, n, cin, cout, h, w):
     """dX = conv(dY, W^T flipped) (pack mode 1), plain (epilogue 2) and through the producer's ReLU mask (epilogue 3).
     (The conv's input channel count is `cout` here: only shapes whose cout is a multiple of 8 are served.)"""
     if cout % 8:
@@ -97,16 +109,17 @@ def test_wino4_dgrad_with_relu_mask(n, cin, cout, h, w):
     close(got3, xr.grad * (mask_src > 0), 1e-4, 2e-4, "dgrad + relu mask")
 
 
-def test_wino4_rejects_channel_counts_it_does_not_serve():
+def test_wino4_rejects_channel_counts_it_does_not_serve(fam):
     from probabilisticteacher_amd import _lib
     lib = _lib.load()
-    assert lib.ptmi_conv3x3_wino4_fwd_fits(20, 64, 8, 8) == 0 and lib.ptmi_conv3x3_wino4_fwd_fits(24, 64, 8, 8) == 1
+    fits = getattr(lib, f"ptmi_conv3x3_{fam}_fwd_fits")
+    assert fits(20, 64, 8, 8) == 0 and fits(24, 64, 8, 8) == 1
     x = torch.zeros(1, 20, 8, 8, device=DEV)
     with pytest.raises(_lib.PtmiError):
         _wino4(x, torch.zeros(64, 20, 3, 3, device=DEV), None, None, 2)
 
 
-def test_wino4_baseline_layer_shapes():
+def test_wino4_baseline_layer_shapes(fam):
     """One image of every distinct layer shape of the 1333x800 stack that the F(4x4,3x3) kernel may serve, against torch CPU on
     border-including crops, + the measured error (printed: the margin to the 1e-4 bar)."""
     worst = 0.0
@@ -124,7 +137,7 @@ def test_wino4_baseline_layer_shapes():
             ref = F.relu(F.conv2d(x[:, :, y0:y1, x0:x1], wt, b, padding=1))
             ref = ref[:, :, ys.start - y0: ys.start - y0 + (ys.stop - ys.start), xs.start - x0: xs.start - x0 + (xs.stop - xs.start)]
             worst = max(worst, close(got[:, :, ys, xs], ref, 1e-4, 1e-4, f"layer {cin}->{cout} {h}x{w} crop {ys} {xs}"))
-    print(f"\n[wino4] worst abs error over the layer-shape crops: {worst:.2e} (bar 1e-4 + 1e-4 |ref|)")
+    print(f"\n[{fam}] worst abs error over the layer-shape crops: {worst:.2e} (bar 1e-4 + 1e-4 |ref|)")
 
 
 # ------------------------------------------------------------------------------------------------ weight gradient (csrc/wino4w.hip)
@@ -200,7 +213,7 @@ def _wino4_sched(x, wp, bias, mask, epilogue, conv_cout, sched):
     from probabilisticteacher_amd import _lib, ops
     n, cin, h, w = x.shape
     y = torch.full((n, conv_cout, h // 2, w // 2) if epilogue == 4 else (n, conv_cout, h, w), float("nan"), device=DEV)
-    _lib.call("ptmi_conv3x3_wino4_fwd_sched", ops._ptr(x), ops._ptr(wp), ops._ptr(bias), ops._ptr(mask), ops._ptr(y), n, cin,
+    _lib.call(f"ptmi_conv3x3_{FAM}_fwd_sched", ops._ptr(x), ops._ptr(wp), ops._ptr(bias), ops._ptr(mask), ops._ptr(y), n, cin,
               conv_cout, h, w, epilogue, ops._ptr(sched), ops._stream())
     return y
 
@@ -215,7 +228,7 @@ SCHED_SHAPES = SHAPES + [
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", SCHED_SHAPES)
-def test_wino4_dynamic_schedule_is_bit_identical_to_static_and_rearms(n, cin, cout, h, w):
+def test_wino4_dynamic_schedule_is_bit_identical_to_static_and_rearms(fam, n, cin, cout, h, w):
     """The work-queue schedule hands every tile to exactly one workgroup: the output equals the static walk's BIT FOR BIT (a tile's
     arithmetic does not depend on who computes it; a tile drawn twice would also pass, a tile never drawn leaves the NaN fill), for
     every epilogue, and the 16 schedule words are zero again after each launch -- the same buffer serves the next launch."""
@@ -224,8 +237,8 @@ def test_wino4_dynamic_schedule_is_bit_identical_to_static_and_rearms(n, cin, co
     x = torch.randn(n, cin, h, w, generator=gen).to(DEV)
     wt = (torch.randn(cout, cin, 3, 3, generator=gen) * math.sqrt(2.0 / (9 * cin))).to(DEV)
     b = (torch.randn(cout, generator=gen) * 0.1).to(DEV)
-    wp = torch.empty(_lib.load().ptmi_conv3x3_wino4_packed_floats(cin, cout), device=DEV)
-    _lib.call("ptmi_conv3x3_wino4_pack_weights", ops._ptr(wt), ops._ptr(wp), cout, cin, 0, ops._stream())
+    wp = torch.empty(getattr(_lib.load(), f"ptmi_conv3x3_{FAM}_packed_floats")(cin, cout), device=DEV)
+    _lib.call(f"ptmi_conv3x3_{FAM}_pack_weights", ops._ptr(wt), ops._ptr(wp), cout, cin, 0, ops._stream())
     mask = torch.randn(n, cout, h, w, generator=gen).to(DEV)
     sched = torch.zeros(16, dtype=torch.int32, device=DEV)
     for epi, bias, m in ((1, b, None), (2, None, None), (3, None, mask), (4, b, None)):
@@ -239,7 +252,7 @@ def test_wino4_dynamic_schedule_is_bit_identical_to_static_and_rearms(n, cin, co
             assert not bool(sched.any()), f"epilogue {epi} launch {rep}: schedule words not zero after the launch: {sched.tolist()}"
 
 
-def test_wino4_dynamic_schedule_under_cu_contention():
+def test_wino4_dynamic_schedule_under_cu_contention(fam):
     """A side stream holds 64 CUs' worth of LDS while the convolution launches (what an RCCL kernel overlapping backward does):
     the output stays bit-identical and the schedule words re-arm.  (Timing under contention: tools/exp/contention.py.)"""
     from probabilisticteacher_amd import _lib, ops
@@ -248,8 +261,8 @@ def test_wino4_dynamic_schedule_under_cu_contention():
     x = torch.randn(n, cin, h, w, generator=gen).to(DEV)
     wt = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.04).to(DEV)
     b = (torch.randn(cout, generator=gen) * 0.1).to(DEV)
-    wp = torch.empty(_lib.load().ptmi_conv3x3_wino4_packed_floats(cin, cout), device=DEV)
-    _lib.call("ptmi_conv3x3_wino4_pack_weights", ops._ptr(wt), ops._ptr(wp), cout, cin, 0, ops._stream())
+    wp = torch.empty(getattr(_lib.load(), f"ptmi_conv3x3_{FAM}_packed_floats")(cin, cout), device=DEV)
+    _lib.call(f"ptmi_conv3x3_{FAM}_pack_weights", ops._ptr(wt), ops._ptr(wp), cout, cin, 0, ops._stream())
     sched = torch.zeros(16, dtype=torch.int32, device=DEV)
     ref = _wino4_sched(x, wp, b, None, 1, cout, None)
     torch.cuda.synchronize()

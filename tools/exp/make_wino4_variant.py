@@ -53,7 +53,7 @@ def main():
             obj = os.path.join(BIN, f"w4_{name}.o")
             subprocess.check_call(["hipcc"] + FLAGS + extra + ["-c", tmp, "-o", obj])
             subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
-                                   os.path.join(BIN, f"libptmi355_{'w4' if which == 'wino4' else 'w4w'}_{name}.so")] + objs + [obj])
+                                   os.path.join(BIN, f"libptmi355_{ {'wino4': 'w4', 'wino4w': 'w4w'}.get(which, which) }_{name}.so")] + objs + [obj])
         finally:
             os.remove(tmp)
         print("built", name, "without", sorted(drop))

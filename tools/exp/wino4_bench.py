@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--epi", type=int, default=1)
     ap.add_argument("--lib", default=None)
     ap.add_argument("--only4", action="store_true")
+    ap.add_argument("--p", action="store_true", help="also time ptmi_conv3x3_wino4p_fwd (round 6: positions split over the wave pair)")
     ap.add_argument("--custom", action="append", default=[], help="name=cin,cout,h,w (repeatable)")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions; the minimum is reported")
     ap.add_argument("--sched", action="store_true", help="wino4: ALSO time ptmi_conv3x3_wino4_fwd_sched (the dynamic tile schedule of round 6)")
@@ -43,7 +44,7 @@ def main():
         fl = 2.0 * 9 * cin * cout * h * w * a.n
         outs = {}
         line = f"{name:8s} n={a.n:2d}"
-        for kind in (("wino4",) if a.only4 else ("wino", "wino4")):
+        for kind in ((("wino4",) if a.only4 else ("wino", "wino4")) + (("wino4p",) if a.p else ())):
             pf = getattr(lib, f"ptmi_conv3x3_{kind}_packed_floats")
             pf.restype = ctypes.c_int64
             wp = torch.empty(pf(cin, cout), device="cuda:0")
@@ -90,7 +91,7 @@ def main():
                     torch.cuda.synchronize()
                     msd = min(msd, e0.elapsed_time(e1) / a.iters)
                 line += f"  wino4 dynamic: {msd:7.3f} ms (x{msd / ms:.3f} of static; equal {bool(torch.equal(y, y_static))})"
-            if a.stamps and kind == "wino4":
+            if a.stamps and kind in ("wino4", "wino4p") and (kind == "wino4p" or not a.p):
                 t = tr.cpu().view(64, 8).tolist()
                 last = max(k for k in range(64) if t[k][0])
                 if last > 2:
@@ -101,7 +102,10 @@ def main():
                         print(f"   tile {k}: zero-init {t[k][1]-t[k][0]}  chunk loop {t[k][2]-t[k][1]} ({(t[k][2]-t[k][1]) / (cin // 4):.0f} per chunk)  "
                               f"vmcnt(0) {t[k][3]-t[k][2]}  epilogue {t[k][4]-t[k][3]}  to next tile {t[k+1][0]-t[k][4]}  total {t[k+1][0]-t[k][0]}")
             line += f"  {kind}: {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s direct-eq"
-        if len(outs) == 2:
+        if "wino4p" in outs and "wino4" in outs:
+            d = (outs["wino4p"][0] - outs["wino4"][0]).abs().max().item()
+            line += f"  wino4p/wino4 x{outs['wino4p'][1] / outs['wino4'][1]:.3f}  max |diff| {d:.2e}"
+        if "wino" in outs and "wino4" in outs:
             d = (outs["wino"][0] - outs["wino4"][0]).abs().max().item()
             line += f"  speed-up {outs['wino'][1] / outs['wino4'][1]:.3f}  max |wino - wino4| {d:.2e} (max |y| {outs['wino'][0].abs().max().item():.2f})"
         print(line, flush=True)
