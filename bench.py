@@ -81,8 +81,8 @@ def cpu_baseline(h, w, K, seed=0, student_only=False):
                        f"1 unlabelled {w}x{h} image, {dt:.1f} s")}
 
 
-PMC_PROFILE = "profiles/r05_bench_b16_pmc_by_kernel.json"
-DOMINANT = "conv3x3_wino4_kernel"         # the kernel the roofline object describes (its rocprofv3 name contains this)
+PMC_PROFILE = "profiles/r06_bench_b16_pmc_by_kernel.json"
+DOMINANT = "conv3x3_wino4p_kernel"        # the kernel the roofline object describes (its rocprofv3 name contains this)
 DOMINANT_AMP = "p8_conv3x3_kernel"        # ... with --amp: the bf16-storage forward / dgrad kernel
 
 
@@ -329,7 +329,7 @@ def main():
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["calls"], 1),
                          "kernel": ("p8_conv3x3_kernel<MT> (bf16 storage: all 3x3 conv fwd + dgrad launches)" if args.amp else
-                                    "conv3x3_wino4_kernel (fused Winograd F(4x4,3x3), round 5: every 3x3 conv fwd + dgrad launch with "
+                                    "conv3x3_wino4p_kernel (fused Winograd F(4x4,3x3), positions split over the wave pair, round 6: every 3x3 conv fwd + dgrad launch with "
                                     ">= 64 input channels; the 3-channel stem runs conv3x3_stem_kernel, listed under kernels)"),
                          "achieved_is": "MFMA FLOPs issued by the kernel (36 multiplies per 4x4 tile and channel pair -- a quarter of "
                                         "the direct algorithm's 144 -- tile padding included) / HIP-event time; equals the direct "

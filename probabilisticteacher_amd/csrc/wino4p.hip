@@ -535,6 +535,10 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
     // One chunk = 72 slots; EVERY chunk runs the same body (no joins of differently specialised copies: at every join the register
     // allocator moved accumulator tiles around).  PAR: parity of the chunk (which of V0 / V1 is current).
     typedef __attribute__((address_space(3))) f32x2 xlds_f32x2_t;
+    auto ld2 = [](const float* p) __attribute__((always_inline)) {                       // the 8-byte group: two positions of one channel
+        const f32x2 t2 = *(const volatile xlds_f32x2_t*)p;
+        return (f32x4){t2[0], t2[1], 0.f, 0.f};
+    };
     auto chunk = [&](auto par_c) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         float(&Vc)[3][6] = PAR ? V1 : V0;
@@ -573,10 +577,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
                 constexpr int g2 = hh < 16 ? hh >> 2 : 4, c2 = hh < 16 ? hh & 3 : hh - 16;
                 if constexpr (h2 >= 20) A[h2 & 3] = *(const volatile xlds_f32x4_t*)(apn + c2 * 64);   // [x4:ar]
                 else if constexpr (g2 < 4) A[h2 & 3] = *(const volatile xlds_f32x4_t*)((c2 < 2 ? ap_lo : ap_hi) + g2 * 256 + (c2 & 1) * 64);   // [x4:ar]
-                else {
-                    const f32x2 t2 = *(const volatile xlds_f32x2_t*)((c2 < 2 ? ap2_lo : ap2_hi) + (c2 & 1) * 32);   // [x4:ar]
-                    A[h2 & 3][0] = t2[0]; A[h2 & 3][1] = t2[1];
-                }
+                else A[h2 & 3] = ld2((c2 < 2 ? ap2_lo : ap2_hi) + (c2 & 1) * 32);   // [x4:ar]
             }
             if constexpr (S == XHAND) {
                 // everything but this chunk's DMA instructions so far (11 of its 12) has landed: slab c + 1, patch c + 2
@@ -652,25 +653,52 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
         const int xw = wave * 1024 + lane * 4, xr = (wave ^ 2) * 1024 + lane * 4;      // this wave's / its partner's (same tile row, other half) slots
         // the full 4x4 outputs of the lane's j-th finalised channel (local tile c = j >> 2, element r = j & 3: real channel
         // co_w + 16 c + 4 kq + r): the wave's own partial + the partner's, which arrives through LDS while this wave sends the partial of
-        // local channel (2 + c, r) the other way.  One workgroup barrier per channel (double-buffered slots).
-        auto inverse = [&](auto ct_c, auto r_c, float (&o)[4][4]) __attribute__((always_inline)) {
-            constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value, j = 4 * ct + r;
-            float* const wb = xbuf + (j & 1) * 4096;
-            {
-                float os[4][4];
-                half_inverse(std::integral_constant<int, 2 + ct>{}, r_c, os);
+        // local channel (2 + c, r) the other way.  One workgroup barrier per channel, double-buffered slots, software-pipelined: the
+        // partial for channel j + 1 is computed and written while the partner's partial for channel j is on its way back from LDS
+        // (the first version -- write, barrier, read, add, per channel -- cost 4.8 k cycles per tile more than the unsplit epilogue)
+        auto send = [&](auto j_c) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_c)::value, ct = 2 + (j >> 2), r = j & 3;
+            // (as half_inverse, emitted row by row: twelve live values instead of twenty-eight)
+            float z[3][4];
+            xfor(std::make_integer_sequence<int, 3>{}, [&](auto i_c) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_c)::value;
+                float m[6];
+                xfor(std::make_integer_sequence<int, 6>{}, [&](auto jj_c) __attribute__((always_inline)) {
+                    constexpr int p = 6 * i + decltype(jj_c)::value;
+                    if constexpr (p < 16) m[decltype(jj_c)::value] = rd(accA[4 * p + ct][r]);
+                    else m[decltype(jj_c)::value] = accV[4 * (p - 16) + ct][r];
+                });
+                xout(m, z[i]);
+            });
+            float* const wb = xbuf + (j & 1) * 4096 + xw;
+            f32x4 sm, df;
     #pragma unroll
-                for (int a = 0; a < 4; ++a)
-                    *(volatile xlds_f32x4_t*)(wb + xw + a * 256) = (f32x4){os[a][0], os[a][1], os[a][2], os[a][3]};
-            }
+            for (int l = 0; l < 4; ++l) { sm[l] = xadd(z[1][l], z[2][l]); df[l] = xsub(z[1][l], z[2][l]); }
+            *(volatile xlds_f32x4_t*)(wb) = (f32x4){xfma(o_e0, z[0][0], sm[0]), xfma(o_e0, z[0][1], sm[1]), xfma(o_e0, z[0][2], sm[2]), xfma(o_e0, z[0][3], sm[3])};
+            *(volatile xlds_f32x4_t*)(wb + 256) = (f32x4){xmul(o_p1, df[0]), xmul(o_p1, df[1]), xmul(o_p1, df[2]), xmul(o_p1, df[3])};
+            *(volatile xlds_f32x4_t*)(wb + 512) = (f32x4){xmul(o_p2, sm[0]), xmul(o_p2, sm[1]), xmul(o_p2, sm[2]), xmul(o_p2, sm[3])};
+            *(volatile xlds_f32x4_t*)(wb + 768) = (f32x4){xfma(o_e3, z[0][0], xmul(o_p3, df[0])), xfma(o_e3, z[0][1], xmul(o_p3, df[1])),
+                                                           xfma(o_e3, z[0][2], xmul(o_p3, df[2])), xfma(o_e3, z[0][3], xmul(o_p3, df[3]))};
+        };
+        auto inverse = [&](auto ct_c, auto r_c, float (&o)[4][4], auto pipe_c) __attribute__((always_inline)) {
+            constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value, j = 4 * ct + r;
+            constexpr bool PIPE = decltype(pipe_c)::value;           // (false: the mask epilogue, whose producer activations are in flight too --
+                                                                      // the pipelined order spills there; its next partial goes out after the adds)
             half_inverse(ct_c, r_c, o);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // (the partner's partial j is in its slot)
+            f32x4 pv[4];
+            const float* const rb = xbuf + (j & 1) * 4096 + xr;
+    #pragma unroll
+            for (int a = 0; a < 4; ++a) pv[a] = *(const volatile xlds_f32x4_t*)(rb + a * 256);
+            // slot (j + 1) & 1 was last read for channel j - 1: consumed by every wave before it reached the barrier above
+            if constexpr (PIPE && j < 7) send(std::integral_constant<int, (j < 7 ? j + 1 : 0)>{});
     #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                const f32x4 pv = *(const volatile xlds_f32x4_t*)(wb + xr + a * 256);
-                o[a][0] = xadd(o[a][0], pv[0]); o[a][1] = xadd(o[a][1], pv[1]); o[a][2] = xadd(o[a][2], pv[2]); o[a][3] = xadd(o[a][3], pv[3]);
+                o[a][0] = xadd(o[a][0], pv[a][0]); o[a][1] = xadd(o[a][1], pv[a][1]); o[a][2] = xadd(o[a][2], pv[a][2]); o[a][3] = xadd(o[a][3], pv[a][3]);
             }
+            if constexpr (!PIPE && j < 7) send(std::integral_constant<int, (j < 7 ? j + 1 : 0)>{});
         };
+        send(std::integral_constant<int, 0>{});
         auto for_channels = [&](auto&& f) __attribute__((always_inline)) {       // the eight channels the wave finalises (local tiles 0, 1)
             xfor(std::make_integer_sequence<int, 8>{}, [&](auto c_c) __attribute__((always_inline)) {
                 f(std::integral_constant<int, (decltype(c_c)::value >> 2)>{}, std::integral_constant<int, (decltype(c_c)::value & 3)>{});
@@ -694,7 +722,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
             for_channels([&](auto ct_c, auto r_c) __attribute__((always_inline)) {
                 constexpr int ct = decltype(ct_c)::value, r = decltype(r_c)::value;
                 float o[4][4];
-                inverse(ct_c, r_c, o);
+                inverse(ct_c, r_c, o, std::true_type{});
                 const float b = bv[ct][r];
                 const bool cok = 16 * ct + r < cmax;
                 const int soff = (co_w + 16 * ct + r) * OHW * 4;
@@ -753,7 +781,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
                     }
                 }
                 float o[4][4];
-                inverse(ct_c, r_c, o);
+                inverse(ct_c, r_c, o, std::integral_constant<bool, (EPI != 3)>{});
                 const float b = bv[ct][r];
     #pragma unroll
                 for (int a = 0; a < 4; ++a) {

@@ -309,7 +309,7 @@ def _use_wino4(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tupl
         return False
     if hw is None or conv_cout is None:
         return True
-    return bool(_lib.load().ptmi_conv3x3_wino4_fwd_fits(conv_cin, conv_cout, int(hw[0]), int(hw[1])))
+    return bool(getattr(_lib.load(), _CONV_ABI["wino4"] + "_fwd_fits")(conv_cin, conv_cout, int(hw[0]), int(hw[1])))
 
 
 def _conv_kind(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tuple[int, int]] = None) -> str:
@@ -319,7 +319,26 @@ def _conv_kind(conv_cin: int, conv_cout: Optional[int] = None, hw: Optional[Tupl
     return "wino" if _use_wino(conv_cin, conv_cout, hw) else "mfma"
 
 
-_CONV_ABI = {"wino4": "ptmi_conv3x3_wino4", "wino": "ptmi_conv3x3_wino", "mfma": "ptmi_conv3x3"}
+# kind -> C-ABI family.  "wino4" is served by csrc/wino4p.hip since round 6 (positions split over the wave pair: 2 - 4 % faster on every
+# layer shape but one, tools/exp/wino4_bench.py --p); set_wino4_family("wino4") selects round 5's csrc/wino4.hip (comparison runs)
+_WINO4_FAMILY = "wino4p"
+
+
+class _ConvAbi(dict):
+    def __getitem__(self, kind):
+        return "ptmi_conv3x3_" + _WINO4_FAMILY if kind == "wino4" else dict.__getitem__(self, kind)
+
+
+_CONV_ABI = _ConvAbi({"wino4": "ptmi_conv3x3_wino4p", "wino": "ptmi_conv3x3_wino", "mfma": "ptmi_conv3x3"})
+
+
+def set_wino4_family(name: str) -> None:
+    """the kernel family behind the "wino4" route: "wino4p" (default, csrc/wino4p.hip) | "wino4" (csrc/wino4.hip).  Packed weights
+    are family-specific: packs made before the switch must not be used after it."""
+    global _WINO4_FAMILY
+    if name not in ("wino4", "wino4p"):
+        raise ValueError(f"unknown F(4x4,3x3) kernel family {name!r}")
+    _WINO4_FAMILY = name
 
 
 def _conv_issued(kind: str, n: int, cin: int, cout: int, h: int, w: int):
@@ -384,7 +403,7 @@ def _sched_buf(device):
 
 def _conv_fwd_call(kind: str, x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue):
     if kind == "wino4":
-        _lib.call("ptmi_conv3x3_wino4_fwd_sched", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
+        _lib.call(_CONV_ABI[kind] + "_fwd_sched", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w,
                   epilogue, _ptr(_sched_buf(x.device)), _stream())
     else:
         _lib.call(_CONV_ABI[kind] + "_fwd", _ptr(x), _ptr(wp), _ptr(bias), _ptr(mask_ref), _ptr(y), n, cin, cout, h, w, epilogue,

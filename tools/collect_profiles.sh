@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round profile set, on the GPU box:  bash tools/collect_profiles.sh r05   -> gpurun_out/<tag>_* (copy what is judged into profiles/)
-TAG=${1:-r05}
+# Round profile set, on the GPU box:  bash tools/collect_profiles.sh r06   -> gpurun_out/<tag>_* (copy what is judged into profiles/)
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
@@ -43,6 +43,21 @@ for v in base noxf nord nodma noho mfonly; do
   [ -f tools/exp/_bin/libptmi355_w4w_$v.so ] && { echo "== $v"; timeout 200 python tools/exp/wino4w_bench.py --lib tools/exp/_bin/libptmi355_w4w_$v.so --layers conv3_2,conv4_2 --n 16 2>&1 | grep conv; }
 done > gpurun_out/${TAG}_wino4_wgrad_elimination.txt 2>&1
 for L in conv1_2 conv3_2 conv4_2; do timeout 300 bash tools/exp/wino4_traffic.sh "" $L 48; done > gpurun_out/${TAG}_wino4_traffic_per_layer_n48.txt 2>&1
+# round 6: the position-split kernel (csrc/wino4p.hip, the default) against round 5's (csrc/wino4.hip), per layer, same process; its
+# tile stamps; the static walk against the dynamic schedule per layer; the CU-contention experiment; which XCD a workgroup runs on
+timeout 600 python tools/exp/wino4_bench.py --only4 --p --n 16 --iters 10 > gpurun_out/${TAG}_wino4p_vs_wino4_per_layer_n16.txt 2>&1
+timeout 600 python tools/exp/wino4_bench.py --only4 --p --n 48 --iters 5 > gpurun_out/${TAG}_wino4p_vs_wino4_per_layer_n48.txt 2>&1
+if [ -f tools/exp/_bin/libptmi355_wino4p_stamp.so ]; then
+  timeout 300 python tools/exp/wino4_bench.py --only4 --p --stamps --lib tools/exp/_bin/libptmi355_wino4p_stamp.so --n 16 --layers conv1_2,conv2_2,conv3_2,conv4_2 --iters 3 --reps 1 > gpurun_out/${TAG}_wino4p_tile_stamps.txt 2>&1
+fi
+for v in base noxf nolds nodma noho mfonly; do
+  [ -f tools/exp/_bin/libptmi355_wino4p_$v.so ] && { echo "== $v"; timeout 200 python tools/exp/wino4_bench.py --only4 --p --lib tools/exp/_bin/libptmi355_wino4p_$v.so --layers conv3_2,conv1_2 --n 16 --iters 10 2>&1 | grep conv; }
+done > gpurun_out/${TAG}_wino4p_elimination.txt 2>&1
+timeout 600 python tools/exp/wino4_bench.py --only4 --sched --n 48 --iters 5 > gpurun_out/${TAG}_wino4_static_vs_dynamic_n48.txt 2>&1
+[ -f tools/exp/_bin/libptmi355_w4_r05.so ] && { for rep in 1 2; do for L in "" "--lib tools/exp/_bin/libptmi355_w4_r05.so"; do echo "== ${L:-product (round 6, static instantiation)} rep $rep"; timeout 300 python tools/exp/wino4_bench.py --only4 --n 48 --iters 5 --layers conv1_2,conv2_2,conv3_2,conv4_2,conv5_1 $L 2>&1 | grep conv; done; done; } > gpurun_out/${TAG}_wino4_r05_vs_r06_n48.txt 2>&1
+timeout 900 python tools/exp/contention.py --hold 0,8,16,32 --schedule static,dynamic --waves 1,4 > gpurun_out/${TAG}_contention.txt 2>&1
+[ -x tools/exp/_bin/xcc_probe ] && tools/exp/_bin/xcc_probe > gpurun_out/${TAG}_xcc_probe.txt 2>&1
+for L in conv1_2 conv3_2 conv4_2; do timeout 300 bash tools/exp/wino4_traffic.sh "" $L 48 wino4p; done > gpurun_out/${TAG}_wino4p_traffic_per_layer_n48.txt 2>&1
 # ROIAlign at the step's launch shapes / ROI extents, host-boundness of the step
 timeout 300 python tools/exp/roi_bench.py > gpurun_out/${TAG}_roi_align_step_shapes.txt 2>&1
 timeout 600 python tools/exp/host_bound.py > gpurun_out/${TAG}_host_bound_fp32.txt 2>&1
