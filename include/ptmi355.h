@@ -56,7 +56,7 @@ int ptmi_conv3x3_fwd(const float* x, const float* wp, const float* bias, const f
                      ptmi_stream_t s);
 /* wgrad: dw[co][ci][3][3] (+)= sum_{n,y,x} dy[n][co][y][x] * x[n][ci][y+ky-1][x+kx-1].
  * workspace: ptmi_conv3x3_wgrad_ws_floats(...) fp32; split-K partials reduced in a fixed order
- * (deterministic).  accumulate != 0 adds into dw.  db (may be NULL) = sum dy over n,y,x. */
+ * (deterministic).  db (may be NULL) = sum dy over n,y,x.  accumulate != 0 adds into dw AND db. */
 int64_t ptmi_conv3x3_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_conv3x3_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws,
                        int n, int cin, int cout, int h, int w, int accumulate, ptmi_stream_t s);

@@ -107,16 +107,13 @@ def wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, cin: int, cout: int, h: int
         _chk(x, cin, n, h, w, "p8 wgrad input")
         _chk(dy, cout, n, h, w, "p8 wgrad grad")
         group = max(1, min(n, _WGRAD_FALLBACK_BYTES // (4 * max(cin, cout) * h * w)))
-        dbg = torch.empty(cout, dtype=F32, device=x.device)
         for i0 in range(0, n, group):
             i1 = min(n, i0 + group)
             x32, dy32 = _widen_images(x, n, cin, h, w, i0, i1), _widen_images(dy, n, cout, h, w, i0, i1)
             ws = ops._ws("wgrad", _lib.load().ptmi_conv3x3_wgrad_ws_floats(i1 - i0, cin, cout, h, w) * 4, x.device)
             with ops._prof("conv3x3_wgrad", 2.0 * 9 * cin * cout * h * w * (i1 - i0)):
-                _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x32), ops._ptr(dy32), ops._ptr(dw), ops._ptr(dbg if i0 else db), ops._ptr(ws),
-                          i1 - i0, cin, cout, h, w, int(i0 > 0), ops._stream())
-            if i0:
-                db += dbg
+                _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x32), ops._ptr(dy32), ops._ptr(dw), ops._ptr(db), ops._ptr(ws),
+                          i1 - i0, cin, cout, h, w, int(i0 > 0), ops._stream())       # (accumulate adds into dw AND db)
         return dw, db
     ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
     with ops._prof("p8_wgrad", 2.0 * 9 * cin * cout * h * w * n):

@@ -42,6 +42,7 @@ def _batch(gen, n, h, w, K):
 @pytest.mark.parametrize("mode", ["all_reduce", "reduce_scatter"])
 def test_bucketed_rccl_allreduce_in_run_step_is_bitwise_identity(rccl_world1, mode):
     """`mode`: one all-reduce per bucket, or the same exchange as reduce-scatter + all-gather on shard-aligned buckets"""
+    from probabilisticteacher_amd import ops
     from probabilisticteacher_amd.config import setup_cfg
     from probabilisticteacher_amd.engine import PTrainer
     from probabilisticteacher_amd.modeling import sampling
@@ -54,6 +55,11 @@ def test_bucketed_rccl_allreduce_in_run_step_is_bitwise_identity(rccl_world1, mo
         ratios = iter([0.8, 0.6, 0.9, 0.7, 0.75, 0.65, 0.85, 0.55] * 2)
         tr = PTrainer(cfg, ratio_fn=lambda: next(ratios), force_grad_reducer=force, grad_reduce=mode)
         assert tr.reducer.active == force and len(tr.reducer.buckets) >= 4
+        # PTrainer picks the kernel policy by `reducer.active` (dynamic tile schedule + 4 weight-gradient waves under an exchange:
+        # the split partial sums then associate differently); "the exchange is a bitwise identity" is a statement at EQUAL policy
+        assert (ops._TILE_SCHEDULE, ops._WGRAD_WAVES) == (("dynamic", 4) if force else ("static", 1))
+        ops.set_tile_schedule("dynamic")
+        ops.set_wgrad_waves(4)
         gen = torch.Generator().manual_seed(77)
         keyg = torch.Generator().manual_seed(5)
         sampling.set_key_source(lambda labels, sizes, bg: torch.rand(labels.shape, generator=keyg))
@@ -65,6 +71,8 @@ def test_bucketed_rccl_allreduce_in_run_step_is_bitwise_identity(rccl_world1, mo
                 out.append((m, tr.student.grad.clone(), tr.student.flat.clone(), tr.teacher.flat.clone(), early))
         finally:
             sampling.set_key_source(None)
+            ops.set_tile_schedule("static")
+            ops.set_wgrad_waves(1)
         results.append(out)
     for it, (a, b) in enumerate(zip(*results)):
         assert a[0].keys() == b[0].keys()

@@ -751,7 +751,12 @@ def test_rpn_loss_weight_quirk_matches_the_reference():
         sampling.set_key_source(perm_key_source(opt.SeededPerm(93)))
         lu, _, _, _ = model(strong, branch="unsupervised", danchor=True)
         for k, v in lu.items():
-            close(v.detach().cpu(), z["unsup_" + k], 1e-4, 1e-6, "unsup " + k)
+            # the RPN terms (this test's subject: no weight on the unsupervised ones) at 1e-4.  The ROI terms are means over the HIP
+            # side's OWN proposal sample from random-init, near-tied scores: one pair of proposals swapping rank -- any 1e-5 change of
+            # the features does it; round 6's position-split convolution kernel did, round 5's did not -- moves the position-indexed
+            # 512-ROI sample and `loss_cls` by ~1e-3.  They are held to 1e-4 where the proposals are handed across
+            # (tests/test_baseline_size_gpu.py, tests/test_config4_gpu.py); here 2e-3 states "the same quantity on another sample"
+            close(v.detach().cpu(), z["unsup_" + k], 1e-4 if k.startswith("loss_rpn") else 2e-3, 1e-6, "unsup " + k)
     finally:
         sampling.set_key_source(None)
 
