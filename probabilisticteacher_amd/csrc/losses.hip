@@ -151,7 +151,13 @@ __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
-// entropy-focal weight of one teacher row: (1 - H(softmax T)/log C)^lambda   (0*log0 -> NaN kept)
+// entropy-focal weight of one teacher row: (1 - H(softmax T)/log C)^lambda   (0*log0 -> NaN kept).
+// ONE deliberate deviation from the literal expression (round 6): for a near-uniform row the exact base 1 - H/log C is >= 0 but of the
+// size of the rounding of the device's expf / logf (|logit gap| < ~1e-3: a few 1e-8), so it can come out as -6e-8, and a negative base to
+// the power lambda = 0.5 is NaN -- it killed one of 24 loss-curve trajectories at iteration 452 (teacher logits (x, x + d), both cls
+// terms NaN, every other term finite; profiles/r06_loss_curves_v5.txt).  The reference's `(1 - entropy / max_entropy) ** weight_lambda`
+// (fast_rcnn.py:199-200, rpn.py:288-290) has the same hazard with ITS libm's rounding; a base below zero is clamped to the exact
+// expression's limit, 0.  A NaN base (0 * log 0 at extreme confidence) still propagates.
 __device__ __forceinline__ float efl_weight(const float* __restrict__ T, int C, float lambda)
 {
     float m = T[0];
@@ -164,7 +170,8 @@ __device__ __forceinline__ float efl_weight(const float* __restrict__ T, int C, 
         H += p * logf(p);
     }
     H = -H;
-    return powf(1.f - H / logf((float)C), lambda);
+    const float base = 1.f - H / logf((float)C);
+    return powf(base < 0.f ? 0.f : base, lambda);
 }
 
 // ------------------------------------------------------------------------------------------ soft CE + EFL (ROI)

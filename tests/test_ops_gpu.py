@@ -429,6 +429,33 @@ def test_segsort_lds_kernel(ops, sizes, topk):
     assert torch.equal(ops.segsort_desc(keys.to(DEV), offs.to(DEV), max_len=max(sizes), topk=topk)[1].cpu().long(), si), "repeatable"
 
 
+def test_efl_weight_of_near_uniform_teacher_rows_is_finite(ops):
+    """Round 6: for near-uniform teacher rows (logit gap < ~1e-3) the base of the entropy-focal weight, 1 - H / log C, is >= 0 exactly
+    but of the size of the device expf / logf rounding, and a base of -6e-8 to the power 0.5 is NaN -- it ended a loss-curve trajectory
+    at iteration 452 (csrc/losses.hip::efl_weight clamps a negative base to 0 since).  Thousands of such rows, K = 1 and K = 8: both
+    soft-label losses finite, gradients finite, and equal to the oracle's expression wherever THAT is finite (here: everywhere)."""
+    gen = g(452)
+    for C in (2, 9):
+        r = 20000
+        base = torch.randn(r, 1, generator=gen)
+        T = base + torch.randn(r, C, generator=gen) * torch.logspace(-7, -2, r).unsqueeze(1)        # gaps 1e-7 .. 1e-2
+        S = torch.randn(r, C, generator=gen)
+        Sd = S.to(DEV).requires_grad_()
+        got = ops.soft_ce_efl(T.to(DEV), Sd, 0.5, 0.5, True, 1.0 / r)
+        got.backward()
+        assert math.isfinite(float(got)) and bool(torch.isfinite(Sd.grad).all()), f"C = {C}: soft_ce_efl {float(got)}"
+        p = F.softmax(T.double(), -1)
+        ent = -(p * torch.log(p)).sum(-1)
+        w = (1 - ent / math.log(C)).clamp_(min=0) ** 0.5
+        ref = torch.sum(F.softmax(T.double() / 0.5, -1) * w.unsqueeze(-1) * -F.log_softmax(S.double(), -1)) / r
+        # (the weights are square roots of a difference of two numbers that agree to 7 digits: in fp32 only their size survives)
+        close(got, ref.float(), 0.3, 1e-6, f"C = {C}: soft ce on near-uniform rows")
+        x = torch.randn(r, generator=gen).to(DEV).requires_grad_()
+        l_cls, _ = ops.rpn_soft_obj_loss(T.to(DEV), x, 0.5, 0.5, True, 1.0 / r)
+        l_cls.backward()
+        assert math.isfinite(float(l_cls)) and bool(torch.isfinite(x.grad).all()), f"C = {C}: rpn_soft_obj_loss {float(l_cls)}"
+
+
 def test_segsort_host_lengths_guard(ops):
     """a max_len / topk that does not describe the segments is a PtmiError BEFORE the launch when the caller hands over
     its host-side segment lengths (all three product call sites do) -- not NaN keys that only a training-mode check would notice"""
