@@ -204,6 +204,18 @@ int ptmi_p8_gemm_nt_fits(int m, int n, int k);
 int64_t ptmi_p8_wgrad_ws_floats(int n, int cin, int cout, int h, int w);
 int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout,
                   int h, int w, int accumulate, ptmi_stream_t s);
+/* The bf16-storage convolution / weight gradient with `waves` fills of the one-workgroup-per-CU slots (round 6; same contract as the
+ * one-fill entry points = waves 1).  ptmi_p8_conv3x3's persistent workgroups walk items b, b + grid, ...; ptmi_p8_wgrad's own one
+ * contiguous share each: a CU held by another kernel when the launch starts -- an RCCL collective overlapping backward under DDP,
+ * pt/engine/trainer.py:92-95,384, the configuration BASELINE configs[4] names -- makes its workgroup run after all others (2x on the
+ * launch, tools/exp/contention.py).  With more, shorter workgroups the dispatcher rebalances: what PTrainer selects when its gradient
+ * exchange is active (convolution 16 waves: one more prologue per workgroup; weight gradient 4 waves: one more partial-sum store). */
+int ptmi_p8_conv3x3_waves(const void* x, const void* wp, const float* bias, const void* mask_ref, void* y,
+                          int n, int cin, int cout, int h, int w, int epilogue, int waves,
+                          ptmi_stream_t s);
+int64_t ptmi_p8_wgrad_ws_floats_waves(int n, int cin, int cout, int h, int w, int waves);
+int ptmi_p8_wgrad_waves(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin,
+                        int cout, int h, int w, int accumulate, int waves, ptmi_stream_t s);
 /* bf16-STORAGE GEMM for the box head's large Linear layer under SOLVER.AMP.ENABLED (FastRCNNConvFCHead fc1 25088 -> 1024 behind
  * pt/modeling/roi_heads/roi_heads.py:126-128; cuBLAS bf16 under autocast): C[m][n] (fp32, row pitch ldc) = A . B^T (+ bias[n]) (+ ReLU)
  * with BOTH operands bf16 in the "P8 matrix" layout t[ceil(k/8)][rows][8] (k in octets, one 16-byte vector per (row, octet)).

@@ -64,6 +64,9 @@ SIGNATURES = {
     "ptmi_p8_gemm_nt_fits": (_i, [_i, _i, _i]),
     "ptmi_p8_wgrad_ws_floats": (_i64, [_i, _i, _i, _i, _i]),
     "ptmi_p8_wgrad": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_p8_conv3x3_waves": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ptmi_p8_wgrad_ws_floats_waves": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "ptmi_p8_wgrad_waves": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ptmi_p8m_elems": (_i64, [_i, _i]),
     "ptmi_p8m_pack": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp]),
     "ptmi_p8_gemm_nt_ws_floats": (_i64, [_i, _i, _i]),

@@ -856,12 +856,12 @@ __global__ __launch_bounds__(256) void p8_wgrad_reduce_kernel(const float* __res
     }
 }
 
-inline int p8_wgrad_splits(int n, int cin, int cout, int h, int w)
+inline int p8_wgrad_splits(int n, int cin, int cout, int h, int w, int waves = 1)
 {
     const P8Dims d = p8_dims(n, h, w);
     const int pairs = cdiv(cout, G_CO) * cdiv(cin, G_CI);
     const int64_t tiles = (int64_t)cdiv(d.ROWS, 4) * cdiv(d.WS, 32);
-    int S = cdiv(256, pairs);
+    int S = cdiv(256 * (waves < 1 ? 1 : waves > 16 ? 16 : waves), pairs);
     if (S > tiles) S = (int)tiles;
     return S < 1 ? 1 : S;
 }
@@ -951,6 +951,12 @@ int ptmi_p8_pack_weights(const float* w, void* wp, int w_cout, int w_cin, int mo
 int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void* mask_ref, void* y, int n, int cin, int cout,
                     int h, int w, int epilogue, ptmi_stream_t s)
 {
+    return ptmi_p8_conv3x3_waves(x, wp, bias, mask_ref, y, n, cin, cout, h, w, epilogue, 1, s);
+}
+
+int ptmi_p8_conv3x3_waves(const void* x, const void* wp, const float* bias, const void* mask_ref, void* y, int n, int cin, int cout,
+                          int h, int w, int epilogue, int waves, ptmi_stream_t s)
+{
     PTMI_CHECK_ARG(x && wp && y && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_conv3x3: bad args");
     PTMI_CHECK_ARG(epilogue >= 0 && epilogue <= 4, "p8_conv3x3: bad epilogue %d", epilogue);
     PTMI_CHECK_ARG((epilogue > 1 && epilogue != 4) || bias, "p8_conv3x3: bias required for epilogue %d", epilogue);
@@ -971,7 +977,11 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
         cus = 256;
-    const int64_t grid = nWork < (cus / 8) * 8 ? nWork : (cus / 8) * 8;
+    // waves > 1: that many fills of the one-workgroup-per-CU slots, each workgroup walking a 1 / waves share of the items (still a
+    // multiple of 8: the XCD affinity of an item id stays) -- the hardware dispatcher then hands the later workgroups to whichever
+    // CU frees up first, so CUs held by another kernel (a collective overlapping backward) cost their share, not a second pass
+    const int64_t slots = (int64_t)(cus / 8) * 8 * (waves < 1 ? 1 : waves > 64 ? 64 : waves);
+    const int64_t grid = nWork < slots ? nWork : slots;
 #define P8_LAUNCH(MT_, FLAT_, POOL_)                                                                                                       \
     hipLaunchKernelGGL((p8_conv3x3_kernel<MT_, FLAT_, POOL_>), dim3((unsigned)grid), dim3(P8T), 0, (hipStream_t)s, (const u16*)x, (const u16*)wp, bias, \
                        (const u16*)mask_ref, (u16*)y, cout, ycb, d.HS, d.WS, d.ROWS, (long long)d.PT, nChunks, epilogue, coTiles, tilesC,   \
@@ -992,9 +1002,14 @@ int ptmi_p8_conv3x3(const void* x, const void* wp, const float* bias, const void
     return 0;
 }
 
+int64_t ptmi_p8_wgrad_ws_floats_waves(int n, int cin, int cout, int h, int w, int waves)
+{
+    return (int64_t)p8_wgrad_splits(n, cin, cout, h, w, waves) * (9 * (int64_t)cout * cin + cout);
+}
+
 int64_t ptmi_p8_wgrad_ws_floats(int n, int cin, int cout, int h, int w)
 {
-    return (int64_t)p8_wgrad_splits(n, cin, cout, h, w) * (9 * (int64_t)cout * cin + cout);
+    return ptmi_p8_wgrad_ws_floats_waves(n, cin, cout, h, w, 1);
 }
 
 int ptmi_p8_wgrad_fits(int n, int cin, int cout, int h, int w)
@@ -1008,12 +1023,18 @@ int ptmi_p8_wgrad_fits(int n, int cin, int cout, int h, int w)
 int ptmi_p8_wgrad(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h, int w,
                   int accumulate, ptmi_stream_t s)
 {
+    return ptmi_p8_wgrad_waves(x, dy, dw, db, ws, n, cin, cout, h, w, accumulate, 1, s);
+}
+
+int ptmi_p8_wgrad_waves(const void* x, const void* dy, float* dw, float* db, float* ws, int n, int cin, int cout, int h, int w,
+                        int accumulate, int waves, ptmi_stream_t s)
+{
     PTMI_CHECK_ARG(x && dy && dw && ws && n > 0 && cin > 0 && cout > 0 && h > 0 && w > 0, "p8_wgrad: bad args");
     const P8Dims d = p8_dims(n, h, w);
     const int xcb = ptmi_p8_planes(cin), dcb = ptmi_p8_planes(cout);
     PTMI_CHECK_ARG(ptmi_p8_wgrad_fits(n, cin, cout, h, w),
                    "p8_wgrad: tensors beyond the 32-bit buffer offsets (n=%d cin=%d cout=%d h=%d w=%d; ptmi_p8_wgrad_fits)", n, cin, cout, h, w);
-    const int S = p8_wgrad_splits(n, cin, cout, h, w);
+    const int S = p8_wgrad_splits(n, cin, cout, h, w, waves);
     const int coTiles = cdiv(cout, G_CO), ciTiles = cdiv(cin, G_CI), tilesC = cdiv(d.WS, 32);
     const int64_t nTiles = (int64_t)cdiv(d.ROWS, 4) * tilesC;
     PTMI_CHECK_ARG(nTiles < (1ll << 31), "p8_wgrad: too many tiles");

@@ -53,6 +53,7 @@ class PTrainer:
         # static walk / one workgroup per CU is 0.5 - 3 % faster
         ops.set_tile_schedule("dynamic" if self.reducer.active else "static")
         ops.set_wgrad_waves(4 if self.reducer.active else 1)
+        ops.set_p8_conv_waves(16 if self.reducer.active else 1)       # (SOLVER.AMP.ENABLED: the bf16-storage convolution, persistent too)
         self._first_step = True
         self.joint_student_pass = True      # one backbone pass for the two student branches when they share a canvas
         self.ensem_ts_model = EnsembleTSModel(self.model_teacher, self.model)

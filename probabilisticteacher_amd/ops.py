@@ -380,6 +380,18 @@ def set_tile_schedule(mode: str) -> None:
 _WGRAD_WAVES = 1                # fills of the one-workgroup-per-CU slots by the Winograd-domain weight-gradient kernels
 
 
+_P8_CONV_WAVES = 1               # ... and by the persistent bf16-storage convolution (ptmi_p8_conv3x3_waves)
+
+
+def set_p8_conv_waves(waves: int) -> None:
+    """1 (default): one persistent workgroup per CU; > 1: that many fills, each workgroup walking a 1 / waves share of the tiles --
+    PTrainer selects 16 when its gradient exchange is active."""
+    global _P8_CONV_WAVES
+    if not 1 <= int(waves) <= 64:
+        raise ValueError(f"p8 conv waves {waves!r} outside 1 .. 64")
+    _P8_CONV_WAVES = int(waves)
+
+
 def set_wgrad_waves(waves: int) -> None:
     """1 (default): one long workgroup per CU; > 1: that many waves of shorter workgroups (ptmi_conv3x3_wino*_wgrad_waves) -- what
     PTrainer selects when its gradient exchange is active, so that CUs held by the collectives cost their share."""

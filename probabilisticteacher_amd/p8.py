@@ -80,8 +80,8 @@ def conv3x3_raw(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor],
     if mask_ref is not None:
         _chk(mask_ref, cout, n, h, w, "p8 conv mask")
     with ops._prof("p8_conv3x3", flops, nbytes):
-        _lib.call("ptmi_p8_conv3x3", ops._ptr(_chk(x, cin, n, h, w, "p8 conv input")), ops._ptr(wp),
-                  ops._ptr(bias), ops._ptr(mask_ref), ops._ptr(y), n, cin, cout, h, w, epilogue, ops._stream())
+        _lib.call("ptmi_p8_conv3x3_waves", ops._ptr(_chk(x, cin, n, h, w, "p8 conv input")), ops._ptr(wp),
+                  ops._ptr(bias), ops._ptr(mask_ref), ops._ptr(y), n, cin, cout, h, w, epilogue, ops._P8_CONV_WAVES, ops._stream())
     return y
 
 
@@ -115,10 +115,10 @@ def wgrad(x: torch.Tensor, dy: torch.Tensor, n: int, cin: int, cout: int, h: int
                 _lib.call("ptmi_conv3x3_wgrad", ops._ptr(x32), ops._ptr(dy32), ops._ptr(dw), ops._ptr(db), ops._ptr(ws),
                           i1 - i0, cin, cout, h, w, int(i0 > 0), ops._stream())       # (accumulate adds into dw AND db)
         return dw, db
-    ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats(n, cin, cout, h, w) * 4, x.device)
+    ws = ops._ws("p8wgrad", _lib.load().ptmi_p8_wgrad_ws_floats_waves(n, cin, cout, h, w, ops._WGRAD_WAVES) * 4, x.device)
     with ops._prof("p8_wgrad", 2.0 * 9 * cin * cout * h * w * n):
-        _lib.call("ptmi_p8_wgrad", ops._ptr(_chk(x, cin, n, h, w, "p8 wgrad input")), ops._ptr(_chk(dy, cout, n, h, w, "p8 wgrad grad")),
-                  ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0, ops._stream())
+        _lib.call("ptmi_p8_wgrad_waves", ops._ptr(_chk(x, cin, n, h, w, "p8 wgrad input")), ops._ptr(_chk(dy, cout, n, h, w, "p8 wgrad grad")),
+                  ops._ptr(dw), ops._ptr(db), ops._ptr(ws), n, cin, cout, h, w, 0, ops._WGRAD_WAVES, ops._stream())
     return dw, db
 
 

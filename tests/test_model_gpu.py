@@ -751,12 +751,35 @@ def test_rpn_loss_weight_quirk_matches_the_reference():
         sampling.set_key_source(perm_key_source(opt.SeededPerm(93)))
         lu, _, _, _ = model(strong, branch="unsupervised", danchor=True)
         for k, v in lu.items():
-            # the RPN terms (this test's subject: no weight on the unsupervised ones) at 1e-4.  The ROI terms are means over the HIP
-            # side's OWN proposal sample from random-init, near-tied scores: one pair of proposals swapping rank -- any 1e-5 change of
-            # the features does it; round 6's position-split convolution kernel did, round 5's did not -- moves the position-indexed
-            # 512-ROI sample and `loss_cls` by ~1e-3.  They are held to 1e-4 where the proposals are handed across
-            # (tests/test_baseline_size_gpu.py, tests/test_config4_gpu.py); here 2e-3 states "the same quantity on another sample"
-            close(v.detach().cpu(), z["unsup_" + k], 1e-4 if k.startswith("loss_rpn") else 2e-3, 1e-6, "unsup " + k)
+            # the RPN terms (this test's subject: no weight on the unsupervised ones) at 1e-4 of the REAL reference's numbers.
+            # The ROI terms are means over each side's OWN proposal sample from random-init, near-tied scores: one pair of
+            # proposals swapping rank -- any 1e-5 change of the features does it; round 6's position-split convolution kernel
+            # did, round 5's did not -- moves the position-indexed 512-ROI sample, `loss_cls` by ~1e-3 and the NLL
+            # `loss_box_reg` (~16 at random init) by ~1e-2.  Against the golden they can only state "the same quantity on
+            # another sample" (5e-2); the 1e-4 statement for them is made below on IDENTICAL proposals.
+            close(v.detach().cpu(), z["unsup_" + k], 1e-4 if k.startswith("loss_rpn") else 5e-2, 1e-6, "unsup " + k)
+        # ... and on identical proposals: the oracle (its `rpn_loss_weight` path is pinned to the same golden on CPU,
+        # tests/test_oracle_golden.py) runs the same branch with its proposal stage answered by the HIP proposals
+        # (tests/test_baseline_size_gpu.py::_ProposalLog, whose `check` also proves the HIP stage exact on its own inputs)
+        from tests.test_baseline_size_gpu import _ProposalLog
+        ocfg = opt.Cfg(num_classes=K, tau=tau, rpn_loss_weight=float(z["loss_weight"]),
+                       rpn_bbox_reg_loss_weight=float(z["bbox_reg_loss_weight"]))
+        oparams = opt.golden_params(opt.Cfg(num_classes=K, tau=tau), int(z["seed"]))
+        ostrong = records(z, "strong", 2)
+        for i, r in enumerate(ostrong):
+            inst = opt.FreeInstances(tuple(r["image"].shape[-2:]))
+            inst.pseudo_boxes = d2.Boxes(torch.from_numpy(z[f"pseudo{i}_pseudo_boxes"]))
+            inst.scores_logists = torch.from_numpy(z[f"pseudo{i}_scores_logists"])
+            inst.boxes_sigma = torch.from_numpy(z[f"pseudo{i}_boxes_sigma"])
+            r["instances"] = inst
+        with pytest.MonkeyPatch.context() as mp:
+            log = _ProposalLog(mp, ocfg)
+            sampling.set_key_source(perm_key_source(opt.SeededPerm(93)))
+            lh, _, _, _ = model(strong, branch="unsupervised", danchor=True)
+            lo, _, _, _ = opt.model_forward(ocfg, oparams, ostrong, "unsupervised", danchor=True, perm_fn=opt.SeededPerm(93))
+            print(f"\n[rpn loss weight, unsupervised branch on identical proposals] {log.check()}")
+        for k, v in lo.items():
+            close(lh[k].detach().cpu(), v.detach(), 1e-4, 1e-6, "unsup (identical proposals) " + k)
     finally:
         sampling.set_key_source(None)
 

@@ -220,6 +220,39 @@ def test_p8_wgrad_full_size_layers(name, cin, cout, h, w):
     assert float((db.cpu() - br.grad).abs().max()) <= 1e-4 * sb, f"{name} db"
 
 
+@pytest.mark.parametrize("waves", [4, 16, 64])
+def test_p8_conv_and_wgrad_waves_entry_points(waves):
+    """round 6: ptmi_p8_conv3x3_waves -- more, shorter persistent workgroups (what PTrainer selects under DDP with SOLVER.AMP.ENABLED) --
+    gives the one-fill kernel's output BIT FOR BIT (a tile's arithmetic does not depend on which workgroup computes it), every epilogue;
+    ptmi_p8_wgrad_waves agrees with one fill up to the summation order of the split partials and repeats bitwise"""
+    from probabilisticteacher_amd import ops, p8
+    n, cin, cout, h, w = 3, 64, 128, 45, 70
+    x = rb(torch.relu(torch.randn(n, cin, h, w, generator=g(81))))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g(82)) * 0.05)
+    b = torch.randn(cout, generator=g(83)) * 0.1
+    gy = rb(torch.randn(n, cout, h, w, generator=g(84)))
+    xp, gp = p8.from_nchw(x.to(DEV)), p8.from_nchw(gy.to(DEV))
+    wp = p8.pack_weights(wt.to(DEV), 0)
+    mask = p8.from_nchw(rb(torch.randn(n, cout, h, w, generator=g(85))).to(DEV))
+    outs = {}
+    try:
+        for wv in (1, waves):
+            ops.set_p8_conv_waves(wv)
+            ops.set_wgrad_waves(min(wv, 16))
+            outs[wv] = [p8.conv3x3_raw(xp, wp, b.to(DEV) if epi in (0, 1, 4) else None, mask if epi == 3 else None, n, cin, cout, h, w, epi)
+                        for epi in (0, 1, 2, 3, 4)] + list(p8.wgrad(xp, gp, n, cin, cout, h, w))
+        again = list(p8.wgrad(xp, gp, n, cin, cout, h, w))
+    finally:
+        ops.set_p8_conv_waves(1)
+        ops.set_wgrad_waves(1)
+    for epi, (a, c) in enumerate(zip(outs[1][:5], outs[waves][:5])):
+        assert torch.equal(a, c), f"epilogue {epi}: {waves} waves differ from one fill"
+    for name, a, c, r in (("dW", outs[1][5], outs[waves][5], again[0]), ("db", outs[1][6], outs[waves][6], again[1])):
+        assert torch.equal(c, r), f"{name}: not bitwise repeatable at {waves} waves"
+        sc = float(a.abs().max())
+        assert float((a - c).abs().max()) <= 1e-4 * sc, f"{name}: {waves} waves vs one fill"
+
+
 def test_p8_wgrad_oversize_fallback_matches_native_kernel(monkeypatch):
     """p8.wgrad's route for a P8 tensor beyond the kernel's 32-bit offsets (ptmi_p8_wgrad_fits = 0) -- the direct fp32
     split-K kernel on widened operands, over GROUPS of images with accumulate = 1 -- forced on a small shape and compared with the

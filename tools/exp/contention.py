@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--schedule", default="static,dynamic")
     ap.add_argument("--lib", default=None)
     ap.add_argument("--waves", default="1", help="comma list: weight-gradient waves of workgroups (ops.set_wgrad_waves)")
+    ap.add_argument("--amp", action="store_true", help="SOLVER.AMP.ENABLED: the bf16-storage kernels (--p8-waves: their convolution's fills)")
+    ap.add_argument("--p8-waves", default="1", help="comma list, paired with --waves by position (ops.set_p8_conv_waves)")
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--per-gpu-batch", type=int, default=8)
@@ -42,7 +44,7 @@ def main():
     B = args.per_gpu_batch
     cfg = setup_cfg(os.path.join(ROOT, "configs/pt/final_c2f.yaml"), [
         "MODEL.DEVICE", "cuda:0", "MODEL.VGG.PRETRAIN", "", "UNSUPNET.BURN_UP_STEP", 0,
-        "SOLVER.IMG_PER_BATCH_LABEL", B, "SOLVER.IMG_PER_BATCH_UNLABEL", B])
+        "SOLVER.IMG_PER_BATCH_LABEL", B, "SOLVER.IMG_PER_BATCH_UNLABEL", B, "SOLVER.AMP.ENABLED", bool(args.amp)])
     K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
     torch.manual_seed(0)
     trainer = PTrainer(cfg)
@@ -56,10 +58,12 @@ def main():
     print(f"# {cus} CUs; lib {_lib.LIB_PATH}; {B} + {B} images of 1333x800 per step")
     base = {}
     rows = []
-    for sched_w in [(s_, int(w_)) for s_ in args.schedule.split(",") for w_ in args.waves.split(",")]:
-        sched = f"{sched_w[0]}/w{sched_w[1]}"
+    p8w = [int(v) for v in args.p8_waves.split(",")]
+    for sched_w in [(s_, int(w_), p8w[min(i_, len(p8w) - 1)]) for s_ in args.schedule.split(",") for i_, w_ in enumerate(args.waves.split(","))]:
+        sched = f"{sched_w[0]}/w{sched_w[1]}" + (f"/p{sched_w[2]}" if args.amp else "")
         ops.set_tile_schedule(sched_w[0])
         ops.set_wgrad_waves(sched_w[1])
+        ops.set_p8_conv_waves(sched_w[2])
         for k in [int(v) for v in args.hold.split(",")]:
             hold_us = 0
             if k:
@@ -87,13 +91,13 @@ def main():
                 base[sched] = m
             rows.append((sched, k, m, {n: v["ms"] / args.steps for n, v in prof.items()}))
             fair = cus / (cus - k)
-            print(f"{sched:11s} hold {k:3d} CUs: {m:8.1f} ms/step  x{m / base[sched]:.3f} of hold 0 (fair share x{fair:.3f})  "
+            print(f"{sched:15s} hold {k:3d} CUs: {m:8.1f} ms/step  x{m / base[sched]:.3f} of hold 0 (fair share x{fair:.3f})  "
                   f"per-step {[round(v, 1) for v in ms]}")
     print("\n# per-kernel-group ms per step (groups >= 1 ms at hold 0)")
     names = [n for n, v in rows[0][3].items() if v >= 1.0]
     print("schedule hold " + " ".join(f"{n[:22]:>22s}" for n in names))
     for sched, k, m, pr in rows:
-        print(f"{sched:11s} {k:4d} " + " ".join(f"{pr.get(n, 0.0):22.2f}" for n in names))
+        print(f"{sched:15s} {k:4d} " + " ".join(f"{pr.get(n, 0.0):22.2f}" for n in names))
     print(json.dumps({"rows": [{"schedule": s, "hold": k, "ms": m, "kernels": pr} for s, k, m, pr in rows]}))
 
 
