@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; O=gpurun_out; mkdir -p $O
+for L in conv1_2 conv3_2; do
+python tools/exp/wino4_bench.py --only4 --p --stamps --n 16 --layers $L --lib tools/exp/_bin/libptmi355_wino4p_epistamp2.so
+done > $O/r06_wino4p_epi_stamps_twice.txt 2>&1
+cat $O/r06_wino4p_epi_stamps_twice.txt | cut -c1-250

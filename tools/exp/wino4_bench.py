@@ -53,7 +53,7 @@ def main():
             y = torch.empty(a.n, cout, h, w, device="cuda:0")
             fwd = getattr(lib, f"ptmi_conv3x3_{kind}_fwd")
 
-            tr = torch.zeros(8 * 64, dtype=torch.int64, device="cuda:0")
+            tr = torch.zeros(8 * 64 + 16 * 64, dtype=torch.int64, device="cuda:0")
 
             def f():
                 rc = fwd(vp(x.data_ptr()), vp(wp.data_ptr()), vp(b.data_ptr()), vp(tr.data_ptr() if a.stamps else x.data_ptr()), vp(y.data_ptr()),
@@ -92,7 +92,8 @@ def main():
                     msd = min(msd, e0.elapsed_time(e1) / a.iters)
                 line += f"  wino4 dynamic: {msd:7.3f} ms (x{msd / ms:.3f} of static; equal {bool(torch.equal(y, y_static))})"
             if a.stamps and kind in ("wino4", "wino4p") and (kind == "wino4p" or not a.p):
-                t = tr.cpu().view(64, 8).tolist()
+                t = tr.cpu()[:512].view(64, 8).tolist()
+                te = tr.cpu()[512:].view(64, 16).tolist()
                 last = max(k for k in range(64) if t[k][0])
                 if last > 2:
                     print(f"   shader clock over tiles 1 .. {last}: {(t[last][0] - t[1][0]) / (t[last][5] - t[1][5]) * 100:.0f} MHz "
@@ -101,6 +102,9 @@ def main():
                     if t[k][4] and t[k + 1][0]:
                         print(f"   tile {k}: zero-init {t[k][1]-t[k][0]}  chunk loop {t[k][2]-t[k][1]} ({(t[k][2]-t[k][1]) / (cin // 4):.0f} per chunk)  "
                               f"vmcnt(0) {t[k][3]-t[k][2]}  epilogue {t[k][4]-t[k][3]}  to next tile {t[k+1][0]-t[k][4]}  total {t[k+1][0]-t[k][0]}")
+                        if te[k][8]:   # tools/exp/make_wino4p_epi_stamps.py: inside the epilogue
+                            print(f"      epilogue: entry -> first send {te[k][8]-t[k][3]}  send {te[k][9]-te[k][8]}  channels "
+                                  f"{[te[k][0]-te[k][9]] + [te[k][c]-te[k][c-1] for c in range(1, 8)]}  closing barrier {t[k][4]-te[k][7]}")
             line += f"  {kind}: {ms:7.3f} ms {fl / ms / 1e9:6.1f} TF/s direct-eq"
         if "wino4p" in outs and "wino4" in outs:
             d = (outs["wino4p"][0] - outs["wino4"][0]).abs().max().item()
