@@ -103,6 +103,9 @@ __device__ __forceinline__ void xout(const float (&m)[6], float (&y)[4])
 // the MFMAs: accumulator tile in AGPRs ("a") or VGPRs ("v")
 __device__ __forceinline__ void xmfma_a(f32x4& c, float a, float b) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b)); }
 __device__ __forceinline__ void xmfma_v(f32x4& c, float a, float b) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); }
+// the same with C = 0 (a tile's FIRST chunk: every accumulator tile is written exactly once per chunk, so the tile needs no zeroing pass)
+__device__ __forceinline__ void xmfma_a0(f32x4& c, float a, float b) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b)); }
+__device__ __forceinline__ void xmfma_v0(f32x4& c, float a, float b) { asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b)); }
 
 template <int... I, class F>
 __device__ __forceinline__ void xfor(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
@@ -539,8 +542,9 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
         const f32x2 t2 = *(const volatile xlds_f32x2_t*)p;
         return (f32x4){t2[0], t2[1], 0.f, 0.f};
     };
-    auto chunk = [&](auto par_c) __attribute__((always_inline)) {
+    auto chunk = [&](auto par_c, auto first_c) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;       // the tile's first chunk: MFMAs with C = 0
         float(&Vc)[3][6] = PAR ? V1 : V0;
         float(&Vn)[3][6] = PAR ? V0 : V1;
         const float* ap_lo = ldsU + uo0 + a_lo;
@@ -570,8 +574,8 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
             constexpr int S = decltype(s_c)::value;
             constexpr int hg = y_hg(S), q = y_q(S), g = hg < 16 ? hg >> 2 : 4, ct = hg < 16 ? hg & 3 : hg - 16, p = 4 * g + q;
             const float av = A[hg & 3][q], bvv = Vc[p / 6][p % 6];
-            if constexpr (p < 16) xmfma_a(accA[4 * p + ct], av, bvv);   // [x4:mf]
-            else xmfma_v(accV[4 * (p - 16) + ct], av, bvv);   // [x4:mf]
+            if constexpr (p < 16) { if constexpr (FIRST) xmfma_a0(accA[4 * p + ct], av, bvv); else xmfma_a(accA[4 * p + ct], av, bvv); }   // [x4:mf]
+            else { if constexpr (FIRST) xmfma_v0(accV[4 * (p - 16) + ct], av, bvv); else xmfma_v(accV[4 * (p - 16) + ct], av, bvv); }   // [x4:mf]
             if constexpr (q == 1) {                          // group hg + 2 (of this chunk, or 0 / 1 of the next one)
                 constexpr int h2 = hg + 2, hh = h2 % 20;
                 constexpr int g2 = hh < 16 ? hh >> 2 : 4, c2 = hh < 16 ? hh & 3 : hh - 16;
@@ -821,15 +825,7 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
 
     for (;;) {
         // [x4@t0]
-        // the accumulators: zeroed while the first tile's first pieces are in flight / the previous tile's stores leave
-        xfor(std::make_integer_sequence<int, 64>{}, [&](auto i_c) __attribute__((always_inline)) {
-            accA[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            asm volatile("" : "+a"(accA[decltype(i_c)::value]));
-        });
-        xfor(std::make_integer_sequence<int, 8>{}, [&](auto i_c) __attribute__((always_inline)) {
-            accV[decltype(i_c)::value] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            asm volatile("" : "+v"(accV[decltype(i_c)::value]));
-        });
+        // (no zeroing pass: the tile's first chunk issues its MFMAs with C = 0)
         if (first) {
             first = false;
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XDI) : "memory");
@@ -846,9 +842,11 @@ __global__ __launch_bounds__(XNT, 1) void conv3x3_wino4p_kernel(
             A[1] = *(const volatile xlds_f32x4_t*)(ldsU + a_lo + 64);
         }
         // [x4@t1]
-        for (int c = 0; c < nChunks; c += 2) {              // nChunks is even (launcher: Cin % 8 == 0)
-            chunk(std::integral_constant<int, 0>{});
-            chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 0>{}, std::true_type{});         // (writes every accumulator tile: C = 0)
+        chunk(std::integral_constant<int, 1>{}, std::false_type{});
+        for (int c = 2; c < nChunks; c += 2) {              // nChunks is even and >= 2 (launcher: Cin % 8 == 0, Cin >= 8)
+            chunk(std::integral_constant<int, 0>{}, std::false_type{});
+            chunk(std::integral_constant<int, 1>{}, std::false_type{});
         }
         // [x4@t2]
         // the last chunk's own DMA instructions (the next tile's chunk 1 slab / chunk 2 patch): with them done, nothing the next
