@@ -1,4 +1,4 @@
-"""Randomised soak of the two F(4x4,3x3) kernels (csrc/wino4.hip, csrc/wino4w.hip) against the direct kernels of the same
+"""Randomised soak of the F(4x4,3x3) kernels (the default forward / dgrad family -- csrc/wino4p.hip since round 6, both tile schedules -- and csrc/wino4w.hip) against the direct kernels of the same
 library: random shapes (channel counts, map sizes incl. maps much smaller / larger than a workgroup tile, image counts that
 make a persistent workgroup walk several tiles), every epilogue, forward and dgrad packs, the weight gradient; every launch is
 issued TWICE and the two results must be bitwise equal (a race in the chunk stream would show as run-to-run differences long
@@ -53,7 +53,11 @@ def fwd_case(rng, gen):
     what = f"fwd mode {mode} epi {epi} n {n} cin {cin} cout {cout} h {h} w {w}"
     assert ops._conv_kind(cin, cout, (h, w)) == "wino4", what
 
+    sched = rng.choice(["static", "dynamic"])        # round 6: both tile schedules of the default family (ops._WINO4_FAMILY: wino4p)
+    what += f" schedule {sched}"
+
     def run():
+        ops.set_tile_schedule(sched)
         wp = ops.conv3x3_pack(wt, mode, epi, (h, w))
         if epi == 4:
             return ops.conv3x3_relu_pool_nograd(x, wt, bias)
@@ -63,6 +67,7 @@ def fwd_case(rng, gen):
     if not torch.equal(a, b):
         return what + f": two launches differ (max {float((a - b).abs().max()):.3e})"
     ref = direct(run)
+    ops.set_tile_schedule("static")
     e = rel_err(a, ref)
     if not (e <= 1e-4):
         return what + f": max err / max |ref| = {e:.3e}"
