@@ -20,6 +20,11 @@ from .flat import BucketedGradReducer, FlatParams, broadcast_
 
 
 class PTrainer:
+    @staticmethod
+    def ddp_wgrad_waves(amp: bool) -> int:
+        """weight-gradient waves PTrainer selects while a gradient exchange is active"""
+        return 2 if amp else 3
+
     def __init__(self, cfg, data_loader=None, ratio_fn: Optional[Callable[[], float]] = None,
                  force_grad_reducer: bool = False, grad_reduce: str = "all_reduce"):
         """force_grad_reducer: run the bucketed gradient all-reduce (hooks + collectives) even with one rank -- needs an
@@ -50,9 +55,11 @@ class PTrainer:
         # CU sharing with the collectives (tools/exp/contention.py): with the gradient exchange active its kernels hold CUs
         # while backward runs -- the persistent convolution then draws its tiles from work queues, and the weight-gradient kernels
         # launch several waves of shorter workgroups, so that a held CU costs its share instead of a second pass.  On one GPU the
-        # static walk / one workgroup per CU is 0.5 - 3 % faster
+        # static walk / one workgroup per CU is 0.5 - 3 % faster.  Waves chosen by profiles/r06_contention_waves_1_to_4.txt /
+        # r06_contention_amp_waves_1_to_4.txt: fp32 3 (+1.4 % without contention, x1.13 with 8 CUs held; 4 costs +2.5 % for x1.10),
+        # bf16-storage kernels 2 (+1.2 %, and no worse under contention than 3 or 4)
         ops.set_tile_schedule("dynamic" if self.reducer.active else "static")
-        ops.set_wgrad_waves(4 if self.reducer.active else 1)
+        ops.set_wgrad_waves(self.ddp_wgrad_waves(bool(cfg.SOLVER.AMP.ENABLED)) if self.reducer.active else 1)
         ops.set_p8_conv_waves(16 if self.reducer.active else 1)       # (SOLVER.AMP.ENABLED: the bf16-storage convolution, persistent too)
         self._first_step = True
         self.joint_student_pass = True      # one backbone pass for the two student branches when they share a canvas

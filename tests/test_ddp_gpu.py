@@ -55,11 +55,12 @@ def test_bucketed_rccl_allreduce_in_run_step_is_bitwise_identity(rccl_world1, mo
         ratios = iter([0.8, 0.6, 0.9, 0.7, 0.75, 0.65, 0.85, 0.55] * 2)
         tr = PTrainer(cfg, ratio_fn=lambda: next(ratios), force_grad_reducer=force, grad_reduce=mode)
         assert tr.reducer.active == force and len(tr.reducer.buckets) >= 4
-        # PTrainer picks the kernel policy by `reducer.active` (dynamic tile schedule + 4 weight-gradient waves under an exchange:
+        # PTrainer picks the kernel policy by `reducer.active` (dynamic tile schedule + 3 weight-gradient waves under an exchange:
         # the split partial sums then associate differently); "the exchange is a bitwise identity" is a statement at EQUAL policy
-        assert (ops._TILE_SCHEDULE, ops._WGRAD_WAVES) == (("dynamic", 4) if force else ("static", 1))
+        waves = PTrainer.ddp_wgrad_waves(False)
+        assert waves == 3 and (ops._TILE_SCHEDULE, ops._WGRAD_WAVES) == (("dynamic", waves) if force else ("static", 1))
         ops.set_tile_schedule("dynamic")
-        ops.set_wgrad_waves(4)
+        ops.set_wgrad_waves(waves)
         gen = torch.Generator().manual_seed(77)
         keyg = torch.Generator().manual_seed(5)
         sampling.set_key_source(lambda labels, sizes, bg: torch.rand(labels.shape, generator=keyg))

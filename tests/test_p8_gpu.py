@@ -220,7 +220,7 @@ def test_p8_wgrad_full_size_layers(name, cin, cout, h, w):
     assert float((db.cpu() - br.grad).abs().max()) <= 1e-4 * sb, f"{name} db"
 
 
-@pytest.mark.parametrize("waves", [4, 16, 64])
+@pytest.mark.parametrize("waves", [2, 4, 16, 64])      # weight gradient: min(waves, 16); 2 = PTrainer.ddp_wgrad_waves(True)
 def test_p8_conv_and_wgrad_waves_entry_points(waves):
     """round 6: ptmi_p8_conv3x3_waves -- more, shorter persistent workgroups (what PTrainer selects under DDP with SOLVER.AMP.ENABLED) --
     gives the one-fill kernel's output BIT FOR BIT (a tile's arithmetic does not depend on which workgroup computes it), every epilogue;

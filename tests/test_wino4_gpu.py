@@ -282,7 +282,7 @@ def ctypes_stream(s):
 
 
 @pytest.mark.parametrize("name", ["ptmi_conv3x3_wino4_wgrad", "ptmi_conv3x3_wino_wgrad"])
-@pytest.mark.parametrize("waves", [1, 4, 16])
+@pytest.mark.parametrize("waves", [1, 3, 4, 16])      # 3: PTrainer.ddp_wgrad_waves(False)
 def test_wgrad_waves_entry_points(name, waves):
     """round 6: the Winograd-domain weight-gradient kernels with `waves` fills of the chip (what PTrainer selects under DDP): same
     result as one fill up to the summation order of the split partials (1e-4 of the scale vs float64 torch; bitwise repeatable)"""
